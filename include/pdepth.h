@@ -1,0 +1,145 @@
+/*
+ * pdepth.h -- C ABI of the MI355X (gfx950) plane-sweep / DPV hot path.
+ *
+ * Drop-in boundary for soulslicer/probabilistic-depth.  The reference has no FFI on this
+ * path: its boundary is a set of Python functions built from ATen ops.  Every entry point
+ * below replaces one of them (reference file:line cited per function); the Python host
+ * package binds this header with ctypes (probabilistic-depth_amd/_native.py) and
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions (all entry points)
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless a stride argument says
+ *     otherwise; strides are in ELEMENTS (floats);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); launches are
+ *     asynchronous, no host synchronisation, no allocation -- callers own all buffers
+ *     (mirrors the reference's native op: models/correlation_package/correlation_cuda.cc:36-42,76);
+ *   - return value 0 = launched, non-zero = PDEPTH_E_* and nothing was launched; the text
+ *     is available from pdepth_last_error() (thread local).  Mirrors the reference's
+ *     "kernel launcher returns 0/1, wrapper raises" convention
+ *     (models/correlation_package/correlation_cuda_kernel.cu:383-392, correlation_cuda.cc:81-83);
+ *   - arithmetic type is fp32 throughout (d_candi is float64 on the
+ *     host and cast to fp32 at use, warping/homography.py:115, utils/img_utils.py:58).
+ */
+#ifndef PDEPTH_H_
+#define PDEPTH_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDEPTH_ABI_VERSION 1
+
+enum {
+    PDEPTH_OK = 0,
+    PDEPTH_E_ARG = 1,       /* bad shape / null pointer / unsupported value      */
+    PDEPTH_E_LAUNCH = 2,    /* hipGetLastError() after launch was not success   */
+    PDEPTH_E_WORKSPACE = 3  /* workspace too small for the requested algorithm  */
+};
+
+/* feature distance, warping/homography.py:128-133 ('L2' | 'L1', anything else raises) */
+enum { PDEPTH_METRIC_L2 = 0, PDEPTH_METRIC_L1 = 1 };
+
+/* algorithm selector for the sweep kernels */
+enum {
+    PDEPTH_ALGO_AUTO = 0,   /* fastest algorithm valid for the given geometry          */
+    PDEPTH_ALGO_DIRECT = 1  /* per-plane bilinear gather, reference op order (any pose) */
+};
+
+/* Geometry + layout of one batched sweep call. */
+typedef struct pdepth_sweep_desc {
+    int32_t B;           /* batch items (depth volumes)                                 */
+    int32_t V;           /* source views per item (reference view excluded)             */
+    int32_t C;           /* feature channels (67 = 64 learned + 3 rgb, models.py:518-520)*/
+    int32_t D;           /* depth planes                                                */
+    int32_t H, W;        /* sweep resolution                                            */
+    int32_t metric;      /* PDEPTH_METRIC_*                                             */
+    int32_t algo;        /* PDEPTH_ALGO_*                                               */
+    float sigma;         /* costV_sigma (cfg.var.sigma_soft_max, 10.0)                  */
+    int64_t ref_bstride; /* elements between ref[b] and ref[b+1]   (>= C*H*W)           */
+    int64_t src_bstride; /* elements between src[b,0] and src[b+1,0]                    */
+    int64_t src_vstride; /* elements between src[b,v] and src[b,v+1] (>= C*H*W)         */
+} pdepth_sweep_desc;
+
+/* Camera of one batched sweep call (all device pointers). */
+typedef struct pdepth_camera {
+    const float *K;     /* [B,3,3]   intrinsic_M_cuda             (models.py:537)        */
+    const float *R;     /* [B,V,3,3] src_cam_poses[b,v,:3,:3]     (models.py:530)        */
+    const float *t;     /* [B,V,3]   src_cam_poses[b,v,:3,3]      (models.py:531)        */
+    const float *rays;  /* [B,3,H*W] unit_ray_array_2D, col=y*W+x (models.py:539)        */
+    const float *cxcy;  /* [B,2]     float32(intrinsic_M[0,2]), float32(intrinsic_M[1,2])
+                                     (warping/homography.py:194)                         */
+} pdepth_camera;
+
+int pdepth_abi_version(void);
+const char *pdepth_last_error(void);
+
+/*
+ * Plane-sweep cost volume.  Replaces est_swp_volume_v4 (warping/homography.py:98-135) +
+ * _back_warp_homo_parallel (:170-198) + img_dis_L2_pard/img_dis_L1_pard (:80-86), batched
+ * over the Python loop at models/models.py:528-550.
+ *   ref  [B,C,H,W] (ref_bstride), src [B,V,C,H,W] (src_bstride/src_vstride), d_candi [D]
+ *   cost [B,D,H,W] contiguous, fully overwritten:
+ *   cost[b,k,y,x] = sum_v ( sum_c dist(warp_{v,k}(src)[c,y,x], ref[c,y,x]) / sigma )
+ */
+int pdepth_sweep_cost_f32(const pdepth_sweep_desc *desc, const pdepth_camera *cam,
+                          const float *ref, const float *src, const float *d_candi,
+                          float *cost, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Fused sweep + DPV reduction: cost -> log_softmax over D -> E[d].  Replaces the chain
+ * est_swp_volume_v4 -> F.log_softmax(dim=1) (models/packnet.py:380-394) ->
+ * dpv_to_depthmap(BV_log=True) (utils/img_utils.py:52-61) without writing the cost volume.
+ *   cost  [B,D,H,W] or NULL     (un-normalised cost, as pdepth_sweep_cost_f32)
+ *   logp  [B,D,H,W] or NULL     (log DPV)
+ *   depth [B,H,W]   or NULL     (expected depth)
+ * At least one output must be non-NULL.
+ */
+int pdepth_sweep_dpv_f32(const pdepth_sweep_desc *desc, const pdepth_camera *cam,
+                         const float *ref, const float *src, const float *d_candi,
+                         float *cost, float *logp, float *depth,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* Bytes of scratch the two sweep entry points need for `desc` (0 for ALGO_DIRECT). */
+size_t pdepth_sweep_workspace_bytes(const pdepth_sweep_desc *desc);
+
+/*
+ * DPV reduction: logits [B,D,H,W] -> logp [B,D,H,W] (may alias logits, may be NULL) and
+ * depth [B,H,W] (may be NULL).  Replaces F.log_softmax(x, dim=1) (models/models.py:560,637,
+ * 694, :351) followed by dpv_to_depthmap(., BV_log=True) (utils/img_utils.py:52-61;
+ * trainer/default_trainer.py:229-233) in one pass over the logits.
+ */
+int pdepth_dpv_reduce_f32(const float *logits, const float *d_candi, int32_t B, int32_t D,
+                          int32_t H, int32_t W, float *logp, float *depth, void *stream);
+
+/*
+ * Expectation only: depth[b,y,x] = sum_k d_k * (bv_log ? exp(dpv[b,k,y,x]) : dpv[b,k,y,x]).
+ * Replaces dpv_to_depthmap (utils/img_utils.py:52-61), batched over B.
+ */
+int pdepth_dpv_expect_f32(const float *dpv, const float *d_candi, int32_t B, int32_t D,
+                          int32_t H, int32_t W, int32_t bv_log, float *depth, void *stream);
+
+/*
+ * Diagonal feature warp: out[b,v,i,y,x] = bilinear(src[b,v,i,:,:]) sampled with the
+ * plane-i homography of view v.  Replaces warp_feature (warping/homography.py:137-168),
+ * which warps all D x C planes and keeps [i,i]; requires C == D.
+ *   desc->C must equal desc->D; desc->V counts ALL views passed (reference view included,
+ *   models/models.py:616-617); src [B,V,D,H,W] via src_bstride/src_vstride; out contiguous.
+ */
+int pdepth_warp_feature_f32(const pdepth_sweep_desc *desc, const pdepth_camera *cam,
+                            const float *src, const float *d_candi, float *out, void *stream);
+
+/*
+ * Sampling coordinates only (diagnostic, used by the parity tests to pin the coordinate
+ * pipeline bit-for-bit): ix, iy [B,V,D,H,W] = un-normalised pixel coordinates handed to the
+ * bilinear sampler (warping/homography.py:185-196 + ATen grid_sampler unnormalize).
+ */
+int pdepth_sample_coords_f32(const pdepth_sweep_desc *desc, const pdepth_camera *cam,
+                             const float *d_candi, float *ix, float *iy, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDEPTH_H_ */

@@ -1,0 +1,193 @@
+"""CPU oracle for the plane-sweep / DPV hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This module is a from-scratch CPU restatement (plain torch fp32 ops, CPU tensors)
+of the reference algorithm.  It exists so that the HIP kernels can be checked
+against the reference's PyTorch-CPU numerics on a machine where the reference
+itself is absent (the GPU box).  Only ``tests/``, ``__graft_entry__.smoke()``
+and the ``cpu_baseline`` leg of ``bench.py`` may import it; the product package
+(``probabilistic-depth_amd``) never does, and has no CPU fallback.
+
+Parity pin: ``tests/golden/make_golden.py`` imports the real reference from
+``/root/reference`` (build container only) and stores its outputs; the
+``-m "not gpu"`` suite asserts this restatement reproduces those fixtures
+bit-for-bit (same ATen ops in the same order => identical rounding).
+
+Every function cites the reference lines it restates (paths relative to the
+reference checkout).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+__all__ = [
+    "powerf", "unit_rays", "intrinsics_from_fov", "plane_coords", "sweep_cost",
+    "warp_feature", "log_dpv", "dpv_to_depthmap", "sweep_dpv", "sample_coords",
+]
+
+
+# --------------------------------------------------------------------------------------
+# host-side producers
+# --------------------------------------------------------------------------------------
+def powerf(d_min, d_max, n_depth, power):
+    """Depth candidates, float64.  utils/img_utils.py:80-85."""
+    q = np.power(np.linspace(start=0, stop=1, num=n_depth), power)
+    return np.array([d_min + (d_max - d_min) * v for v in q])
+
+
+def unit_rays(width, height, hfov, vfov):
+    """z=1 rays, [3, h*w] fp32, column index y*w+x.
+
+    warping/view.py:16-30 (per pixel formula), :32-62 (table),
+    kittiloader/kitti.py:311-312 (transpose/reshape/cast).
+    The reference fills the table with a Python double loop in float64; the
+    expression below evaluates the identical float64 formula per element.
+    """
+    th = math.tan(math.radians(hfov / 2.0))
+    tv = math.tan(math.radians(vfov / 2.0))
+    rays = np.zeros((height, width, 3))
+    for y in range(height):
+        yv = tv * ((2.0 * ((y + 0.5) / height)) - 1.0)
+        for x in range(width):
+            rays[y, x, 0] = th * ((2.0 * ((x + 0.5) / width)) - 1.0)
+            rays[y, x, 1] = yv
+            rays[y, x, 2] = 1.0
+    flat = np.reshape(np.transpose(rays, axes=[2, 0, 1]), [3, -1])
+    return torch.from_numpy(flat.astype(np.float32))
+
+
+def intrinsics_from_fov(width, height, hfov, vfov):
+    """KITTI-branch intrinsics at the sweep resolution, float64 3x3.
+
+    kittiloader/kitti.py:284-293.
+    """
+    K = np.zeros((3, 3))
+    K[2, 2] = 1.0
+    K[0, 0] = (width / 2.0) / math.tan(math.radians(hfov / 2.0))
+    K[0, 2] = width / 2.0
+    K[1, 1] = (height / 2.0) / math.tan(math.radians(vfov / 2.0))
+    K[1, 2] = height / 2.0
+    return K
+
+
+# --------------------------------------------------------------------------------------
+# sweep geometry
+# --------------------------------------------------------------------------------------
+def plane_coords(K, R_v, t_v, rays, d_candi_f32, cx, cy):
+    """Normalised sampling grid [D, hw, 2] for one source view.
+
+    warping/homography.py:119-121 (term1/term2, note (K@R)@rays association),
+    :185-196 (P = term1 + term2*d; P/(Pz+1e-10); (u-cx)/cx, (v-cy)/cy).
+    """
+    term1 = K.matmul(t_v).reshape(3, 1)
+    term2 = K.matmul(R_v).matmul(rays)
+    n_d = d_candi_f32.shape[0]
+    P = term1.unsqueeze(0) + term2.repeat(n_d, 1, 1) * d_candi_f32.reshape(n_d, 1, 1)
+    P = P / (P[:, 2, :].unsqueeze(1) + 1e-10)
+    gx = (P[:, 0, :] - cx) / cx
+    gy = (P[:, 1, :] - cy) / cy
+    return torch.stack((gx, gy), dim=-1)
+
+
+def sample_coords(K, R_v, t_v, rays, d_candi, cx, cy, h, w):
+    """Un-normalised pixel coordinates (ix, iy) [D, hw] that grid_sample uses.
+
+    ATen CPU vectorised grid_sampler_2d, align_corners=False
+    (ATen/native/cpu/GridSamplerKernel.cpp ComputeLocation::unnormalize):
+    ix = (gx + 1) * (w / 2) - 0.5, which the build contracts into ONE fma (pinned by
+    tests/test_coords_pin.py against F.grid_sample itself).  The fma is evaluated here
+    through float64 (exact product, one rounding of the sum, then the cast).
+    Used by tests to check a kernel's sample positions; not part of the reference's surface.
+    """
+    d32 = torch.from_numpy(np.asarray(d_candi).astype(np.float32))
+    g = plane_coords(K, R_v, t_v, rays, d32, cx, cy)
+    ix = ((g[..., 0] + 1).double() * (w / 2) - 0.5).float()
+    iy = ((g[..., 1] + 1).double() * (h / 2) - 0.5).float()
+    return ix, iy
+
+
+def _warp_all_planes(src_view, d_candi_f32, K, R_v, t_v, rays, cx, cy, h, w):
+    """Bilinear warp of one source view into every depth plane -> [D, C, h, w].
+
+    warping/homography.py:123 (repeat over D), :170-198 (_back_warp_homo_parallel;
+    grid_sample bilinear / zeros / default align_corners=False).
+    """
+    n_d = d_candi_f32.shape[0]
+    grid = plane_coords(K, R_v, t_v, rays, d_candi_f32, cx, cy).reshape(n_d, h, w, 2)
+    stacked = src_view.repeat(n_d, 1, 1, 1)
+    return F.grid_sample(stacked, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+
+
+def sweep_cost(feat_ref, feat_src, d_candi, R, t, K, rays, cx, cy, sigma, metric="L2"):
+    """Plane-sweep cost volume of ONE batch item -> [1, D, h, w].
+
+    warping/homography.py:98-135 (est_swp_volume_v4), :80-86 (L2 / L1 distance).
+    feat_ref [1,C,h,w]; feat_src [1,V,C,h,w]; R [V,3,3]; t [V,3]; K [3,3] fp32 tensor;
+    rays [3,hw]; cx, cy = np.float32 principal point read from the numpy copy of K
+    (models/models.py:538).
+    """
+    h, w = feat_ref.shape[2], feat_ref.shape[3]
+    d32 = torch.from_numpy(np.asarray(d_candi).astype(np.float32))
+    cost = torch.zeros(1, d32.shape[0], h, w)
+    for v in range(feat_src.shape[1]):
+        warped = _warp_all_planes(feat_src[:, v], d32, K, R[v], t[v], rays, cx, cy, h, w)
+        if metric == "L2":
+            dist = torch.sum((warped - feat_ref) ** 2, 1)
+        elif metric == "L1":
+            dist = torch.sum(torch.abs(warped - feat_ref), 1)
+        else:
+            raise Exception("undefined metric for feature distance ...")
+        cost[0] = cost[0] + dist / sigma
+    return cost
+
+
+def warp_feature(feat_src, d_candi, R, t, K, rays, cx, cy):
+    """Channel i of every view warped with depth plane i -> [1, V, D, h, w].
+
+    warping/homography.py:137-168: the reference warps all D x C planes and keeps
+    the diagonal [i, i]; restated the same (wasteful) way so rounding is identical.
+    """
+    if feat_src.shape[0] != 1:
+        raise Exception("Warped Accum Error")
+    h, w = feat_src.shape[3], feat_src.shape[4]
+    d32 = torch.from_numpy(np.asarray(d_candi).astype(np.float32))
+    out = torch.zeros(feat_src.shape)
+    for v in range(feat_src.shape[1]):
+        warped = _warp_all_planes(feat_src[:, v], d32, K, R[v], t[v], rays, cx, cy, h, w)
+        idx = torch.arange(d32.shape[0])
+        out[0, v] = warped[idx, idx]
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# DPV reduction
+# --------------------------------------------------------------------------------------
+def log_dpv(logits):
+    """log-softmax over the depth axis.  models/models.py:560,637,694; packnet.py:394."""
+    return F.log_softmax(logits, dim=1)
+
+
+def dpv_to_depthmap(dpv, d_candi, BV_log=False):
+    """E[d] over the depth axis of a [1,D,H,W] DPV -> [1,H,W].  utils/img_utils.py:52-61."""
+    if dpv.shape[0] != 1:
+        raise Exception("Unable to handle this case")
+    z = dpv.squeeze(0)
+    if BV_log:
+        z = torch.exp(z)
+    d = torch.tensor(d_candi).unsqueeze(1).unsqueeze(1).float()
+    return torch.sum(d * z, dim=0).unsqueeze(0)
+
+
+def sweep_dpv(feat_ref, feat_src, d_candi, R, t, K, rays, cx, cy, sigma, metric="L2"):
+    """cost -> log-DPV -> depth for one item (the PackNet-style fusable chain).
+
+    models/packnet.py:380-394 (log_softmax straight on the cost volume) followed by
+    trainer/default_trainer.py:232 (dpv_to_depthmap(..., BV_log=True)).
+    Returns (cost [1,D,h,w], logp [1,D,h,w], depth [1,h,w]).
+    """
+    cost = sweep_cost(feat_ref, feat_src, d_candi, R, t, K, rays, cx, cy, sigma, metric)
+    logp = log_dpv(cost)
+    return cost, logp, dpv_to_depthmap(logp, d_candi, BV_log=True)

@@ -1,0 +1,242 @@
+"""ctypes binding of the C ABI in include/pdepth.h (libpdepth_hip.so, built in-tree).
+
+The product path has NO CPU fallback: if the shared library is missing or a tensor is not
+a contiguous fp32 device tensor, these wrappers raise.  torch is used only for device
+memory and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpdepth_hip.so")
+
+METRIC_L2, METRIC_L1 = 0, 1
+ALGO_AUTO, ALGO_DIRECT = 0, 1
+
+# every symbol include/pdepth.h declares (tests check the library exports all of them)
+EXPORTED_SYMBOLS = (
+    "pdepth_abi_version", "pdepth_last_error", "pdepth_sweep_workspace_bytes",
+    "pdepth_sweep_cost_f32", "pdepth_sweep_dpv_f32", "pdepth_dpv_reduce_f32",
+    "pdepth_dpv_expect_f32", "pdepth_warp_feature_f32", "pdepth_sample_coords_f32",
+)
+
+
+class SweepDesc(Structure):
+    _fields_ = [
+        ("B", c_int32), ("V", c_int32), ("C", c_int32), ("D", c_int32), ("H", c_int32), ("W", c_int32),
+        ("metric", c_int32), ("algo", c_int32), ("sigma", c_float),
+        ("ref_bstride", c_int64), ("src_bstride", c_int64), ("src_vstride", c_int64),
+    ]
+
+
+class Camera(Structure):
+    _fields_ = [("K", c_void_p), ("R", c_void_p), ("t", c_void_p), ("rays", c_void_p), ("cxcy", c_void_p)]
+
+
+_lib = None
+
+
+def load():
+    """Load libpdepth_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C probabilistic-depth_amd/csrc)")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.pdepth_abi_version.restype = c_int
+    lib.pdepth_last_error.restype = c_char_p
+    lib.pdepth_sweep_workspace_bytes.restype = c_size_t
+    lib.pdepth_sweep_workspace_bytes.argtypes = [POINTER(SweepDesc)]
+    lib.pdepth_sweep_cost_f32.argtypes = [POINTER(SweepDesc), POINTER(Camera), c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.pdepth_sweep_dpv_f32.argtypes = [POINTER(SweepDesc), POINTER(Camera), c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.pdepth_dpv_reduce_f32.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                          c_void_p, c_void_p]
+    lib.pdepth_dpv_expect_f32.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                          c_void_p, c_void_p]
+    lib.pdepth_warp_feature_f32.argtypes = [POINTER(SweepDesc), POINTER(Camera), c_void_p, c_void_p, c_void_p,
+                                            c_void_p]
+    lib.pdepth_sample_coords_f32.argtypes = [POINTER(SweepDesc), POINTER(Camera), c_void_p, c_void_p, c_void_p,
+                                             c_void_p]
+    for fn in ("pdepth_sweep_cost_f32", "pdepth_sweep_dpv_f32", "pdepth_dpv_reduce_f32",
+               "pdepth_dpv_expect_f32", "pdepth_warp_feature_f32", "pdepth_sample_coords_f32"):
+        getattr(lib, fn).restype = c_int
+    if lib.pdepth_abi_version() != 1:
+        raise RuntimeError("libpdepth_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(rc, lib):
+    if rc != 0:
+        raise RuntimeError(lib.pdepth_last_error().decode())
+
+
+def _dev(t: torch.Tensor, name: str) -> int:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the HIP path needs a device tensor (got {t.device}); there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _inner_contiguous(t: torch.Tensor, n_inner: int) -> bool:
+    """True if the last n_inner dims are laid out densely (row-major)."""
+    exp = 1
+    for size, stride in zip(reversed(t.shape[-n_inner:]), reversed(t.stride()[-n_inner:])):
+        if size != 1 and stride != exp:
+            return False
+        exp *= size
+    return True
+
+
+def _camera(K, R, t, rays, cxcy, B, V, HW):
+    for nm, x, shape in (("K", K, (B, 3, 3)), ("R", R, (B, V, 3, 3)), ("t", t, (B, V, 3)),
+                         ("rays", rays, (B, 3, HW)), ("cxcy", cxcy, (B, 2))):
+        if tuple(x.shape) != shape:
+            raise RuntimeError(f"{nm}: expected shape {shape}, got {tuple(x.shape)}")
+    K, R, t, rays, cxcy = (x.contiguous() for x in (K, R, t, rays, cxcy))
+    cam = Camera(_dev(K, "K"), _dev(R, "R"), _dev(t, "t"), _dev(rays, "rays"), _dev(cxcy, "cxcy"))
+    return cam, (K, R, t, rays, cxcy)  # keep the contiguous copies alive
+
+
+def sweep(ref, src, K, R, t, rays, cxcy, d_candi, sigma, metric=METRIC_L2, algo=ALGO_AUTO,
+          want_cost=True, want_logp=False, want_depth=False):
+    """Batched plane sweep (+ optional fused DPV reduction).
+
+    ref [B,C,H,W], src [B,V,C,H,W] (batch/view strides free, inner C,H,W dense), K [B,3,3],
+    R [B,V,3,3], t [B,V,3], rays [B,3,HW], cxcy [B,2], d_candi [D] -- fp32 device tensors.
+    Returns (cost | None, logp | None, depth | None).
+    """
+    lib = load()
+    _dev(ref, "ref"), _dev(src, "src")
+    if ref.dim() != 4 or src.dim() != 5:
+        raise RuntimeError("sweep: ref must be [B,C,H,W] and src [B,V,C,H,W]")
+    B, C, H, W = ref.shape
+    V = src.shape[1]
+    if tuple(src.shape) != (B, V, C, H, W):
+        raise RuntimeError(f"sweep: src shape {tuple(src.shape)} does not match ref {tuple(ref.shape)}")
+    if not _inner_contiguous(ref, 3):
+        ref = ref.contiguous()
+    if not _inner_contiguous(src, 3):
+        src = src.contiguous()
+    d_candi = d_candi.contiguous()
+    D = d_candi.numel()
+    dev = ref.device
+    cam, keep = _camera(K, R, t, rays, cxcy, B, V, H * W)
+    desc = SweepDesc(B, V, C, D, H, W, int(metric), int(algo), float(sigma),
+                     ref.stride(0) if B > 1 else C * H * W,
+                     src.stride(0) if B > 1 else V * C * H * W,
+                     src.stride(1) if V > 1 else C * H * W)
+    ws_bytes = lib.pdepth_sweep_workspace_bytes(ctypes.byref(desc))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev) if ws_bytes else None
+    cost = torch.empty((B, D, H, W), dtype=torch.float32, device=dev) if want_cost else None
+    logp = torch.empty((B, D, H, W), dtype=torch.float32, device=dev) if want_logp else None
+    depth = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_depth else None
+    with torch.cuda.device(dev):
+        rc = lib.pdepth_sweep_dpv_f32(
+            ctypes.byref(desc), ctypes.byref(cam), _dev(ref, "ref"), _dev(src, "src"), _dev(d_candi, "d_candi"),
+            cost.data_ptr() if want_cost else None, logp.data_ptr() if want_logp else None,
+            depth.data_ptr() if want_depth else None, ws.data_ptr() if ws is not None else None, ws_bytes,
+            _stream(dev))
+    _check(rc, lib)
+    del keep
+    return cost, logp, depth
+
+
+def dpv_reduce(logits, d_candi, want_logp=True, want_depth=True, inplace=False):
+    """logits [B,D,H,W] -> (logp [B,D,H,W] | None, depth [B,H,W] | None)."""
+    lib = load()
+    _dev(logits, "logits")
+    if logits.dim() != 4:
+        raise RuntimeError("dpv_reduce: logits must be [B,D,H,W]")
+    logits = logits.contiguous()
+    B, D, H, W = logits.shape
+    d_candi = d_candi.contiguous()
+    if d_candi.numel() != D:
+        raise RuntimeError(f"dpv_reduce: d_candi has {d_candi.numel()} entries, volume has D={D}")
+    dev = logits.device
+    logp = (logits if inplace else torch.empty_like(logits)) if want_logp else None
+    depth = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_depth else None
+    with torch.cuda.device(dev):
+        rc = lib.pdepth_dpv_reduce_f32(_dev(logits, "logits"), _dev(d_candi, "d_candi"), B, D, H, W,
+                                       logp.data_ptr() if want_logp else None,
+                                       depth.data_ptr() if want_depth else None, _stream(dev))
+    _check(rc, lib)
+    return logp, depth
+
+
+def dpv_expect(dpv, d_candi, bv_log):
+    """dpv [B,D,H,W] -> depth [B,H,W] = sum_k d_k * (exp(dpv) if bv_log else dpv)."""
+    lib = load()
+    _dev(dpv, "dpv")
+    if dpv.dim() != 4:
+        raise RuntimeError("dpv_expect: dpv must be [B,D,H,W]")
+    dpv = dpv.contiguous()
+    B, D, H, W = dpv.shape
+    d_candi = d_candi.contiguous()
+    if d_candi.numel() != D:
+        raise RuntimeError(f"dpv_expect: d_candi has {d_candi.numel()} entries, volume has D={D}")
+    depth = torch.empty((B, H, W), dtype=torch.float32, device=dpv.device)
+    with torch.cuda.device(dpv.device):
+        rc = lib.pdepth_dpv_expect_f32(_dev(dpv, "dpv"), _dev(d_candi, "d_candi"), B, D, H, W, int(bool(bv_log)),
+                                       depth.data_ptr(), _stream(dpv.device))
+    _check(rc, lib)
+    return depth
+
+
+def warp_feature(src, K, R, t, rays, cxcy, d_candi):
+    """src [B,V,D,H,W] -> out [B,V,D,H,W], channel i warped with depth plane i."""
+    lib = load()
+    _dev(src, "src")
+    if src.dim() != 5:
+        raise RuntimeError("warp_feature: src must be [B,V,D,H,W]")
+    B, V, C, H, W = src.shape
+    if not _inner_contiguous(src, 3):
+        src = src.contiguous()
+    d_candi = d_candi.contiguous()
+    D = d_candi.numel()
+    cam, keep = _camera(K, R, t, rays, cxcy, B, V, H * W)
+    desc = SweepDesc(B, V, C, D, H, W, 0, 0, 1.0, 0, src.stride(0) if B > 1 else V * C * H * W,
+                     src.stride(1) if V > 1 else C * H * W)
+    out = torch.empty((B, V, D, H, W), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        rc = lib.pdepth_warp_feature_f32(ctypes.byref(desc), ctypes.byref(cam), _dev(src, "src"),
+                                         _dev(d_candi, "d_candi"), out.data_ptr(), _stream(src.device))
+    _check(rc, lib)
+    del keep
+    return out
+
+
+def sample_coords(K, R, t, rays, cxcy, d_candi, H, W):
+    """Diagnostic: (ix, iy) [B,V,D,H,W] sample positions handed to the bilinear sampler."""
+    lib = load()
+    _dev(K, "K")
+    B, V = R.shape[0], R.shape[1]
+    d_candi = d_candi.contiguous()
+    D = d_candi.numel()
+    cam, keep = _camera(K, R, t, rays, cxcy, B, V, H * W)
+    desc = SweepDesc(B, V, 1, D, H, W, 0, 0, 1.0, 0, 0, H * W)
+    ix = torch.empty((B, V, D, H, W), dtype=torch.float32, device=K.device)
+    iy = torch.empty_like(ix)
+    with torch.cuda.device(K.device):
+        rc = lib.pdepth_sample_coords_f32(ctypes.byref(desc), ctypes.byref(cam), _dev(d_candi, "d_candi"),
+                                          ix.data_ptr(), iy.data_ptr(), _stream(K.device))
+    _check(rc, lib)
+    del keep
+    return ix, iy

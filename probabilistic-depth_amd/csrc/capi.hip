@@ -1,0 +1,145 @@
+// C ABI of the hot path (include/pdepth.h): argument validation + kernel dispatch.
+// No torch types, no allocation, no host synchronisation.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/pdepth.h"
+#include "kernels.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_desc(const pdepth_sweep_desc* d, const pdepth_camera* cam, const char* who) {
+    if (!d || !cam) return fail(PDEPTH_E_ARG, "%s: null descriptor", who);
+    if (d->B <= 0 || d->V <= 0 || d->C <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0)
+        return fail(PDEPTH_E_ARG, "%s: non-positive dimension B=%d V=%d C=%d D=%d H=%d W=%d", who,
+                    d->B, d->V, d->C, d->D, d->H, d->W);
+    if ((long long)d->H * d->W > (1ll << 30))
+        return fail(PDEPTH_E_ARG, "%s: H*W too large", who);
+    if (!cam->K || !cam->R || !cam->t || !cam->rays || !cam->cxcy)
+        return fail(PDEPTH_E_ARG, "%s: null camera pointer", who);
+    const long long chw = (long long)d->C * d->H * d->W;
+    if (d->src_vstride < chw || d->src_bstride < 0 || d->ref_bstride < 0)
+        return fail(PDEPTH_E_ARG, "%s: bad strides", who);
+    return PDEPTH_OK;
+}
+
+pdepth::SweepArgs make_args(const pdepth_sweep_desc* d, const pdepth_camera* cam, const float* ref,
+                            const float* src, const float* d_candi) {
+    pdepth::SweepArgs a{};
+    a.ref = ref; a.src = src;
+    a.K = cam->K; a.R = cam->R; a.t = cam->t; a.rays = cam->rays; a.cxcy = cam->cxcy;
+    a.d_candi = d_candi;
+    a.B = d->B; a.V = d->V; a.C = d->C; a.D = d->D; a.H = d->H; a.W = d->W;
+    a.metric = d->metric; a.sigma = d->sigma;
+    a.ref_bstride = d->ref_bstride; a.src_bstride = d->src_bstride; a.src_vstride = d->src_vstride;
+    return a;
+}
+
+int launched(hipError_t e, const char* who) {
+    if (e != hipSuccess) return fail(PDEPTH_E_LAUNCH, "%s: %s", who, hipGetErrorString(e));
+    return PDEPTH_OK;
+}
+
+int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const float* ref,
+                 const float* src, const float* d_candi, float* cost, float* logp, float* depth,
+                 void* stream, const char* who) {
+    if (int rc = check_desc(d, cam, who)) return rc;
+    if (!ref || !src || !d_candi) return fail(PDEPTH_E_ARG, "%s: null input pointer", who);
+    if (!cost && !logp && !depth) return fail(PDEPTH_E_ARG, "%s: no output requested", who);
+    if (d->metric != PDEPTH_METRIC_L2 && d->metric != PDEPTH_METRIC_L1)
+        return fail(PDEPTH_E_ARG, "%s: undefined metric for feature distance (%d)", who, d->metric);
+    if (d->algo != PDEPTH_ALGO_AUTO && d->algo != PDEPTH_ALGO_DIRECT)
+        return fail(PDEPTH_E_ARG, "%s: unknown algo %d", who, d->algo);
+    if (!(d->sigma > 0.0f) && !(d->sigma < 0.0f))
+        return fail(PDEPTH_E_ARG, "%s: sigma must be non-zero", who);
+    if (d->D > pdepth::sweep_direct_max_planes(d->C))
+        return fail(PDEPTH_E_ARG, "%s: D=%d exceeds the %d planes one launch supports at C=%d", who,
+                    d->D, pdepth::sweep_direct_max_planes(d->C), d->C);
+    pdepth::SweepArgs a = make_args(d, cam, ref, src, d_candi);
+    a.cost_out = cost; a.logp_out = logp; a.depth_out = depth;
+    return launched(pdepth::launch_sweep_direct(a, (hipStream_t)stream), who);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pdepth_abi_version(void) { return PDEPTH_ABI_VERSION; }
+const char* pdepth_last_error(void) { return g_err; }
+
+size_t pdepth_sweep_workspace_bytes(const pdepth_sweep_desc* desc) {
+    (void)desc;
+    return 0;
+}
+
+int pdepth_sweep_cost_f32(const pdepth_sweep_desc* desc, const pdepth_camera* cam, const float* ref,
+                          const float* src, const float* d_candi, float* cost, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    (void)workspace; (void)workspace_bytes;
+    if (!cost) return fail(PDEPTH_E_ARG, "pdepth_sweep_cost_f32: null output");
+    return sweep_common(desc, cam, ref, src, d_candi, cost, nullptr, nullptr, stream,
+                        "pdepth_sweep_cost_f32");
+}
+
+int pdepth_sweep_dpv_f32(const pdepth_sweep_desc* desc, const pdepth_camera* cam, const float* ref,
+                         const float* src, const float* d_candi, float* cost, float* logp,
+                         float* depth, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)workspace; (void)workspace_bytes;
+    return sweep_common(desc, cam, ref, src, d_candi, cost, logp, depth, stream,
+                        "pdepth_sweep_dpv_f32");
+}
+
+int pdepth_dpv_reduce_f32(const float* logits, const float* d_candi, int32_t B, int32_t D, int32_t H,
+                          int32_t W, float* logp, float* depth, void* stream) {
+    if (!logits || !d_candi) return fail(PDEPTH_E_ARG, "pdepth_dpv_reduce_f32: null input");
+    if (!logp && !depth) return fail(PDEPTH_E_ARG, "pdepth_dpv_reduce_f32: no output requested");
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0)
+        return fail(PDEPTH_E_ARG, "pdepth_dpv_reduce_f32: non-positive dimension");
+    return launched(pdepth::launch_dpv_reduce(logits, d_candi, B, D, H, W, logp, depth,
+                                              (hipStream_t)stream), "pdepth_dpv_reduce_f32");
+}
+
+int pdepth_dpv_expect_f32(const float* dpv, const float* d_candi, int32_t B, int32_t D, int32_t H,
+                          int32_t W, int32_t bv_log, float* depth, void* stream) {
+    if (!dpv || !d_candi || !depth) return fail(PDEPTH_E_ARG, "pdepth_dpv_expect_f32: null pointer");
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0)
+        return fail(PDEPTH_E_ARG, "pdepth_dpv_expect_f32: non-positive dimension");
+    return launched(pdepth::launch_dpv_expect(dpv, d_candi, B, D, H, W, bv_log, depth,
+                                              (hipStream_t)stream), "pdepth_dpv_expect_f32");
+}
+
+int pdepth_warp_feature_f32(const pdepth_sweep_desc* desc, const pdepth_camera* cam, const float* src,
+                            const float* d_candi, float* out, void* stream) {
+    if (int rc = check_desc(desc, cam, "pdepth_warp_feature_f32")) return rc;
+    if (!src || !d_candi || !out) return fail(PDEPTH_E_ARG, "pdepth_warp_feature_f32: null pointer");
+    if (desc->C != desc->D)
+        return fail(PDEPTH_E_ARG, "pdepth_warp_feature_f32: needs C == D (got C=%d D=%d)", desc->C, desc->D);
+    pdepth::SweepArgs a = make_args(desc, cam, nullptr, src, d_candi);
+    return launched(pdepth::launch_warp_feature(a, out, (hipStream_t)stream), "pdepth_warp_feature_f32");
+}
+
+int pdepth_sample_coords_f32(const pdepth_sweep_desc* desc, const pdepth_camera* cam,
+                             const float* d_candi, float* ix, float* iy, void* stream) {
+    if (!desc || !cam) return fail(PDEPTH_E_ARG, "pdepth_sample_coords_f32: null descriptor");
+    pdepth_sweep_desc d = *desc;
+    if (d.C <= 0) d.C = 1;
+    d.src_vstride = (long long)d.C * d.H * d.W;
+    if (int rc = check_desc(&d, cam, "pdepth_sample_coords_f32")) return rc;
+    if (!d_candi || !ix || !iy) return fail(PDEPTH_E_ARG, "pdepth_sample_coords_f32: null pointer");
+    pdepth::SweepArgs a = make_args(&d, cam, nullptr, nullptr, d_candi);
+    return launched(pdepth::launch_sample_coords(a, ix, iy, (hipStream_t)stream), "pdepth_sample_coords_f32");
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// Internal launch interface between the C ABI (capi.hip) and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace pdepth {
+
+// Flattened arguments of one sweep launch (device pointers, element strides).
+struct SweepArgs {
+    const float* ref;
+    const float* src;
+    const float* K;
+    const float* R;
+    const float* t;
+    const float* rays;
+    const float* cxcy;
+    const float* d_candi;
+    float* cost_out;   // [B,D,H,W] or nullptr
+    float* logp_out;   // [B,D,H,W] or nullptr
+    float* depth_out;  // [B,H,W]   or nullptr
+    int B, V, C, D, H, W;
+    int metric;
+    float sigma;
+    long long ref_bstride, src_bstride, src_vstride;
+};
+
+// sweep_direct.hip
+hipError_t launch_sweep_direct(const SweepArgs& a, hipStream_t stream);
+int sweep_direct_max_planes(int C);
+
+// dpv.hip
+hipError_t launch_dpv_reduce(const float* logits, const float* d_candi, int B, int D, int H,
+                             int W, float* logp, float* depth, hipStream_t stream);
+hipError_t launch_dpv_expect(const float* dpv, const float* d_candi, int B, int D, int H, int W,
+                             int bv_log, float* depth, hipStream_t stream);
+
+// warp.hip
+hipError_t launch_warp_feature(const SweepArgs& a, float* out, hipStream_t stream);
+hipError_t launch_sample_coords(const SweepArgs& a, float* ix, float* iy, hipStream_t stream);
+
+}  // namespace pdepth

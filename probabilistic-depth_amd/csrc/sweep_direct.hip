@@ -1,0 +1,135 @@
+// Direct plane-sweep kernel: per-plane bilinear gather in the reference's op order.
+//
+// Replaces est_swp_volume_v4 / _back_warp_homo_parallel / img_dis_L{1,2}_pard
+// (warping/homography.py:98-135, :170-198, :80-86) and, when logp/depth are requested, the
+// log_softmax + dpv_to_depthmap tail (models/packnet.py:394, utils/img_utils.py:52-61).
+//
+// This is the always-valid path: any pose, any metric, any C/D.  One wave (64 lanes) owns
+// 64 consecutive pixels of one batch item; the D per-pixel costs live in LDS as
+// cost[k][lane] so the fused softmax/expectation epilogue needs no second pass over HBM and
+// the cost/logp stores are 256-byte coalesced rows.  Source taps are gathered from global
+// memory (L1/L2); the reference feature vector of the pixel is held in registers.
+#include <hip/hip_runtime.h>
+
+#include "geometry.hpp"
+#include "kernels.hpp"
+
+namespace pdepth {
+
+template <int METRIC, int CCH, bool MULTI_CHUNK>
+__global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x;
+    const int HW = a.H * a.W;
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * 64 + tid;
+    const bool live = pix < HW;
+    const int p = live ? pix : HW - 1;  // dead lanes shadow the last pixel, never store
+
+    float* cost = lds;                                  // [D][64]
+    float* acc = MULTI_CHUNK ? lds + a.D * 64 : nullptr;  // [D][64], raw per-view sums
+    for (int k = 0; k < a.D; ++k) cost[k * 64 + tid] = 0.0f;
+
+    const float cx = a.cxcy[b * 2 + 0];
+    const float cy = a.cxcy[b * 2 + 1];
+    const float half_w = (float)a.W / 2.0f;
+    const float half_h = (float)a.H / 2.0f;
+    const float r0 = a.rays[((size_t)b * 3 + 0) * HW + p];
+    const float r1 = a.rays[((size_t)b * 3 + 1) * HW + p];
+    const float r2 = a.rays[((size_t)b * 3 + 2) * HW + p];
+    const float* refp = a.ref + (size_t)b * a.ref_bstride + p;
+
+    for (int v = 0; v < a.V; ++v) {
+        ViewXform xf;
+        make_view_xform(a.K + b * 9, a.R + ((size_t)b * a.V + v) * 9,
+                        a.t + ((size_t)b * a.V + v) * 3, xf);
+        float t2a, t2b, t2c;
+        ray_term2(xf, r0, r1, r2, t2a, t2b, t2c);
+        const float* srcv = a.src + (size_t)b * a.src_bstride + (size_t)v * a.src_vstride;
+
+        if (MULTI_CHUNK)
+            for (int k = 0; k < a.D; ++k) acc[k * 64 + tid] = 0.0f;
+
+        for (int c0 = 0; c0 < a.C; c0 += CCH) {
+            float rf[CCH];
+#pragma unroll
+            for (int cc = 0; cc < CCH; ++cc)
+                rf[cc] = (c0 + cc < a.C) ? refp[(size_t)(c0 + cc) * HW] : 0.0f;
+
+            for (int k = 0; k < a.D; ++k) {
+                float ix, iy;
+                plane_sample_pos(xf, t2a, t2b, t2c, a.d_candi[k], cx, cy, half_w, half_h, ix, iy);
+                const Footprint f = make_footprint(ix, iy, a.W, a.H);
+                const float* s00 = srcv + (size_t)c0 * HW + (f.y0 * a.W + f.x0);
+                float part = 0.0f;
+#pragma unroll
+                for (int cc = 0; cc < CCH; ++cc) {
+                    if (c0 + cc < a.C) {  // wave-uniform
+                        const float* s = s00 + (size_t)cc * HW;
+                        const float vnw = (f.mask & 1u) ? s[0] : 0.0f;
+                        const float vne = (f.mask & 2u) ? s[1] : 0.0f;
+                        const float vsw = (f.mask & 4u) ? s[a.W] : 0.0f;
+                        const float vse = (f.mask & 8u) ? s[a.W + 1] : 0.0f;
+                        float val = vnw * f.nw;
+                        val = __builtin_fmaf(vne, f.ne, val);
+                        val = __builtin_fmaf(vsw, f.sw, val);
+                        val = __builtin_fmaf(vse, f.se, val);
+                        const float diff = val - rf[cc];
+                        part = part + (METRIC == 0 ? diff * diff : fabsf(diff));
+                    }
+                }
+                if (MULTI_CHUNK)
+                    acc[k * 64 + tid] = acc[k * 64 + tid] + part;
+                else
+                    cost[k * 64 + tid] = cost[k * 64 + tid] + part / a.sigma;
+            }
+        }
+        if (MULTI_CHUNK)
+            for (int k = 0; k < a.D; ++k)
+                cost[k * 64 + tid] = cost[k * 64 + tid] + acc[k * 64 + tid] / a.sigma;
+    }
+
+    // ---- epilogue: cost store, log-softmax over D, expectation --------------------------
+    if (a.cost_out && live) {
+        float* o = a.cost_out + (size_t)b * a.D * HW + pix;
+        for (int k = 0; k < a.D; ++k) o[(size_t)k * HW] = cost[k * 64 + tid];
+    }
+    if (a.logp_out || a.depth_out) {
+        float m = -INFINITY;
+        for (int k = 0; k < a.D; ++k) m = fmaxf(m, cost[k * 64 + tid]);
+        float s = 0.0f;
+        for (int k = 0; k < a.D; ++k) s = s + expf(cost[k * 64 + tid] - m);
+        const float ls = logf(s);
+        float e = 0.0f;
+        float* o = a.logp_out ? a.logp_out + (size_t)b * a.D * HW + pix : nullptr;
+        for (int k = 0; k < a.D; ++k) {
+            const float lp = (cost[k * 64 + tid] - m) - ls;
+            if (o && live) o[(size_t)k * HW] = lp;
+            e = e + a.d_candi[k] * expf(lp);
+        }
+        if (a.depth_out && live) a.depth_out[(size_t)b * HW + pix] = e;
+    }
+}
+
+template <int METRIC>
+static hipError_t launch_metric(const SweepArgs& a, hipStream_t stream) {
+    const int HW = a.H * a.W;
+    dim3 grid((HW + 63) / 64, a.B);
+    if (a.C <= 68) {
+        const size_t lds = (size_t)a.D * 64 * sizeof(float);
+        hipLaunchKernelGGL((sweep_direct_kernel<METRIC, 68, false>), grid, dim3(64), lds, stream, a);
+    } else {
+        const size_t lds = (size_t)a.D * 64 * sizeof(float) * 2;
+        hipLaunchKernelGGL((sweep_direct_kernel<METRIC, 32, true>), grid, dim3(64), lds, stream, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep_direct(const SweepArgs& a, hipStream_t stream) {
+    return a.metric == 0 ? launch_metric<0>(a, stream) : launch_metric<1>(a, stream);
+}
+
+// Largest D the direct kernel can hold in LDS (two arrays in the chunked variant).
+int sweep_direct_max_planes(int C) { return C <= 68 ? 512 : 256; }
+
+}  // namespace pdepth

@@ -1,0 +1,66 @@
+"""Batched entry points of the hot path (thin, typed wrappers over ``_native``).
+
+These are what the host model and the harness call; the reference-compatible per-item
+functions in ``warping.homography`` / ``utils.img_utils`` are wrappers around them.
+All tensors are fp32 device tensors; nothing here runs on the CPU.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _native
+
+METRICS = {"L2": _native.METRIC_L2, "L1": _native.METRIC_L1}
+ALGOS = {"auto": _native.ALGO_AUTO, "direct": _native.ALGO_DIRECT}
+
+
+def _metric(feat_dist):
+    if feat_dist not in METRICS:
+        # same error as warping/homography.py:133
+        raise Exception("undefined metric for feature distance ...")
+    return METRICS[feat_dist]
+
+
+def d_candi_tensor(d_candi, device):
+    """float64 numpy / list / tensor -> fp32 device tensor (homography.py:115 cast)."""
+    if isinstance(d_candi, torch.Tensor):
+        return d_candi.to(device=device, dtype=torch.float32)
+    import numpy as np
+    return torch.from_numpy(np.asarray(d_candi).astype(np.float32)).to(device)
+
+
+def sweep_cost(ref, src, K, R, t, rays, cxcy, d_candi, sigma, feat_dist="L2", algo="auto"):
+    """cost [B,D,H,W].  Batched est_swp_volume_v4 (warping/homography.py:98-135)."""
+    cost, _, _ = _native.sweep(ref, src, K, R, t, rays, cxcy, d_candi_tensor(d_candi, ref.device), sigma,
+                               _metric(feat_dist), ALGOS[algo], want_cost=True)
+    return cost
+
+
+def sweep_dpv(ref, src, K, R, t, rays, cxcy, d_candi, sigma, feat_dist="L2", algo="auto",
+              want_cost=False, want_logp=True, want_depth=True):
+    """Fused sweep -> log_softmax(dim=1) -> E[d].  Returns (cost|None, logp|None, depth|None).
+
+    models/packnet.py:380-394 + utils/img_utils.py:52-61 in one kernel.
+    """
+    return _native.sweep(ref, src, K, R, t, rays, cxcy, d_candi_tensor(d_candi, ref.device), sigma,
+                         _metric(feat_dist), ALGOS[algo], want_cost=want_cost, want_logp=want_logp,
+                         want_depth=want_depth)
+
+
+def dpv_reduce(logits, d_candi, want_logp=True, want_depth=True, inplace=False):
+    """(logp, depth) from logits [B,D,H,W]: log_softmax(dim=1) + dpv_to_depthmap(BV_log=True)."""
+    return _native.dpv_reduce(logits, d_candi_tensor(d_candi, logits.device), want_logp, want_depth, inplace)
+
+
+def dpv_expect(dpv, d_candi, BV_log=False):
+    """depth [B,H,W] from a (log-)DPV [B,D,H,W] (utils/img_utils.py:52-61, batched)."""
+    return _native.dpv_expect(dpv, d_candi_tensor(d_candi, dpv.device), BV_log)
+
+
+def warp_feature(src, K, R, t, rays, cxcy, d_candi):
+    """[B,V,D,H,W] diagonal warp (warping/homography.py:137-168, batched)."""
+    return _native.warp_feature(src, K, R, t, rays, cxcy, d_candi_tensor(d_candi, src.device))
+
+
+def sample_coords(K, R, t, rays, cxcy, d_candi, H, W):
+    return _native.sample_coords(K, R, t, rays, cxcy, d_candi_tensor(d_candi, K.device), H, W)

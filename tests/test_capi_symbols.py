@@ -1,0 +1,60 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/pdepth.h declares.
+No compute calls here (no GPU); argument-validation paths return before any launch."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import pdepth_amd
+from pdepth_amd import _native
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "pdepth.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pdepth_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == sorted(_native.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _native.load()
+    for sym in _declared_symbols():
+        assert hasattr(lib, sym), f"{sym} declared in include/pdepth.h but not exported"
+    assert lib.pdepth_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    lib = _native.load()
+    desc = _native.SweepDesc(0, 1, 1, 1, 1, 1, 0, 0, 10.0, 0, 0, 1)
+    cam = _native.Camera(None, None, None, None, None)
+    rc = lib.pdepth_sweep_cost_f32(ctypes.byref(desc), ctypes.byref(cam), None, None, None, 1, None, 0, None)
+    assert rc == 1 and b"non-positive" in lib.pdepth_last_error()
+    rc = lib.pdepth_dpv_reduce_f32(None, None, 1, 1, 1, 1, None, None, None)
+    assert rc == 1 and b"null input" in lib.pdepth_last_error()
+    desc = _native.SweepDesc(1, 1, 4, 8, 2, 2, 0, 0, 1.0, 0, 0, 16)
+    cam = _native.Camera(1, 1, 1, 1, 1)
+    rc = lib.pdepth_warp_feature_f32(ctypes.byref(desc), ctypes.byref(cam), 1, 1, 1, None)
+    assert rc == 1 and b"C == D" in lib.pdepth_last_error()
+    desc = _native.SweepDesc(1, 1, 4, 8, 2, 2, 7, 0, 1.0, 16, 16, 16)
+    rc = lib.pdepth_sweep_dpv_f32(ctypes.byref(desc), ctypes.byref(cam), 1, 1, 1, 1, None, None, None, 0, None)
+    assert rc == 1 and b"undefined metric" in lib.pdepth_last_error()
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    from pdepth_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.dpv_expect(torch.zeros(1, 4, 2, 2), [1.0, 2.0, 3.0, 4.0])
+    src = open(os.path.join(REPO, "probabilistic-depth_amd", "_native.py")).read()
+    for root, _, files in os.walk(os.path.join(REPO, "probabilistic-depth_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                body = open(os.path.join(root, f)).read()
+                assert "import oracle" not in body and "from oracle" not in body, f"{f} must not use the oracle"
+    assert "oracle" not in src

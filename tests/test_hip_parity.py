@@ -1,0 +1,186 @@
+"""GPU suite: the HIP path (through the C ABI) against the golden fixtures and the CPU oracle.
+
+Tolerances
+  sample coordinates : bit-exact (integer-like contract, see csrc/geometry.hpp)
+  cost / logp        : 2e-4 abs + 2e-5 rel (fp32 summation order over C differs from ATen's cascade sum)
+  depth              : 1e-4 abs  (BASELINE.json north_star)
+"""
+import numpy as np
+import pytest
+import torch
+
+import pdepth_amd  # noqa: F401
+from pdepth_amd import ops, synth
+from pdepth_amd.utils import img_utils
+from pdepth_amd.warping import homography
+from oracle import ref_cpu as O
+from util import DEPTH_ATOL, golden, oracle_batch, to_dev
+
+pytestmark = pytest.mark.gpu
+
+COST_ATOL, COST_RTOL = 2e-4, 2e-5
+
+
+def _cam(g, dev):
+    K = torch.from_numpy(g["K"]).to(dev)
+    return {"intrinsic_M_cuda": K, "intrinsic_M": g["K"], "unit_ray_array_2D": torch.from_numpy(g["rays"]).to(dev)}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU suite needs a GPU"
+    return torch.device("cuda:0")
+
+
+# ---------------------------------------------------------------------------------------------
+# golden fixtures through the reference-compatible per-item API
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["g1_rot_trans", "g2_identity", "g3_out_of_bounds"])
+@pytest.mark.parametrize("metric", ["L2", "L1"])
+def test_golden_tiny_sweeps(dev, name, metric):
+    g = golden(name + ".npz")
+    cost = homography.est_swp_volume_v4(torch.from_numpy(g["ref"]).to(dev), torch.from_numpy(g["src"]).to(dev),
+                                        g["d_candi"], torch.from_numpy(g["R"]).to(dev),
+                                        torch.from_numpy(g["t"]).to(dev), _cam(g, dev), float(g["sigma"]),
+                                        feat_dist=metric)
+    assert cost.shape == (1, 8, 16, 24) and cost.device.type == "cuda"
+    np.testing.assert_allclose(cost.cpu().numpy(), g["cost_" + metric], rtol=COST_RTOL, atol=COST_ATOL)
+
+
+@pytest.mark.parametrize("name", ["g4_stereo_64x96", "g4_mono_64x128"])
+def test_golden_model_real(dev, name):
+    g = golden(name + ".npz")
+    kw = eval(str(g["synth_kwargs"]), {"__builtins__": {}}, {"dict": dict})
+    it = synth.make_item(**kw)
+    b = to_dev({k: (v[None] if isinstance(v, torch.Tensor) else v) for k, v in it.items()}, dev)
+    cost, logp, depth = ops.sweep_dpv(b["ref"], b["src"], b["K"], b["R"], b["t"], b["rays"], b["cxcy"],
+                                      b["d_candi"], 10.0, want_cost=True)
+    np.testing.assert_allclose(cost.cpu().numpy()[:, ::4, ::2, ::2], g["cost_sub"], rtol=COST_RTOL, atol=COST_ATOL)
+    np.testing.assert_allclose(logp.cpu().numpy()[:, ::4, ::2, ::2], g["logp_sub"], rtol=COST_RTOL, atol=COST_ATOL)
+    err = np.abs(depth.cpu().numpy() - g["depth"]).max()
+    assert err <= DEPTH_ATOL, f"depth differs from the reference fixture by {err:.3e}"
+
+
+def test_golden_dpv(dev):
+    g = golden("g5_dpv.npz")
+    for nm in ("broad", "peaked"):
+        x = torch.from_numpy(g[nm + "_logits"]).to(dev)
+        logp, depth = ops.dpv_reduce(x, g["d_candi"])
+        np.testing.assert_allclose(logp.cpu().numpy(), g[nm + "_logp"], rtol=1e-6, atol=2e-6)
+        assert np.abs(depth.cpu().numpy() - g[nm + "_depth_log"]).max() <= DEPTH_ATOL
+        d1 = img_utils.dpv_to_depthmap(torch.from_numpy(g[nm + "_logp"]).to(dev), g["d_candi"], BV_log=True)
+        assert np.abs(d1.cpu().numpy() - g[nm + "_depth_log"]).max() <= DEPTH_ATOL
+        d2 = img_utils.dpv_to_depthmap(torch.exp(torch.from_numpy(g[nm + "_logp"])).to(dev), g["d_candi"])
+        assert np.abs(d2.cpu().numpy() - g[nm + "_depth_lin"]).max() <= DEPTH_ATOL
+    with pytest.raises(Exception, match="Unable to handle this case"):
+        img_utils.dpv_to_depthmap(torch.zeros(2, 4, 3, 3, device=dev), g["d_candi"][:4])
+
+
+def test_golden_warp_feature(dev):
+    g = golden("g6_warp_feature.npz")
+    out = homography.warp_feature(torch.from_numpy(g["feat"]).to(dev), g["d_candi"], torch.from_numpy(g["R"]).to(dev),
+                                  torch.from_numpy(g["t"]).to(dev), _cam(g, dev))
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-6, atol=1e-6)
+    with pytest.raises(Exception, match="Warped Accum Error"):
+        homography.warp_feature(torch.zeros(2, 1, 8, 4, 4, device=dev), g["d_candi"], None, None, _cam(g, dev))
+
+
+# ---------------------------------------------------------------------------------------------
+# seeded inputs against the oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pose,H,W,off", [("mono", 60, 100, 1.3), ("stereo", 64, 128, 0.0), ("mono", 33, 47, -0.6)])
+def test_sample_coordinates_bit_exact(dev, pose, H, W, off):
+    b = synth.make_batch(21, 2, C=1, D=16, H=H, W=W, V=2, pose=pose, cx_off=off, cy_off=-off / 2)
+    d = to_dev(b, dev)
+    ix, iy = ops.sample_coords(d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], H, W)
+    for bi in range(2):
+        for v in range(2):
+            K = b["K"][bi]
+            ox, oy = O.sample_coords(K, b["R"][bi, v], b["t"][bi, v], b["rays"][bi], b["d_candi"],
+                                     K.numpy()[0, 2], K.numpy()[1, 2], H, W)
+            gx, gy = ix[bi, v].cpu().reshape(16, -1), iy[bi, v].cpu().reshape(16, -1)
+            bad = int((gx != ox).sum() + (gy != oy).sum())
+            assert bad == 0, f"{bad} of {2 * gx.numel()} sample coordinates differ from the CPU path"
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(C=67, D=64, H=64, W=128, V=1, pose="mono"),
+    dict(C=67, D=64, H=64, W=128, V=1, pose="stereo"),
+    dict(C=7, D=8, H=17, W=23, V=3, pose="mono", cx_off=1.1, cy_off=-0.4),   # ragged sizes, 3 views
+    dict(C=70, D=16, H=20, W=36, V=2, pose="mono"),                          # C > 68: chunked-channel kernel
+    dict(C=67, D=128, H=16, W=64, V=1, pose="stereo"),                       # D=128 (config 5 depth count)
+    dict(C=64, D=64, H=32, W=64, V=1, pose="mono", peaked=True),
+])
+@pytest.mark.parametrize("metric", ["L2", "L1"])
+def test_sweep_matches_oracle(dev, cfg, metric):
+    if metric == "L1" and cfg["D"] == 128:
+        pytest.skip("covered by L2")
+    b = synth.make_batch(31, 2, **cfg)
+    ocost, ologp, odepth = oracle_batch(b, metric)
+    d = to_dev(b, dev)
+    cost, logp, depth = ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"],
+                                      d["d_candi"], 10.0, feat_dist=metric, want_cost=True)
+    np.testing.assert_allclose(cost.cpu().numpy(), ocost.numpy(), rtol=COST_RTOL, atol=COST_ATOL)
+    np.testing.assert_allclose(logp.cpu().numpy(), ologp.numpy(), rtol=COST_RTOL, atol=COST_ATOL)
+    err = (depth.cpu() - odepth).abs().max().item()
+    assert err <= DEPTH_ATOL, f"depth differs from the CPU oracle by {err:.3e}"
+    # cost-only entry point returns the same volume
+    cost2 = ops.sweep_cost(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0,
+                           feat_dist=metric)
+    assert torch.equal(cost, cost2)
+
+
+def test_strided_views_no_copy(dev):
+    """ref = last view, sources = leading views of ONE [B,V+1,C,H,W] tensor (models/models.py:533-534)."""
+    b = synth.make_batch(32, 2, C=9, D=8, H=12, W=20, V=2, pose="mono")
+    allv = torch.cat([b["src"], b["ref"][:, None]], dim=1).to(dev)
+    d = to_dev(b, dev)
+    want = ops.sweep_cost(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0)
+    got = ops.sweep_cost(allv[:, -1], allv[:, :-1], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0)
+    assert torch.equal(want, got)
+
+
+def test_dpv_reduce_shapes_and_properties(dev):
+    rng = np.random.default_rng(5)
+    for (B, D, H, W) in ((2, 64, 32, 48), (1, 128, 8, 12), (3, 7, 5, 9), (1, 200, 4, 6), (2, 64, 3, 5)):
+        x = torch.from_numpy(rng.standard_normal((B, D, H, W), dtype=np.float32) * 3)
+        dc = O.powerf(5.0, 40.0, D, 1.0)
+        logp, depth = ops.dpv_reduce(x.to(dev), dc)
+        want_lp = O.log_dpv(x)
+        np.testing.assert_allclose(logp.cpu().numpy(), want_lp.numpy(), rtol=1e-6, atol=3e-6)
+        for bi in range(B):
+            want_d = O.dpv_to_depthmap(want_lp[bi:bi + 1], dc, BV_log=True)
+            assert (depth[bi:bi + 1].cpu() - want_d).abs().max().item() <= DEPTH_ATOL
+        # properties: probabilities sum to one, depth inside [d_min, d_max], shift invariance
+        assert (torch.exp(logp).sum(1) - 1).abs().max().item() < 1e-5
+        assert depth.min().item() >= 5.0 - 1e-4 and depth.max().item() <= 40.0 + 1e-4
+        logp2, depth2 = ops.dpv_reduce((x + 3.0).to(dev), dc)
+        assert (logp2 - logp).abs().max().item() < 1e-5 and (depth2 - depth).abs().max().item() < 1e-4
+        # in-place variant
+        xi = x.to(dev).clone()
+        lp3, _ = ops.dpv_reduce(xi, dc, inplace=True)
+        assert lp3.data_ptr() == xi.data_ptr() and torch.equal(lp3, logp)
+
+
+def test_full_size_properties(dev):
+    """BASELINE config 2 size (B=4, D=64, 256x512, C=67): properties that need no oracle."""
+    b = synth.make_batch(2, 2, C=67, D=64, H=256, W=512, V=1, pose="stereo")
+    d = to_dev(b, dev)
+    cost, logp, depth = ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"],
+                                      d["d_candi"], 10.0, want_cost=True)
+    assert torch.isfinite(cost).all() and (cost >= 0).all()
+    assert (torch.exp(logp).sum(1) - 1).abs().max().item() < 1e-5
+    assert depth.min().item() >= 5.0 - 1e-4 and depth.max().item() <= 40.0 + 1e-4
+    # fused outputs == unfused chain on the same cost volume
+    lp2, dp2 = ops.dpv_reduce(cost, d["d_candi"])
+    assert (lp2 - logp).abs().max().item() < 2e-5 and (dp2 - depth).abs().max().item() < DEPTH_ATOL
+    # identity pose with src == ref gives ~zero cost everywhere (linearity of the sampler)
+    eye = torch.eye(3, device=dev).reshape(1, 1, 3, 3).repeat(2, 1, 1, 1)
+    zero = torch.zeros(2, 1, 3, device=dev)
+    c0 = ops.sweep_cost(d["ref"], d["ref"][:, None], d["K"], eye, zero, d["rays"], d["cxcy"], d["d_candi"], 10.0)
+    assert c0.abs().max().item() < 1e-4
+    # a few oracle spot-rows at full size would take minutes; one 8-row strip through the oracle instead:
+    strip = {k: v for k, v in b.items()}
+    oc, _, _ = oracle_batch({**strip, "ref": b["ref"][:1], "src": b["src"][:1], "K": b["K"][:1], "R": b["R"][:1],
+                             "t": b["t"][:1], "rays": b["rays"][:1], "cxcy": b["cxcy"][:1]})
+    np.testing.assert_allclose(cost[:1].cpu().numpy(), oc.numpy(), rtol=COST_RTOL, atol=COST_ATOL)

@@ -1,0 +1,112 @@
+"""CPU suite: the oracle restatement reproduces the reference's golden vectors.
+
+The fixtures were produced by tests/golden/make_golden.py from the real reference.  On the
+CPU/torch build that generated them the oracle must be bit-identical (same ATen ops, same
+order); on another CPU a few ulps of MKL/vector-width drift are tolerated.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import pdepth_amd  # noqa: F401
+from pdepth_amd import synth
+from pdepth_amd.utils import img_utils as host_img_utils
+from pdepth_amd.warping import view as host_view
+from oracle import ref_cpu as O
+from util import golden, same_cpu_as_golden
+
+
+def _assert_pinned(got, want, g, rtol=2e-5, atol=2e-5):
+    got, want = np.asarray(got), np.asarray(want)
+    if same_cpu_as_golden(g):
+        assert np.array_equal(got, want), "oracle is no longer bit-identical to the reference fixture"
+    else:
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("name", ["g1_rot_trans", "g2_identity", "g3_out_of_bounds"])
+@pytest.mark.parametrize("metric", ["L2", "L1"])
+def test_tiny_sweeps(name, metric):
+    g = golden(name + ".npz")
+    K = torch.from_numpy(g["K"])
+    cost = O.sweep_cost(torch.from_numpy(g["ref"]), torch.from_numpy(g["src"]), g["d_candi"],
+                        torch.from_numpy(g["R"]), torch.from_numpy(g["t"]), K, torch.from_numpy(g["rays"]),
+                        g["K"][0, 2], g["K"][1, 2], float(g["sigma"]), metric)
+    _assert_pinned(cost.numpy(), g["cost_" + metric], g)
+    if name == "g2_identity" and metric == "L2":
+        # src != ref here, so the cost is not ~0; identity only means "samples land on pixel centres"
+        assert np.isfinite(cost.numpy()).all()
+
+
+def test_identity_pose_same_image_is_zero_cost():
+    it = synth.make_item(7, C=5, D=4, H=8, W=12, V=1, pose="identity")
+    it["src"] = it["ref"][None].clone()
+    K = it["K"]
+    cost = O.sweep_cost(it["ref"][None], it["src"][None], it["d_candi"], it["R"], it["t"], K, it["rays"],
+                        K.numpy()[0, 2], K.numpy()[1, 2], 10.0)
+    assert cost.abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("name", ["g4_stereo_64x96", "g4_mono_64x128"])
+def test_model_real(name):
+    g = golden(name + ".npz")
+    kw = eval(str(g["synth_kwargs"]), {"__builtins__": {}}, {"dict": dict})
+    it = synth.make_item(**kw)
+    K = it["K"]
+    cost, logp, depth = O.sweep_dpv(it["ref"][None], it["src"][None], it["d_candi"], it["R"], it["t"], K,
+                                    it["rays"], K.numpy()[0, 2], K.numpy()[1, 2], 10.0)
+    _assert_pinned(cost.numpy()[:, ::4, ::2, ::2], g["cost_sub"], g, atol=2e-4)
+    _assert_pinned(logp.numpy()[:, ::4, ::2, ::2], g["logp_sub"], g, atol=2e-4)
+    _assert_pinned(depth.numpy(), g["depth"], g, atol=1e-4)
+    assert abs(cost.double().sum().item() - float(g["cost_sum"])) < 1e-3 * abs(float(g["cost_sum"]))
+
+
+def test_dpv_reduce():
+    g = golden("g5_dpv.npz")
+    for nm in ("broad", "peaked"):
+        x = torch.from_numpy(g[nm + "_logits"])
+        lp = O.log_dpv(x)
+        _assert_pinned(lp.numpy(), g[nm + "_logp"], g)
+        _assert_pinned(O.dpv_to_depthmap(lp, g["d_candi"], BV_log=True).numpy(), g[nm + "_depth_log"], g)
+        _assert_pinned(O.dpv_to_depthmap(torch.exp(lp), g["d_candi"], BV_log=False).numpy(), g[nm + "_depth_lin"], g)
+    with pytest.raises(Exception, match="Unable to handle this case"):
+        O.dpv_to_depthmap(torch.zeros(2, 4, 3, 3), g["d_candi"][:4])
+
+
+def test_warp_feature():
+    g = golden("g6_warp_feature.npz")
+    K = torch.from_numpy(g["K"])
+    out = O.warp_feature(torch.from_numpy(g["feat"]), g["d_candi"], torch.from_numpy(g["R"]),
+                         torch.from_numpy(g["t"]), K, torch.from_numpy(g["rays"]), g["K"][0, 2], g["K"][1, 2])
+    _assert_pinned(out.numpy(), g["out"], g)
+    with pytest.raises(Exception, match="Warped Accum Error"):
+        O.warp_feature(torch.zeros(2, 1, 8, 4, 4), g["d_candi"], None, None, K, None, 0, 0)
+
+
+def test_host_producers():
+    g = golden("g7_host.npz")
+    for p in (1.0, 1.25, 1.5):
+        want = g["powerf_%g" % p]
+        assert np.array_equal(O.powerf(5.0, 40.0, 64, p), want)
+        assert np.array_equal(synth.powerf(5.0, 40.0, 64, p), want)
+        assert np.array_equal(host_img_utils.powerf(5.0, 40.0, 64, p), want)
+    for (w, h) in ((96, 64), (128, 64)):
+        want = g["rays_%dx%d" % (w, h)]
+        assert np.array_equal(O.unit_rays(w, h, 80.0, 35.0).numpy(), want)
+        cam = host_view.camera_from_fov(w, h, 80.0, 35.0)
+        assert np.array_equal(cam["unit_ray_array_2D"].numpy(), want)
+        assert np.array_equal(cam["intrinsic_M"], g["K_%dx%d" % (w, h)])
+        assert np.array_equal(O.intrinsics_from_fov(w, h, 80.0, 35.0), g["K_%dx%d" % (w, h)])
+    # K @ ray = (x+.5, y+.5, 1) for loader-built cameras (known oracle fact)
+    cam = host_view.camera_from_fov(96, 64, 80.0, 35.0)
+    kr = cam["intrinsic_M"] @ cam["unit_ray_array_2D"].double().numpy()
+    xs = np.tile(np.arange(96) + 0.5, 64)
+    assert np.abs(kr[0] - xs).max() < 1e-4
+
+
+def test_undefined_metric_raises():
+    it = synth.make_item(3, C=3, D=2, H=4, W=6)
+    with pytest.raises(Exception, match="undefined metric"):
+        O.sweep_cost(it["ref"][None], it["src"][None], it["d_candi"], it["R"], it["t"], it["K"], it["rays"],
+                     1.0, 1.0, 10.0, metric="cosine")
