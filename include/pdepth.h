@@ -42,6 +42,16 @@ enum {
 /* feature distance, warping/homography.py:128-133 ('L2' | 'L1', anything else raises) */
 enum { PDEPTH_METRIC_L2 = 0, PDEPTH_METRIC_L1 = 1 };
 
+/* Rounding of the host BLAS whose sgemm/sgemv the reference's CPU path calls for K@R, K@t and
+ * (K@R)@rays (warping/homography.py:119-121).  One ulp of those terms moves the L2 cost by ~1e-3,
+ * so "identical to the reference CPU path" depends on which MKL code path the host takes:
+ *   FMA      (MKL on Intel AVX-512/AVX2): sgemm = fma chain k=0,1,2 (first product rounded alone);
+ *                                         sgemv (K@t) = (p1 + p2) + p0, products rounded separately
+ *   SEPARATE (MKL on AMD EPYC)          : sgemm and sgemv = (p0 + p1) + p2, products rounded separately
+ * The Python host probes torch's CPU matmul once and passes the matching mode
+ * (probabilistic-depth_amd/_native.py host_blas_mode()). */
+enum { PDEPTH_BLAS_FMA = 0, PDEPTH_BLAS_SEPARATE = 1 };
+
 /* algorithm selector for the sweep kernels */
 enum {
     PDEPTH_ALGO_AUTO = 0,   /* fastest algorithm valid for the given geometry          */
@@ -57,6 +67,7 @@ typedef struct pdepth_sweep_desc {
     int32_t H, W;        /* sweep resolution                                            */
     int32_t metric;      /* PDEPTH_METRIC_*                                             */
     int32_t algo;        /* PDEPTH_ALGO_*                                               */
+    int32_t blas_mode;   /* PDEPTH_BLAS_* : rounding of K@R, K@t, (K@R)@rays            */
     float sigma;         /* costV_sigma (cfg.var.sigma_soft_max, 10.0)                  */
     int64_t ref_bstride; /* elements between ref[b] and ref[b+1]   (>= C*H*W)           */
     int64_t src_bstride; /* elements between src[b,0] and src[b+1,0]                    */

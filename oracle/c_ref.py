@@ -25,7 +25,7 @@ def _fp(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def sweep_dpv_f64(ref, src, K, R, t, rays, cx, cy, d_candi, sigma, metric="L2"):
+def sweep_dpv_f64(ref, src, K, R, t, rays, cx, cy, d_candi, sigma, metric="L2", blas_separate=0):
     """numpy fp32 inputs of ONE item -> (cost [D,H,W], logp [D,H,W], depth [H,W]) float64."""
     lib = load()
     ref = np.ascontiguousarray(ref, np.float32)
@@ -40,5 +40,5 @@ def sweep_dpv_f64(ref, src, K, R, t, rays, cx, cy, d_candi, sigma, metric="L2"):
     lib.pdo_sweep_dpv_f64.restype = None
     lib.pdo_sweep_dpv_f64(_fp(ref), _fp(src), _fp(K), _fp(R), _fp(t), _fp(rays), ctypes.c_float(float(cx)),
                           ctypes.c_float(float(cy)), _fp(d32), V, C, D, H, W, ctypes.c_double(float(sigma)),
-                          0 if metric == "L2" else 1, _fp(cost), _fp(logp), _fp(depth), _fp(scratch))
+                          0 if metric == "L2" else 1, int(blas_separate), _fp(cost), _fp(logp), _fp(depth), _fp(scratch))
     return cost, logp, depth

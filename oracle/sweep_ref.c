@@ -20,27 +20,36 @@
 #include <math.h>
 #include <stddef.h>
 
-static void view_xform(const float *K, const float *R, const float *t, float *kr, float *kt) {
+/* 3-term dot product with the rounding of the host BLAS (include/pdepth.h PDEPTH_BLAS_*):
+ * separate = 0: fma chain (MKL on Intel); separate = 1: (p0 + p1) + p2 (MKL on AMD). */
+static float dot3_blas(int separate, float a0, float b0, float a1, float b1, float a2, float b2) {
+    volatile float p0 = a0 * b0;
+    if (separate) {
+        volatile float p1 = a1 * b1, p2 = a2 * b2;
+        volatile float s = p0 + p1;
+        return s + p2;
+    }
+    return fmaf(a2, b2, fmaf(a1, b1, p0));
+}
+
+static void view_xform(int separate, const float *K, const float *R, const float *t, float *kr, float *kt) {
     for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) {
-            float acc = K[i * 3 + 0] * R[0 * 3 + j];
-            acc = fmaf(K[i * 3 + 1], R[1 * 3 + j], acc);
-            acc = fmaf(K[i * 3 + 2], R[2 * 3 + j], acc);
-            kr[i * 3 + j] = acc;
-        }
+        for (int j = 0; j < 3; ++j)
+            kr[i * 3 + j] = dot3_blas(separate, K[i * 3 + 0], R[0 * 3 + j], K[i * 3 + 1], R[1 * 3 + j],
+                                      K[i * 3 + 2], R[2 * 3 + j]);
         {
             volatile float p0 = K[i * 3 + 0] * t[0], p1 = K[i * 3 + 1] * t[1], p2 = K[i * 3 + 2] * t[2];
-            volatile float s = p1 + p2;
-            kt[i] = s + p0;
+            volatile float s = separate ? p0 + p1 : p1 + p2;
+            kt[i] = separate ? s + p2 : s + p0;
         }
     }
 }
 
-static void sample_pos(const float *kr, const float *kt, float r0, float r1, float r2, float d, float cx,
-                       float cy, int H, int W, float *ix, float *iy) {
-    float a = fmaf(kr[2], r2, fmaf(kr[1], r1, kr[0] * r0));
-    float b = fmaf(kr[5], r2, fmaf(kr[4], r1, kr[3] * r0));
-    float c = fmaf(kr[8], r2, fmaf(kr[7], r1, kr[6] * r0));
+static void sample_pos(int separate, const float *kr, const float *kt, float r0, float r1, float r2, float d,
+                       float cx, float cy, int H, int W, float *ix, float *iy) {
+    float a = dot3_blas(separate, kr[0], r0, kr[1], r1, kr[2], r2);
+    float b = dot3_blas(separate, kr[3], r0, kr[4], r1, kr[5], r2);
+    float c = dot3_blas(separate, kr[6], r0, kr[7], r1, kr[8], r2);
     volatile float ad = a * d, bd = b * d, cd = c * d; /* separate mul, then add (two ATen ops) */
     float px = kt[0] + ad, py = kt[1] + bd, pz = kt[2] + cd;
     float den = pz + 1e-10f;
@@ -54,18 +63,18 @@ static void sample_pos(const float *kr, const float *kt, float r0, float r1, flo
  * Outputs (any may be NULL): cost [D,H,W], logp [D,H,W], depth [H,W]  -- all double. */
 void pdo_sweep_dpv_f64(const float *ref, const float *src, const float *K, const float *R, const float *t,
                        const float *rays, float cx, float cy, const float *d_candi, int V, int C, int D,
-                       int H, int W, double sigma, int metric, double *cost, double *logp, double *depth,
-                       double *scratch /* [D] per call, caller provided */) {
+                       int H, int W, double sigma, int metric, int blas_separate, double *cost, double *logp,
+                       double *depth, double *scratch /* [D] per call, caller provided */) {
     const int HW = H * W;
     for (int p = 0; p < HW; ++p) {
         for (int k = 0; k < D; ++k) scratch[k] = 0.0;
         for (int v = 0; v < V; ++v) {
             float kr[9], kt[3];
-            view_xform(K, R + v * 9, t + v * 3, kr, kt);
+            view_xform(blas_separate, K, R + v * 9, t + v * 3, kr, kt);
             const float *sv = src + (size_t)v * C * HW;
             for (int k = 0; k < D; ++k) {
                 float ix, iy;
-                sample_pos(kr, kt, rays[p], rays[HW + p], rays[2 * HW + p], d_candi[k], cx, cy, H, W, &ix, &iy);
+                sample_pos(blas_separate, kr, kt, rays[p], rays[HW + p], rays[2 * HW + p], d_candi[k], cx, cy, H, W, &ix, &iy);
                 double acc = 0.0;
                 if (ix == ix && iy == iy) {
                     float xf = floorf(ix), yf = floorf(iy);

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libpdepth_hip.so")
 
 METRIC_L2, METRIC_L1 = 0, 1
 ALGO_AUTO, ALGO_DIRECT = 0, 1
+BLAS_FMA, BLAS_SEPARATE = 0, 1
 
 # every symbol include/pdepth.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
@@ -29,7 +30,7 @@ EXPORTED_SYMBOLS = (
 class SweepDesc(Structure):
     _fields_ = [
         ("B", c_int32), ("V", c_int32), ("C", c_int32), ("D", c_int32), ("H", c_int32), ("W", c_int32),
-        ("metric", c_int32), ("algo", c_int32), ("sigma", c_float),
+        ("metric", c_int32), ("algo", c_int32), ("blas_mode", c_int32), ("sigma", c_float),
         ("ref_bstride", c_int64), ("src_bstride", c_int64), ("src_vstride", c_int64),
     ]
 
@@ -39,6 +40,41 @@ class Camera(Structure):
 
 
 _lib = None
+_host_blas = None
+
+
+def host_blas_mode():
+    """Which rounding the host BLAS behind torch's CPU matmul uses (include/pdepth.h PDEPTH_BLAS_*).
+
+    The reference's CPU path computes K@R, K@t and (K@R)@rays with torch.matmul (MKL); whether MKL
+    fuses multiply-adds depends on the host CPU.  One tiny CPU matmul is compared with both
+    closed forms (products/sums evaluated in float64 then rounded, which is exact for one fma)
+    so the kernels reproduce the sampling positions of the reference run on THIS host.
+    Override with PDEPTH_BLAS_MODE=fma|separate.
+    """
+    global _host_blas
+    if _host_blas is not None:
+        return _host_blas
+    env = os.environ.get("PDEPTH_BLAS_MODE", "").lower()
+    if env in ("fma", "separate"):
+        _host_blas = BLAS_FMA if env == "fma" else BLAS_SEPARATE
+        return _host_blas
+    import numpy as np
+    g = torch.Generator().manual_seed(7)
+    A = (torch.randn(3, 3, generator=g) * 100).float()
+    Bm = torch.randn(3, 4096, generator=g).float()
+    C = A.matmul(Bm).numpy()
+    a, b = A.numpy().astype(np.float64), Bm.numpy().astype(np.float64)
+    f32 = np.float32
+    p = [(a[:, k:k + 1] * b[k:k + 1, :]) for k in range(3)]          # exact products (float64)
+    fma = ((p[0].astype(f32).astype(np.float64) + p[1]).astype(f32).astype(np.float64) + p[2]).astype(f32)
+    sep = ((p[0].astype(f32) + p[1].astype(f32)).astype(f32) + p[2].astype(f32)).astype(f32)
+    bad_fma, bad_sep = int((fma != C).sum()), int((sep != C).sum())
+    if bad_fma == 0 or bad_fma < bad_sep:
+        _host_blas = BLAS_FMA
+    else:
+        _host_blas = BLAS_SEPARATE
+    return _host_blas
 
 
 def load():
@@ -115,8 +151,12 @@ def _camera(K, R, t, rays, cxcy, B, V, HW):
     return cam, (K, R, t, rays, cxcy)  # keep the contiguous copies alive
 
 
+def _blas(blas_mode):
+    return host_blas_mode() if blas_mode is None else int(blas_mode)
+
+
 def sweep(ref, src, K, R, t, rays, cxcy, d_candi, sigma, metric=METRIC_L2, algo=ALGO_AUTO,
-          want_cost=True, want_logp=False, want_depth=False):
+          want_cost=True, want_logp=False, want_depth=False, blas_mode=None):
     """Batched plane sweep (+ optional fused DPV reduction).
 
     ref [B,C,H,W], src [B,V,C,H,W] (batch/view strides free, inner C,H,W dense), K [B,3,3],
@@ -139,7 +179,7 @@ def sweep(ref, src, K, R, t, rays, cxcy, d_candi, sigma, metric=METRIC_L2, algo=
     D = d_candi.numel()
     dev = ref.device
     cam, keep = _camera(K, R, t, rays, cxcy, B, V, H * W)
-    desc = SweepDesc(B, V, C, D, H, W, int(metric), int(algo), float(sigma),
+    desc = SweepDesc(B, V, C, D, H, W, int(metric), int(algo), _blas(blas_mode), float(sigma),
                      ref.stride(0) if B > 1 else C * H * W,
                      src.stride(0) if B > 1 else V * C * H * W,
                      src.stride(1) if V > 1 else C * H * W)
@@ -200,7 +240,7 @@ def dpv_expect(dpv, d_candi, bv_log):
     return depth
 
 
-def warp_feature(src, K, R, t, rays, cxcy, d_candi):
+def warp_feature(src, K, R, t, rays, cxcy, d_candi, blas_mode=None):
     """src [B,V,D,H,W] -> out [B,V,D,H,W], channel i warped with depth plane i."""
     lib = load()
     _dev(src, "src")
@@ -212,7 +252,7 @@ def warp_feature(src, K, R, t, rays, cxcy, d_candi):
     d_candi = d_candi.contiguous()
     D = d_candi.numel()
     cam, keep = _camera(K, R, t, rays, cxcy, B, V, H * W)
-    desc = SweepDesc(B, V, C, D, H, W, 0, 0, 1.0, 0, src.stride(0) if B > 1 else V * C * H * W,
+    desc = SweepDesc(B, V, C, D, H, W, 0, 0, _blas(blas_mode), 1.0, 0, src.stride(0) if B > 1 else V * C * H * W,
                      src.stride(1) if V > 1 else C * H * W)
     out = torch.empty((B, V, D, H, W), dtype=torch.float32, device=src.device)
     with torch.cuda.device(src.device):
@@ -223,7 +263,7 @@ def warp_feature(src, K, R, t, rays, cxcy, d_candi):
     return out
 
 
-def sample_coords(K, R, t, rays, cxcy, d_candi, H, W):
+def sample_coords(K, R, t, rays, cxcy, d_candi, H, W, blas_mode=None):
     """Diagnostic: (ix, iy) [B,V,D,H,W] sample positions handed to the bilinear sampler."""
     lib = load()
     _dev(K, "K")
@@ -231,7 +271,7 @@ def sample_coords(K, R, t, rays, cxcy, d_candi, H, W):
     d_candi = d_candi.contiguous()
     D = d_candi.numel()
     cam, keep = _camera(K, R, t, rays, cxcy, B, V, H * W)
-    desc = SweepDesc(B, V, 1, D, H, W, 0, 0, 1.0, 0, 0, H * W)
+    desc = SweepDesc(B, V, 1, D, H, W, 0, 0, _blas(blas_mode), 1.0, 0, 0, H * W)
     ix = torch.empty((B, V, D, H, W), dtype=torch.float32, device=K.device)
     iy = torch.empty_like(ix)
     with torch.cuda.device(K.device):

@@ -29,6 +29,8 @@ int check_desc(const pdepth_sweep_desc* d, const pdepth_camera* cam, const char*
         return fail(PDEPTH_E_ARG, "%s: H*W too large", who);
     if (!cam->K || !cam->R || !cam->t || !cam->rays || !cam->cxcy)
         return fail(PDEPTH_E_ARG, "%s: null camera pointer", who);
+    if (d->blas_mode != PDEPTH_BLAS_FMA && d->blas_mode != PDEPTH_BLAS_SEPARATE)
+        return fail(PDEPTH_E_ARG, "%s: unknown blas_mode %d", who, d->blas_mode);
     const long long chw = (long long)d->C * d->H * d->W;
     if (d->src_vstride < chw || d->src_bstride < 0 || d->ref_bstride < 0)
         return fail(PDEPTH_E_ARG, "%s: bad strides", who);
@@ -42,7 +44,7 @@ pdepth::SweepArgs make_args(const pdepth_sweep_desc* d, const pdepth_camera* cam
     a.K = cam->K; a.R = cam->R; a.t = cam->t; a.rays = cam->rays; a.cxcy = cam->cxcy;
     a.d_candi = d_candi;
     a.B = d->B; a.V = d->V; a.C = d->C; a.D = d->D; a.H = d->H; a.W = d->W;
-    a.metric = d->metric; a.sigma = d->sigma;
+    a.metric = d->metric; a.sigma = d->sigma; a.blas_mode = d->blas_mode;
     a.ref_bstride = d->ref_bstride; a.src_bstride = d->src_bstride; a.src_vstride = d->src_vstride;
     return a;
 }

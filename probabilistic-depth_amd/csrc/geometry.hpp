@@ -7,8 +7,12 @@
 // rounding of the corresponding ATen/MKL op.  The orders were pinned empirically against
 // torch 2.10 CPU (tests/test_coords_pin.py keeps them pinned):
 //
-//   K@R, (K@R)@rays  sgemm, N>=2 : fma chain over k = 0,1,2, first product rounded alone
-//   K@t              sgemv, N==1 : (p1 + p2) + p0, products rounded separately, no fma
+//   K@R, (K@R)@rays  sgemm, N>=2 : blas_mode FMA      -> fma chain over k = 0,1,2, first product
+//                                                       rounded alone (MKL on Intel)
+//                                  blas_mode SEPARATE -> (p0 + p1) + p2, products rounded
+//                                                       separately (MKL on AMD EPYC)
+//   K@t              sgemv, N==1 : FMA -> (p1 + p2) + p0 ; SEPARATE -> (p0 + p1) + p2 ; both with
+//                                  separately rounded products
 //   term1 + term2*d              : separate mul and add (two ATen ops)
 //   P / (Pz + 1e-10)             : IEEE add, IEEE divide
 //   (u - cx) / cx                : IEEE sub, IEEE divide
@@ -27,33 +31,44 @@ namespace pdepth {
 struct ViewXform {
     float kr[9];  // K @ R
     float kt[3];  // K @ t
+    int separate; // blas_mode == PDEPTH_BLAS_SEPARATE
 };
+
+__device__ __forceinline__ float dot3_blas(int separate, float a0, float b0, float a1, float b1,
+                                           float a2, float b2) {
+    const float p0 = a0 * b0;
+    if (separate) {
+        const float p1 = a1 * b1;
+        const float p2 = a2 * b2;
+        return (p0 + p1) + p2;
+    }
+    return __builtin_fmaf(a2, b2, __builtin_fmaf(a1, b1, p0));
+}
 
 __device__ __forceinline__ void make_view_xform(const float* __restrict__ K,
                                                 const float* __restrict__ R,
-                                                const float* __restrict__ t, ViewXform& x) {
+                                                const float* __restrict__ t, int blas_mode,
+                                                ViewXform& x) {
+    x.separate = blas_mode;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            float acc = K[i * 3 + 0] * R[0 * 3 + j];
-            acc = __builtin_fmaf(K[i * 3 + 1], R[1 * 3 + j], acc);
-            acc = __builtin_fmaf(K[i * 3 + 2], R[2 * 3 + j], acc);
-            x.kr[i * 3 + j] = acc;
-        }
+        for (int j = 0; j < 3; ++j)
+            x.kr[i * 3 + j] = dot3_blas(x.separate, K[i * 3 + 0], R[0 * 3 + j], K[i * 3 + 1],
+                                        R[1 * 3 + j], K[i * 3 + 2], R[2 * 3 + j]);
         const float p0 = K[i * 3 + 0] * t[0];
         const float p1 = K[i * 3 + 1] * t[1];
         const float p2 = K[i * 3 + 2] * t[2];
-        x.kt[i] = (p1 + p2) + p0;
+        x.kt[i] = x.separate ? (p0 + p1) + p2 : (p1 + p2) + p0;
     }
 }
 
 // term2 = (K@R) @ ray for one pixel.
 __device__ __forceinline__ void ray_term2(const ViewXform& x, float r0, float r1, float r2,
                                           float& a, float& b, float& c) {
-    a = __builtin_fmaf(x.kr[2], r2, __builtin_fmaf(x.kr[1], r1, x.kr[0] * r0));
-    b = __builtin_fmaf(x.kr[5], r2, __builtin_fmaf(x.kr[4], r1, x.kr[3] * r0));
-    c = __builtin_fmaf(x.kr[8], r2, __builtin_fmaf(x.kr[7], r1, x.kr[6] * r0));
+    a = dot3_blas(x.separate, x.kr[0], r0, x.kr[1], r1, x.kr[2], r2);
+    b = dot3_blas(x.separate, x.kr[3], r0, x.kr[4], r1, x.kr[5], r2);
+    c = dot3_blas(x.separate, x.kr[6], r0, x.kr[7], r1, x.kr[8], r2);
 }
 
 // Un-normalised sample position of one pixel on one depth plane.

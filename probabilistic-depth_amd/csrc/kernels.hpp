@@ -22,6 +22,7 @@ struct SweepArgs {
     float* depth_out;  // [B,H,W]   or nullptr
     int B, V, C, D, H, W;
     int metric;
+    int blas_mode;
     float sigma;
     long long ref_bstride, src_bstride, src_vstride;
 };

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a) {
     for (int v = 0; v < a.V; ++v) {
         ViewXform xf;
         make_view_xform(a.K + b * 9, a.R + ((size_t)b * a.V + v) * 9,
-                        a.t + ((size_t)b * a.V + v) * 3, xf);
+                        a.t + ((size_t)b * a.V + v) * 3, a.blas_mode, xf);
         float t2a, t2b, t2c;
         ray_term2(xf, r0, r1, r2, t2a, t2b, t2c);
         const float* srcv = a.src + (size_t)b * a.src_bstride + (size_t)v * a.src_vstride;

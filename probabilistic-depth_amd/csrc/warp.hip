@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void warp_feature_kernel(SweepArgs a, float* _
     const int v = blockIdx.y;
     const int b = blockIdx.z;
     ViewXform xf;
-    make_view_xform(a.K + b * 9, a.R + ((size_t)b * a.V + v) * 9, a.t + ((size_t)b * a.V + v) * 3, xf);
+    make_view_xform(a.K + b * 9, a.R + ((size_t)b * a.V + v) * 9, a.t + ((size_t)b * a.V + v) * 3, a.blas_mode, xf);
     float t2a, t2b, t2c;
     ray_term2(xf, a.rays[((size_t)b * 3 + 0) * HW + pix], a.rays[((size_t)b * 3 + 1) * HW + pix],
               a.rays[((size_t)b * 3 + 2) * HW + pix], t2a, t2b, t2c);
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void sample_coords_kernel(SweepArgs a, float* 
     const int v = blockIdx.y;
     const int b = blockIdx.z;
     ViewXform xf;
-    make_view_xform(a.K + b * 9, a.R + ((size_t)b * a.V + v) * 9, a.t + ((size_t)b * a.V + v) * 3, xf);
+    make_view_xform(a.K + b * 9, a.R + ((size_t)b * a.V + v) * 9, a.t + ((size_t)b * a.V + v) * 3, a.blas_mode, xf);
     float t2a, t2b, t2c;
     ray_term2(xf, a.rays[((size_t)b * 3 + 0) * HW + pix], a.rays[((size_t)b * 3 + 1) * HW + pix],
               a.rays[((size_t)b * 3 + 2) * HW + pix], t2a, t2b, t2c);

@@ -12,6 +12,7 @@ from . import _native
 
 METRICS = {"L2": _native.METRIC_L2, "L1": _native.METRIC_L1}
 ALGOS = {"auto": _native.ALGO_AUTO, "direct": _native.ALGO_DIRECT}
+BLAS_MODES = {"fma": _native.BLAS_FMA, "separate": _native.BLAS_SEPARATE, None: None}
 
 
 def _metric(feat_dist):
@@ -29,22 +30,26 @@ def d_candi_tensor(d_candi, device):
     return torch.from_numpy(np.asarray(d_candi).astype(np.float32)).to(device)
 
 
-def sweep_cost(ref, src, K, R, t, rays, cxcy, d_candi, sigma, feat_dist="L2", algo="auto"):
-    """cost [B,D,H,W].  Batched est_swp_volume_v4 (warping/homography.py:98-135)."""
+def sweep_cost(ref, src, K, R, t, rays, cxcy, d_candi, sigma, feat_dist="L2", algo="auto", blas=None):
+    """cost [B,D,H,W].  Batched est_swp_volume_v4 (warping/homography.py:98-135).
+
+    blas: None = reproduce the rounding of THIS host's CPU BLAS (see _native.host_blas_mode),
+    "fma" / "separate" to force one (golden fixtures record the mode of the host that made them).
+    """
     cost, _, _ = _native.sweep(ref, src, K, R, t, rays, cxcy, d_candi_tensor(d_candi, ref.device), sigma,
-                               _metric(feat_dist), ALGOS[algo], want_cost=True)
+                               _metric(feat_dist), ALGOS[algo], want_cost=True, blas_mode=BLAS_MODES[blas])
     return cost
 
 
 def sweep_dpv(ref, src, K, R, t, rays, cxcy, d_candi, sigma, feat_dist="L2", algo="auto",
-              want_cost=False, want_logp=True, want_depth=True):
+              want_cost=False, want_logp=True, want_depth=True, blas=None):
     """Fused sweep -> log_softmax(dim=1) -> E[d].  Returns (cost|None, logp|None, depth|None).
 
     models/packnet.py:380-394 + utils/img_utils.py:52-61 in one kernel.
     """
     return _native.sweep(ref, src, K, R, t, rays, cxcy, d_candi_tensor(d_candi, ref.device), sigma,
                          _metric(feat_dist), ALGOS[algo], want_cost=want_cost, want_logp=want_logp,
-                         want_depth=want_depth)
+                         want_depth=want_depth, blas_mode=BLAS_MODES[blas])
 
 
 def dpv_reduce(logits, d_candi, want_logp=True, want_depth=True, inplace=False):
@@ -57,10 +62,12 @@ def dpv_expect(dpv, d_candi, BV_log=False):
     return _native.dpv_expect(dpv, d_candi_tensor(d_candi, dpv.device), BV_log)
 
 
-def warp_feature(src, K, R, t, rays, cxcy, d_candi):
+def warp_feature(src, K, R, t, rays, cxcy, d_candi, blas=None):
     """[B,V,D,H,W] diagonal warp (warping/homography.py:137-168, batched)."""
-    return _native.warp_feature(src, K, R, t, rays, cxcy, d_candi_tensor(d_candi, src.device))
+    return _native.warp_feature(src, K, R, t, rays, cxcy, d_candi_tensor(d_candi, src.device),
+                                blas_mode=BLAS_MODES[blas])
 
 
-def sample_coords(K, R, t, rays, cxcy, d_candi, H, W):
-    return _native.sample_coords(K, R, t, rays, cxcy, d_candi_tensor(d_candi, K.device), H, W)
+def sample_coords(K, R, t, rays, cxcy, d_candi, H, W, blas=None):
+    return _native.sample_coords(K, R, t, rays, cxcy, d_candi_tensor(d_candi, K.device), H, W,
+                                 blas_mode=BLAS_MODES[blas])

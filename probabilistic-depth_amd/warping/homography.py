@@ -24,7 +24,7 @@ def _camera_tensors(cam_intrinsic, device):
 
 
 def est_swp_volume_v4(feat_img_ref, feat_img_src, d_candi, R, t, cam_intrinsic, costV_sigma,
-                      feat_dist="L2", debug_ipdb=False):
+                      feat_dist="L2", debug_ipdb=False, blas=None):
     r"""
     feat_img_ref - NCHW tensor (N == 1)
     feat_img_src - NVCHW tensor.  V is for different views
@@ -38,10 +38,10 @@ def est_swp_volume_v4(feat_img_ref, feat_img_src, d_candi, R, t, cam_intrinsic, 
     R = R.to(device=device, dtype=torch.float32).reshape(1, V, 3, 3)
     t = t.to(device=device, dtype=torch.float32).reshape(1, V, 3)
     return ops.sweep_cost(feat_img_ref[:1], feat_img_src[:1], K, R, t, rays, cxcy, d_candi, costV_sigma,
-                          feat_dist=feat_dist)
+                          feat_dist=feat_dist, blas=blas)
 
 
-def warp_feature(feat_img_src, d_candi, R, t, cam_intrinsic):
+def warp_feature(feat_img_src, d_candi, R, t, cam_intrinsic, blas=None):
     r"""
     feat_img_src - NVCHW tensor (N == 1, C == len(d_candi)); channel i is warped with plane i
     returns [1, V, C, H, W]
@@ -53,7 +53,7 @@ def warp_feature(feat_img_src, d_candi, R, t, cam_intrinsic):
     K, rays, cxcy = _camera_tensors(cam_intrinsic, device)
     R = R.to(device=device, dtype=torch.float32).reshape(1, V, 3, 3)
     t = t.to(device=device, dtype=torch.float32).reshape(1, V, 3)
-    return ops.warp_feature(feat_img_src, K, R, t, rays, cxcy, d_candi)
+    return ops.warp_feature(feat_img_src, K, R, t, rays, cxcy, d_candi, blas=blas)
 
 
 def get_rel_extrinsicM(ext_ref, ext_src):

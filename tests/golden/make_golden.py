@@ -20,6 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
 REF = "/root/reference"
 sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
 sys.path.insert(0, REF)
 
 import numpy as np  # noqa: E402
@@ -72,7 +73,12 @@ def _rays_and_K(view, w, h, hfov, vfov):
 def main():
     homo, view, img_utils = _import_reference()
     torch.manual_seed(1234)
-    meta = dict(torch=torch.__version__, cpu_capability=torch.backends.cpu.get_cpu_capability())
+    import pdepth_amd
+    from util_host import cpu_vendor
+    # blas_mode: how THIS host's MKL rounds K@R / K@t / (K@R)@rays (include/pdepth.h PDEPTH_BLAS_*);
+    # the HIP kernels are asked for the same mode when they are checked against these fixtures.
+    meta = dict(torch=torch.__version__, cpu_capability=torch.backends.cpu.get_cpu_capability(),
+                cpu_vendor=cpu_vendor(), blas_mode=np.int32(pdepth_amd._native.host_blas_mode()))
     save = lambda name, **kw: np.savez_compressed(os.path.join(HERE, name), **kw, **{"meta_" + k: v for k, v in meta.items()})
 
     # ---- G1/G2/G3: tiny sweeps (16x24, C=7, D=8, V=2), off-centre principal point -------

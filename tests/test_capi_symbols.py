@@ -31,19 +31,41 @@ def test_library_exports_every_declared_symbol():
 
 def test_argument_validation_without_gpu():
     lib = _native.load()
-    desc = _native.SweepDesc(0, 1, 1, 1, 1, 1, 0, 0, 10.0, 0, 0, 1)
+    desc = _native.SweepDesc(0, 1, 1, 1, 1, 1, 0, 0, 0, 10.0, 0, 0, 1)
     cam = _native.Camera(None, None, None, None, None)
     rc = lib.pdepth_sweep_cost_f32(ctypes.byref(desc), ctypes.byref(cam), None, None, None, 1, None, 0, None)
     assert rc == 1 and b"non-positive" in lib.pdepth_last_error()
     rc = lib.pdepth_dpv_reduce_f32(None, None, 1, 1, 1, 1, None, None, None)
     assert rc == 1 and b"null input" in lib.pdepth_last_error()
-    desc = _native.SweepDesc(1, 1, 4, 8, 2, 2, 0, 0, 1.0, 0, 0, 16)
+    desc = _native.SweepDesc(1, 1, 4, 8, 2, 2, 0, 0, 0, 1.0, 0, 0, 16)
     cam = _native.Camera(1, 1, 1, 1, 1)
     rc = lib.pdepth_warp_feature_f32(ctypes.byref(desc), ctypes.byref(cam), 1, 1, 1, None)
     assert rc == 1 and b"C == D" in lib.pdepth_last_error()
-    desc = _native.SweepDesc(1, 1, 4, 8, 2, 2, 7, 0, 1.0, 16, 16, 16)
+    desc = _native.SweepDesc(1, 1, 4, 8, 2, 2, 7, 0, 0, 1.0, 16, 16, 16)
     rc = lib.pdepth_sweep_dpv_f32(ctypes.byref(desc), ctypes.byref(cam), 1, 1, 1, 1, None, None, None, 0, None)
     assert rc == 1 and b"undefined metric" in lib.pdepth_last_error()
+    desc = _native.SweepDesc(1, 1, 4, 8, 2, 2, 0, 0, 5, 1.0, 16, 16, 16)
+    rc = lib.pdepth_sweep_dpv_f32(ctypes.byref(desc), ctypes.byref(cam), 1, 1, 1, 1, None, None, None, 0, None)
+    assert rc == 1 and b"blas_mode" in lib.pdepth_last_error()
+
+
+def test_host_blas_probe_is_decisive():
+    """The probe must reproduce torch's CPU matmul exactly with one of the two documented modes."""
+    import numpy as np
+    import torch
+    mode = _native.host_blas_mode()
+    assert mode in (_native.BLAS_FMA, _native.BLAS_SEPARATE)
+    A = torch.randn(3, 3) * 50
+    Bm = torch.randn(3, 777)
+    C = A.matmul(Bm).numpy()
+    a, b = A.numpy().astype(np.float64), Bm.numpy().astype(np.float64)
+    p = [a[:, k:k + 1] * b[k:k + 1, :] for k in range(3)]
+    f32 = np.float32
+    if mode == _native.BLAS_FMA:
+        want = ((p[0].astype(f32).astype(np.float64) + p[1]).astype(f32).astype(np.float64) + p[2]).astype(f32)
+    else:
+        want = ((p[0].astype(f32) + p[1].astype(f32)).astype(f32) + p[2].astype(f32)).astype(f32)
+    assert np.array_equal(want, C)
 
 
 def test_product_path_has_no_cpu_fallback():

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-import pdepth_amd  # noqa: F401
+import pdepth_amd
 from pdepth_amd import synth
 from oracle import ref_cpu as O
 
@@ -22,14 +22,26 @@ def fma(a, b, c):
             + np.asarray(c, f32).astype(np.float64)).astype(f32)
 
 
+def dot3(separate, a0, b0, a1, b1, a2, b2):
+    p0 = (np.asarray(a0, f32) * np.asarray(b0, f32)).astype(f32)
+    if separate:
+        p1 = (np.asarray(a1, f32) * np.asarray(b1, f32)).astype(f32)
+        p2 = (np.asarray(a2, f32) * np.asarray(b2, f32)).astype(f32)
+        return ((p0 + p1).astype(f32) + p2).astype(f32)
+    return fma(a2, b2, fma(a1, b1, p0))
+
+
 def emulate_coords(K, R, t, rays, d_candi, cx, cy, h, w):
+    """csrc/geometry.hpp in numpy, with the BLAS rounding mode the host probe selected."""
+    sep = pdepth_amd._native.host_blas_mode() == pdepth_amd._native.BLAS_SEPARATE
     KR = np.zeros((3, 3), f32)
     kt = np.zeros(3, f32)
     for i in range(3):
         for j in range(3):
-            KR[i, j] = fma(K[i, 2], R[2, j], fma(K[i, 1], R[1, j], f32(K[i, 0] * R[0, j])))
-        kt[i] = f32(f32(f32(K[i, 1] * t[1]) + f32(K[i, 2] * t[2])) + f32(K[i, 0] * t[0]))
-    T2 = np.stack([fma(KR[i, 2], rays[2], fma(KR[i, 1], rays[1], (KR[i, 0] * rays[0]).astype(f32))) for i in range(3)])
+            KR[i, j] = dot3(sep, K[i, 0], R[0, j], K[i, 1], R[1, j], K[i, 2], R[2, j])
+        p = [f32(K[i, k] * t[k]) for k in range(3)]
+        kt[i] = f32(f32(p[0] + p[1]) + p[2]) if sep else f32(f32(p[1] + p[2]) + p[0])
+    T2 = np.stack([dot3(sep, KR[i, 0], rays[0], KR[i, 1], rays[1], KR[i, 2], rays[2]) for i in range(3)])
     d = np.asarray(d_candi).astype(f32)
     P = (kt[None, :, None] + (T2[None] * d[:, None, None]).astype(f32)).astype(f32)
     den = (P[:, 2] + f32(1e-10)).astype(f32)

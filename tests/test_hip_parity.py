@@ -14,7 +14,7 @@ from pdepth_amd import ops, synth
 from pdepth_amd.utils import img_utils
 from pdepth_amd.warping import homography
 from oracle import ref_cpu as O
-from util import DEPTH_ATOL, golden, oracle_batch, to_dev
+from util import DEPTH_ATOL, golden, golden_blas, oracle_batch, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +42,7 @@ def test_golden_tiny_sweeps(dev, name, metric):
     cost = homography.est_swp_volume_v4(torch.from_numpy(g["ref"]).to(dev), torch.from_numpy(g["src"]).to(dev),
                                         g["d_candi"], torch.from_numpy(g["R"]).to(dev),
                                         torch.from_numpy(g["t"]).to(dev), _cam(g, dev), float(g["sigma"]),
-                                        feat_dist=metric)
+                                        feat_dist=metric, blas=golden_blas(g))
     assert cost.shape == (1, 8, 16, 24) and cost.device.type == "cuda"
     np.testing.assert_allclose(cost.cpu().numpy(), g["cost_" + metric], rtol=COST_RTOL, atol=COST_ATOL)
 
@@ -54,7 +54,7 @@ def test_golden_model_real(dev, name):
     it = synth.make_item(**kw)
     b = to_dev({k: (v[None] if isinstance(v, torch.Tensor) else v) for k, v in it.items()}, dev)
     cost, logp, depth = ops.sweep_dpv(b["ref"], b["src"], b["K"], b["R"], b["t"], b["rays"], b["cxcy"],
-                                      b["d_candi"], 10.0, want_cost=True)
+                                      b["d_candi"], 10.0, want_cost=True, blas=golden_blas(g))
     np.testing.assert_allclose(cost.cpu().numpy()[:, ::4, ::2, ::2], g["cost_sub"], rtol=COST_RTOL, atol=COST_ATOL)
     np.testing.assert_allclose(logp.cpu().numpy()[:, ::4, ::2, ::2], g["logp_sub"], rtol=COST_RTOL, atol=COST_ATOL)
     err = np.abs(depth.cpu().numpy() - g["depth"]).max()
@@ -79,7 +79,7 @@ def test_golden_dpv(dev):
 def test_golden_warp_feature(dev):
     g = golden("g6_warp_feature.npz")
     out = homography.warp_feature(torch.from_numpy(g["feat"]).to(dev), g["d_candi"], torch.from_numpy(g["R"]).to(dev),
-                                  torch.from_numpy(g["t"]).to(dev), _cam(g, dev))
+                                  torch.from_numpy(g["t"]).to(dev), _cam(g, dev), blas=golden_blas(g))
     np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-6, atol=1e-6)
     with pytest.raises(Exception, match="Warped Accum Error"):
         homography.warp_feature(torch.zeros(2, 1, 8, 4, 4, device=dev), g["d_candi"], None, None, _cam(g, dev))

@@ -17,8 +17,16 @@ def golden(name):
 
 
 def same_cpu_as_golden(g):
-    return str(g["meta_cpu_capability"]) == torch.backends.cpu.get_cpu_capability() and \
-        str(g["meta_torch"]) == torch.__version__
+    """True when this host runs the same torch build on the same CPU family as the fixture's host
+    (then the oracle must be BIT-identical; elsewhere MKL/vector-width drift is tolerated)."""
+    from util_host import cpu_vendor
+    return (str(g["meta_cpu_capability"]) == torch.backends.cpu.get_cpu_capability()
+            and str(g["meta_torch"]) == torch.__version__ and str(g["meta_cpu_vendor"]) == cpu_vendor())
+
+
+def golden_blas(g):
+    """'fma' | 'separate': BLAS rounding of the host that generated fixture g."""
+    return "separate" if int(g["meta_blas_mode"]) == 1 else "fma"
 
 
 def oracle_item(it, metric="L2", sigma=10.0):
