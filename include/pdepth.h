@@ -113,7 +113,8 @@ int pdepth_sweep_dpv_f32(const pdepth_sweep_desc *desc, const pdepth_camera *cam
                          float *cost, float *logp, float *depth,
                          void *workspace, size_t workspace_bytes, void *stream);
 
-/* Bytes of scratch the two sweep entry points need for `desc` (0 for ALGO_DIRECT). */
+/* Bytes of scratch the two sweep entry points need for `desc` (0 for ALGO_DIRECT); the workspace
+ * must be 256-byte aligned.  ALGO_AUTO without it returns PDEPTH_E_WORKSPACE. */
 size_t pdepth_sweep_workspace_bytes(const pdepth_sweep_desc *desc);
 
 /*

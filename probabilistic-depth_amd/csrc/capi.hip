@@ -54,9 +54,15 @@ int launched(hipError_t e, const char* who) {
     return PDEPTH_OK;
 }
 
+// The tiled kernel needs the tile-flag array (and a D x H x W scratch volume when neither cost nor
+// logp is requested); ALGO_AUTO uses it whenever the caller supplied that workspace.
+size_t tiled_ws_bytes(const pdepth_sweep_desc* d, bool need_scratch) {
+    return pdepth::sweep_tiled_workspace_bytes(d->B, d->D, d->H, d->W, need_scratch);
+}
+
 int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const float* ref,
                  const float* src, const float* d_candi, float* cost, float* logp, float* depth,
-                 void* stream, const char* who) {
+                 void* workspace, size_t workspace_bytes, void* stream, const char* who) {
     if (int rc = check_desc(d, cam, who)) return rc;
     if (!ref || !src || !d_candi) return fail(PDEPTH_E_ARG, "%s: null input pointer", who);
     if (!cost && !logp && !depth) return fail(PDEPTH_E_ARG, "%s: no output requested", who);
@@ -71,6 +77,15 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
                     d->D, pdepth::sweep_direct_max_planes(d->C), d->C);
     pdepth::SweepArgs a = make_args(d, cam, ref, src, d_candi);
     a.cost_out = cost; a.logp_out = logp; a.depth_out = depth;
+    if (d->algo == PDEPTH_ALGO_AUTO) {
+        const size_t need = tiled_ws_bytes(d, !cost && !logp);
+        if (!workspace || workspace_bytes < need)
+            return fail(PDEPTH_E_WORKSPACE, "%s: ALGO_AUTO needs %zu bytes of workspace (got %zu); "
+                        "query pdepth_sweep_workspace_bytes()", who, need, workspace_bytes);
+        if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0)
+            return fail(PDEPTH_E_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
+        return launched(pdepth::launch_sweep_tiled(a, workspace, (hipStream_t)stream), who);
+    }
     return launched(pdepth::launch_sweep_direct(a, (hipStream_t)stream), who);
 }
 
@@ -82,24 +97,23 @@ int pdepth_abi_version(void) { return PDEPTH_ABI_VERSION; }
 const char* pdepth_last_error(void) { return g_err; }
 
 size_t pdepth_sweep_workspace_bytes(const pdepth_sweep_desc* desc) {
-    (void)desc;
-    return 0;
+    if (!desc || desc->algo != PDEPTH_ALGO_AUTO) return 0;
+    if (desc->B <= 0 || desc->D <= 0 || desc->H <= 0 || desc->W <= 0) return 0;
+    return tiled_ws_bytes(desc, true);  // worst case: depth-only output needs the scratch volume
 }
 
 int pdepth_sweep_cost_f32(const pdepth_sweep_desc* desc, const pdepth_camera* cam, const float* ref,
                           const float* src, const float* d_candi, float* cost, void* workspace,
                           size_t workspace_bytes, void* stream) {
-    (void)workspace; (void)workspace_bytes;
     if (!cost) return fail(PDEPTH_E_ARG, "pdepth_sweep_cost_f32: null output");
-    return sweep_common(desc, cam, ref, src, d_candi, cost, nullptr, nullptr, stream,
-                        "pdepth_sweep_cost_f32");
+    return sweep_common(desc, cam, ref, src, d_candi, cost, nullptr, nullptr, workspace, workspace_bytes,
+                        stream, "pdepth_sweep_cost_f32");
 }
 
 int pdepth_sweep_dpv_f32(const pdepth_sweep_desc* desc, const pdepth_camera* cam, const float* ref,
                          const float* src, const float* d_candi, float* cost, float* logp,
                          float* depth, void* workspace, size_t workspace_bytes, void* stream) {
-    (void)workspace; (void)workspace_bytes;
-    return sweep_common(desc, cam, ref, src, d_candi, cost, logp, depth, stream,
+    return sweep_common(desc, cam, ref, src, d_candi, cost, logp, depth, workspace, workspace_bytes, stream,
                         "pdepth_sweep_dpv_f32");
 }
 

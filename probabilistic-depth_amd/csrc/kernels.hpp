@@ -29,7 +29,13 @@ struct SweepArgs {
 
 // sweep_direct.hip
 hipError_t launch_sweep_direct(const SweepArgs& a, hipStream_t stream);
+hipError_t launch_sweep_direct_flagged(const SweepArgs& a, const int* tile_flags, int tiles_x, int tiles,
+                                       hipStream_t stream);
 int sweep_direct_max_planes(int C);
+
+// sweep_tiled.hip
+size_t sweep_tiled_workspace_bytes(int B, int D, int H, int W, bool need_scratch);
+hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t stream);
 
 // dpv.hip
 hipError_t launch_dpv_reduce(const float* logits, const float* d_candi, int B, int D, int H,

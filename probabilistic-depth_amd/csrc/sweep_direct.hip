@@ -16,14 +16,29 @@
 
 namespace pdepth {
 
+// tile_flags == nullptr : block i owns pixels [64 i, 64 i + 64) of the flattened image.
+// tile_flags != nullptr : block i owns quarter (i & 3) -- 16 wide x 4 tall -- of 16x16 tile (i >> 2)
+//                         and runs only if the tiled kernel flagged that tile (sweep_tiled.hip).
 template <int METRIC, int CCH, bool MULTI_CHUNK>
-__global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a) {
+__global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int* __restrict__ tile_flags,
+                                                          int tiles_x, int tiles) {
     extern __shared__ float lds[];
     const int tid = threadIdx.x;
     const int HW = a.H * a.W;
     const int b = blockIdx.y;
-    const int pix = blockIdx.x * 64 + tid;
-    const bool live = pix < HW;
+    int pix;
+    bool live;
+    if (tile_flags) {
+        const int tile = blockIdx.x >> 2;
+        if (tile_flags[b * tiles + tile] == 0) return;  // block-uniform
+        const int x = (tile % tiles_x) * 16 + (tid & 15);
+        const int y = (tile / tiles_x) * 16 + (blockIdx.x & 3) * 4 + (tid >> 4);
+        live = x < a.W && y < a.H;
+        pix = y * a.W + x;
+    } else {
+        pix = blockIdx.x * 64 + tid;
+        live = pix < HW;
+    }
     const int p = live ? pix : HW - 1;  // dead lanes shadow the last pixel, never store
 
     float* cost = lds;                                  // [D][64]
@@ -112,24 +127,38 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a) {
 }
 
 template <int METRIC>
-static hipError_t launch_metric(const SweepArgs& a, hipStream_t stream) {
+static hipError_t launch_metric(const SweepArgs& a, const int* tile_flags, int tiles_x, int tiles,
+                                hipStream_t stream) {
     const int HW = a.H * a.W;
-    dim3 grid((HW + 63) / 64, a.B);
+    dim3 grid(tile_flags ? tiles * 4 : (HW + 63) / 64, a.B);
     if (a.C <= 68) {
         const size_t lds = (size_t)a.D * 64 * sizeof(float);
-        hipLaunchKernelGGL((sweep_direct_kernel<METRIC, 68, false>), grid, dim3(64), lds, stream, a);
+        auto kern = sweep_direct_kernel<METRIC, 68, false>;
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, a, tile_flags, tiles_x, tiles);
     } else {
         const size_t lds = (size_t)a.D * 64 * sizeof(float) * 2;
-        hipLaunchKernelGGL((sweep_direct_kernel<METRIC, 32, true>), grid, dim3(64), lds, stream, a);
+        auto kern = sweep_direct_kernel<METRIC, 32, true>;
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, a, tile_flags, tiles_x, tiles);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_sweep_direct(const SweepArgs& a, hipStream_t stream) {
-    return a.metric == 0 ? launch_metric<0>(a, stream) : launch_metric<1>(a, stream);
+    return a.metric == 0 ? launch_metric<0>(a, nullptr, 0, 0, stream)
+                         : launch_metric<1>(a, nullptr, 0, 0, stream);
+}
+
+hipError_t launch_sweep_direct_flagged(const SweepArgs& a, const int* tile_flags, int tiles_x, int tiles,
+                                       hipStream_t stream) {
+    return a.metric == 0 ? launch_metric<0>(a, tile_flags, tiles_x, tiles, stream)
+                         : launch_metric<1>(a, tile_flags, tiles_x, tiles, stream);
 }
 
 // Largest D the direct kernel can hold in LDS (two arrays in the chunked variant).
-int sweep_direct_max_planes(int C) { return C <= 68 ? 512 : 256; }
+int sweep_direct_max_planes(int C) { return C <= 68 ? 512 : 256; }  // 128 KB of LDS
 
 }  // namespace pdepth

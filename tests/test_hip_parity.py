@@ -112,22 +112,60 @@ def test_sample_coordinates_bit_exact(dev, pose, H, W, off):
     dict(C=64, D=64, H=32, W=64, V=1, pose="mono", peaked=True),
 ])
 @pytest.mark.parametrize("metric", ["L2", "L1"])
-def test_sweep_matches_oracle(dev, cfg, metric):
+@pytest.mark.parametrize("algo", ["auto", "direct"])
+def test_sweep_matches_oracle(dev, cfg, metric, algo):
     if metric == "L1" and cfg["D"] == 128:
         pytest.skip("covered by L2")
     b = synth.make_batch(31, 2, **cfg)
-    ocost, ologp, odepth = oracle_batch(b, metric)
+    ocost, ologp, odepth = _oracle_cached(repr(sorted(cfg.items())), metric, b)
     d = to_dev(b, dev)
     cost, logp, depth = ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"],
-                                      d["d_candi"], 10.0, feat_dist=metric, want_cost=True)
+                                      d["d_candi"], 10.0, feat_dist=metric, want_cost=True, algo=algo)
     np.testing.assert_allclose(cost.cpu().numpy(), ocost.numpy(), rtol=COST_RTOL, atol=COST_ATOL)
     np.testing.assert_allclose(logp.cpu().numpy(), ologp.numpy(), rtol=COST_RTOL, atol=COST_ATOL)
     err = (depth.cpu() - odepth).abs().max().item()
     assert err <= DEPTH_ATOL, f"depth differs from the CPU oracle by {err:.3e}"
     # cost-only entry point returns the same volume
     cost2 = ops.sweep_cost(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0,
-                           feat_dist=metric)
+                           feat_dist=metric, algo=algo)
     assert torch.equal(cost, cost2)
+    # depth-only request (tiled kernel then keeps its costs in workspace scratch)
+    _, _, depth3 = ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"],
+                                 10.0, feat_dist=metric, want_cost=False, want_logp=False, want_depth=True, algo=algo)
+    assert torch.equal(depth, depth3)
+
+
+_ORACLE_CACHE = {}
+
+
+def _oracle_cached(key, metric, batch):
+    if (key, metric) not in _ORACLE_CACHE:
+        _ORACLE_CACHE[(key, metric)] = oracle_batch(batch, metric)
+    return _ORACLE_CACHE[(key, metric)]
+
+
+@pytest.mark.parametrize("pose_kind", ["big_rotation", "sideways", "behind"])
+def test_tiled_falls_back_to_gather_on_extreme_poses(dev, pose_kind):
+    """Windows that do not fit LDS (or samples behind the camera) take the gather kernel tile by tile;
+    the result must equal the all-gather path (same arithmetic order per pixel)."""
+    b = synth.make_batch(41, 2, C=12, D=16, H=40, W=72, V=2, pose="mono")
+    R = b["R"].clone(); t = b["t"].clone()
+    if pose_kind == "big_rotation":
+        c, s_ = np.cos(0.6), np.sin(0.6)
+        R[:, 0] = torch.tensor([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], dtype=torch.float32)  # 34 deg roll
+    elif pose_kind == "sideways":
+        t[:, 0] = torch.tensor([6.0, 2.0, 0.0])
+    else:
+        t[:, 1] = torch.tensor([0.0, 0.0, -20.0])  # some planes end up behind the source camera
+    b["R"], b["t"] = R, t
+    d = to_dev(b, dev)
+    args = (d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0)
+    c_auto, l_auto, d_auto = ops.sweep_dpv(*args, want_cost=True, algo="auto")
+    c_dir, l_dir, d_dir = ops.sweep_dpv(*args, want_cost=True, algo="direct")
+    np.testing.assert_allclose(c_auto.cpu().numpy(), c_dir.cpu().numpy(), rtol=1e-5, atol=1e-5, equal_nan=True)
+    np.testing.assert_allclose(d_auto.cpu().numpy(), d_dir.cpu().numpy(), rtol=0, atol=DEPTH_ATOL, equal_nan=True)
+    ocost, _, odepth = oracle_batch(b)
+    np.testing.assert_allclose(c_auto.cpu().numpy(), ocost.numpy(), rtol=COST_RTOL, atol=COST_ATOL, equal_nan=True)
 
 
 def test_strided_views_no_copy(dev):
