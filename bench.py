@@ -130,6 +130,7 @@ def main():
                          "kernel": "fused sweep+DPV", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "per_rank_kernel_ms": [float(x) for x in allm[:, 1]],
+            "gather_fallback_tiles": pdepth_amd._native.fallback_tiles(hi - lo, cfg["H"], cfg["W"]),
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)

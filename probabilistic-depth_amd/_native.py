@@ -196,7 +196,20 @@ def sweep(ref, src, K, R, t, rays, cxcy, d_candi, sigma, metric=METRIC_L2, algo=
             _stream(dev))
     _check(rc, lib)
     del keep
+    global _last_workspace
+    _last_workspace = ws  # diagnostics only: tile flags of the last sweep (see fallback_tiles())
     return cost, logp, depth
+
+
+_last_workspace = None
+
+
+def fallback_tiles(B, H, W):
+    """Diagnostics: how many 16x4 tiles of the last ALGO_AUTO sweep were left to the gather kernel."""
+    if _last_workspace is None:
+        return 0
+    n = B * ((W + 15) // 16) * ((H + 3) // 4)
+    return int(_last_workspace[: 4 * n].view(torch.int32).sum().item())
 
 
 def dpv_reduce(logits, d_candi, want_logp=True, want_depth=True, inplace=False):

@@ -54,10 +54,9 @@ int launched(hipError_t e, const char* who) {
     return PDEPTH_OK;
 }
 
-// The tiled kernel needs the tile-flag array (and a D x H x W scratch volume when neither cost nor
-// logp is requested); ALGO_AUTO uses it whenever the caller supplied that workspace.
-size_t tiled_ws_bytes(const pdepth_sweep_desc* d, bool need_scratch) {
-    return pdepth::sweep_tiled_workspace_bytes(d->B, d->D, d->H, d->W, need_scratch);
+// The tiled kernel needs one int per 16x4 tile (flags of tiles left to the gather kernel).
+size_t tiled_ws_bytes(const pdepth_sweep_desc* d) {
+    return pdepth::sweep_tiled_workspace_bytes(d->B, d->H, d->W);
 }
 
 int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const float* ref,
@@ -77,8 +76,10 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
                     d->D, pdepth::sweep_direct_max_planes(d->C), d->C);
     pdepth::SweepArgs a = make_args(d, cam, ref, src, d_candi);
     a.cost_out = cost; a.logp_out = logp; a.depth_out = depth;
-    if (d->algo == PDEPTH_ALGO_AUTO) {
-        const size_t need = tiled_ws_bytes(d, !cost && !logp);
+    // the tiled kernel addresses one view through a 32-bit buffer descriptor (C*H*W*4 bytes < 2^31)
+    if (d->algo == PDEPTH_ALGO_AUTO && d->D <= pdepth::sweep_tiled_max_planes() &&
+        (long long)d->C * d->H * d->W * 4 < (1ll << 31)) {
+        const size_t need = tiled_ws_bytes(d);
         if (!workspace || workspace_bytes < need)
             return fail(PDEPTH_E_WORKSPACE, "%s: ALGO_AUTO needs %zu bytes of workspace (got %zu); "
                         "query pdepth_sweep_workspace_bytes()", who, need, workspace_bytes);
@@ -99,7 +100,7 @@ const char* pdepth_last_error(void) { return g_err; }
 size_t pdepth_sweep_workspace_bytes(const pdepth_sweep_desc* desc) {
     if (!desc || desc->algo != PDEPTH_ALGO_AUTO) return 0;
     if (desc->B <= 0 || desc->D <= 0 || desc->H <= 0 || desc->W <= 0) return 0;
-    return tiled_ws_bytes(desc, true);  // worst case: depth-only output needs the scratch volume
+    return tiled_ws_bytes(desc);
 }
 
 int pdepth_sweep_cost_f32(const pdepth_sweep_desc* desc, const pdepth_camera* cam, const float* ref,

@@ -34,7 +34,8 @@ hipError_t launch_sweep_direct_flagged(const SweepArgs& a, const int* tile_flags
 int sweep_direct_max_planes(int C);
 
 // sweep_tiled.hip
-size_t sweep_tiled_workspace_bytes(int B, int D, int H, int W, bool need_scratch);
+size_t sweep_tiled_workspace_bytes(int B, int H, int W);
+int sweep_tiled_max_planes();
 hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t stream);
 
 // dpv.hip

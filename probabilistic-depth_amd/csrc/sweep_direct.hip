@@ -17,8 +17,8 @@
 namespace pdepth {
 
 // tile_flags == nullptr : block i owns pixels [64 i, 64 i + 64) of the flattened image.
-// tile_flags != nullptr : block i owns quarter (i & 3) -- 16 wide x 4 tall -- of 16x16 tile (i >> 2)
-//                         and runs only if the tiled kernel flagged that tile (sweep_tiled.hip).
+// tile_flags != nullptr : block i owns the 16 wide x 4 tall tile i and runs only if the tiled
+//                         kernel flagged that tile (sweep_tiled.hip).
 template <int METRIC, int CCH, bool MULTI_CHUNK>
 __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int* __restrict__ tile_flags,
                                                           int tiles_x, int tiles) {
@@ -29,10 +29,10 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int
     int pix;
     bool live;
     if (tile_flags) {
-        const int tile = blockIdx.x >> 2;
+        const int tile = blockIdx.x;
         if (tile_flags[b * tiles + tile] == 0) return;  // block-uniform
         const int x = (tile % tiles_x) * 16 + (tid & 15);
-        const int y = (tile / tiles_x) * 16 + (blockIdx.x & 3) * 4 + (tid >> 4);
+        const int y = (tile / tiles_x) * 4 + (tid >> 4);
         live = x < a.W && y < a.H;
         pix = y * a.W + x;
     } else {
@@ -130,7 +130,7 @@ template <int METRIC>
 static hipError_t launch_metric(const SweepArgs& a, const int* tile_flags, int tiles_x, int tiles,
                                 hipStream_t stream) {
     const int HW = a.H * a.W;
-    dim3 grid(tile_flags ? tiles * 4 : (HW + 63) / 64, a.B);
+    dim3 grid(tile_flags ? tiles : (HW + 63) / 64, a.B);
     if (a.C <= 68) {
         const size_t lds = (size_t)a.D * 64 * sizeof(float);
         auto kern = sweep_direct_kernel<METRIC, 68, false>;

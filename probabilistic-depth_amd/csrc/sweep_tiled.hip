@@ -1,26 +1,29 @@
 // LDS-tiled plane sweep: the fast path of pdepth_sweep_{cost,dpv}_f32.
 //
 // Same arithmetic as sweep_direct.hip (reference op order, bit-faithful sample positions) but the
-// bilinear taps come from LDS instead of global memory:
+// bilinear taps come from LDS instead of global memory.
 //
-//   block   = 16x16 reference pixels (256 threads, 4 waves; a wave is 16 wide x 4 tall);
-//   planes  = processed in groups of KP consecutive depth planes.  The per-plane geometry
-//             (tap offset into the LDS window + 4 bilinear weights) of a group lives in registers,
-//             so it is computed ONCE per (pixel, plane, view) -- not once per channel chunk;
-//   window  = bounding box of every tap the block touches in the current plane group, staged
-//             channel-chunk by channel-chunk (4*CG channels) into LDS as float4 texels
-//             [g][row][col] with the row pitch padded to a multiple of 16 texels, which makes the
-//             per-lane ds_read_b128 of a 16x4 wave bank-conflict free.  Texels outside the image
-//             are staged as zeros, which IS padding_mode='zeros' -- no per-tap masks in the loop;
-//   ref     = the block's reference features of the chunk, staged next to the window;
-//   costs   = per-plane costs go to the output volume (cost, else logp, else workspace scratch),
-//             accumulated over views in view order like homography.py:129; the fused epilogue
-//             re-reads the pixel's D costs (L2-hot) for log_softmax + E[d].
+//   block   = 16x4 reference pixels x 4 plane groups = 256 threads.  Wave w of the block owns the
+//             same 64 pixels (lane = 16 wide x 4 tall) and plane group w: KP = 8 consecutive depth
+//             planes of the current "super group" of 4*KP = 32 planes.  The per-plane geometry of a
+//             thread (tap offset into the LDS window + 4 bilinear weights, 8 planes) lives in
+//             registers and is computed ONCE per (pixel, plane, view);
+//   window  = bounding box of every tap the block touches in the current super group, staged four
+//             channels at a time into LDS as float4 texels [row][col] (double buffered: chunk ch+1
+//             travels global -> registers while chunk ch is computed from LDS; one barrier per
+//             chunk).  The row pitch is a multiple of 16 texels, which makes the per-lane
+//             ds_read_b128 of a 16x4 wave bank-conflict free.  Texels outside the image are staged
+//             as zeros, which IS padding_mode='zeros' -- no per-tap masks in the inner loop;
+//   ref     = the tile's reference features of the chunk, staged next to the window;
+//   costs   = cost[k][pixel] of the tile in LDS (D x 64 floats), accumulated over views in view
+//             order like homography.py:129; the fused epilogue (log_softmax over D + E[d]) runs on
+//             those with the 4 waves splitting the planes, so nothing but the requested outputs is
+//             ever written to HBM.
 //
-// Consecutive planes of a group hit neighbouring texels, so a group's window is only a few texels
-// wider than the tile; each HBM byte of the source map is read once into L2 and re-staged from
-// there.  A block whose window does not fit NTEX_MAX texels (extreme poses) raises its tile flag
-// and leaves the tile to the gather kernel of sweep_direct.hip -- results are identical.
+// Consecutive planes hit neighbouring texels, so a super group's window is only a few texels larger
+// than the tile and each source texel is staged from L2 a handful of times per chunk instead of being
+// gathered 4 x D times.  A block whose window does not fit (extreme poses) raises its tile flag and
+// leaves the tile to the gather kernel of sweep_direct.hip -- results are identical.
 #include <hip/hip_runtime.h>
 
 #include "geometry.hpp"
@@ -30,14 +33,13 @@ namespace pdepth {
 
 namespace {
 
-constexpr int TILE = 16;          // tile edge (pixels)
+constexpr int TW = 16, TH = 4;    // tile (pixels); one wave covers it
+constexpr int NPG = 4;            // plane groups per block (= waves)
 constexpr int KP = 8;             // planes per group
-constexpr int CG = 2;             // float4 channel groups per chunk (8 channels)
-constexpr int NTEX_MAX = 1536;    // window texels per chunk group (LDS: NTEX_MAX*CG*16 B = 48 KB)
-
-struct Bbox {
-    int x0, y0, x1, y1;
-};
+constexpr int SG = NPG * KP;      // planes per super group
+constexpr int NBUF = 2;           // LDS window buffers
+constexpr int NTEX_MAX = 1024;    // window texels per buffer (LDS: NTEX_MAX*NBUF*16 B = 32 KB)
+constexpr int SLOTS = 6;          // 16x16 sub-blocks of a window (register-staged prefetch)
 
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
@@ -53,18 +55,23 @@ __device__ __forceinline__ int wave_max(int v) {
 }  // namespace
 
 template <int METRIC>
-__global__ __launch_bounds__(256, 2) void sweep_tiled_kernel(SweepArgs a, float* __restrict__ buf,
-                                                             int* __restrict__ tile_flags, int tiles_x) {
+__global__ __launch_bounds__(256, 2) void sweep_tiled_kernel(SweepArgs a, int* __restrict__ tile_flags,
+                                                             int tiles_x) {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
-    float4* win = lds4;                        // [CG][NTEX_MAX]
-    float4* reft = lds4 + CG * NTEX_MAX;       // [CG][256]
+    float4* win = lds4;                                   // [NBUF][NTEX_MAX]
+    float4* reft = lds4 + NBUF * NTEX_MAX;                // [NBUF][64]
+    float* costs = reinterpret_cast<float*>(reft + NBUF * 64);  // [D][64]
+    float* red = costs + (size_t)a.D * 64;                // [NPG][64]
     __shared__ int s_bbox[4];
 
     const int tid = threadIdx.x;
-    const int lx = tid & 15, ly = tid >> 4;
+    const int pgl = tid >> 6;        // plane group of this wave
+    const int lane = tid & 63;       // pixel of the tile
+    const int lx = lane & 15, ly = lane >> 4;
+    const int sx = tid & 15, sy = tid >> 4;  // 16x16 staging grid over the window
     const int tile = blockIdx.x;
     const int b = blockIdx.y;
-    const int tx0 = (tile % tiles_x) * TILE, ty0 = (tile / tiles_x) * TILE;
+    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
     const int x = tx0 + lx, y = ty0 + ly;
     const bool live = x < a.W && y < a.H;
     const int HW = a.H * a.W;
@@ -76,8 +83,8 @@ __global__ __launch_bounds__(256, 2) void sweep_tiled_kernel(SweepArgs a, float*
     const float r1 = a.rays[((size_t)b * 3 + 1) * HW + p];
     const float r2 = a.rays[((size_t)b * 3 + 2) * HW + p];
     const float* refb = a.ref + (size_t)b * a.ref_bstride;
-    float* bufp = buf + (size_t)b * a.D * HW + p;
-    const int nchunk = (a.C + 4 * CG - 1) / (4 * CG);
+    const auto ref_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)refb, (short)0, a.C * HW * 4, 0x00020000);
+    const int nchunk = (a.C + 3) / 4;
 
     for (int v = 0; v < a.V; ++v) {
         ViewXform xf;
@@ -86,109 +93,146 @@ __global__ __launch_bounds__(256, 2) void sweep_tiled_kernel(SweepArgs a, float*
         float t2a, t2b, t2c;
         ray_term2(xf, r0, r1, r2, t2a, t2b, t2c);
         const float* srcv = a.src + (size_t)b * a.src_bstride + (size_t)v * a.src_vstride;
+        const auto src_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)srcv, (short)0, a.C * HW * 4, 0x00020000);
 
-        for (int k0 = 0; k0 < a.D; k0 += KP) {
-            // ---- geometry of this plane group (registers) ---------------------------------
-            int tx[KP], tyy[KP];
+        for (int k0 = 0; k0 < a.D; k0 += SG) {
+            const int kw = k0 + pgl * KP;  // first plane of this wave's group
+            // ---- geometry of this thread's KP planes (registers) ----------------------------
+            int off[KP];
             float wnw[KP], wne[KP], wsw[KP], wse[KP];
             int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN;
 #pragma unroll
             for (int i = 0; i < KP; ++i) {
-                const int k = min(k0 + i, a.D - 1);
+                const int k = min(kw + i, a.D - 1);
                 float ix, iy;
                 plane_sample_pos(xf, t2a, t2b, t2c, a.d_candi[k], cx, cy, half_w, half_h, ix, iy);
                 const Footprint f = make_footprint(ix, iy, a.W, a.H);
-                tx[i] = f.x0; tyy[i] = f.y0;
                 wnw[i] = f.nw; wne[i] = f.ne; wsw[i] = f.sw; wse[i] = f.se;
                 if (f.mask != 0u && live) {  // at least one tap inside the image
                     bx0 = min(bx0, f.x0); bx1 = max(bx1, f.x0);
                     by0 = min(by0, f.y0); by1 = max(by1, f.y0);
+                    off[i] = f.y0 * 65536 + (f.x0 & 0xffff);  // packed until the window is known
                 } else {
-                    // all four taps read zero: point the sample at texel 0 of the window with
-                    // weights that keep the reference's result (0 for finite positions, NaN for
-                    // NaN positions because 0 * NaN = NaN as in ATen)
-                    tx[i] = INT_MIN;
+                    // all four taps read zero: the sample is pointed at texel 0 of the window with
+                    // weights that keep the reference's result (0 for finite positions, NaN for NaN
+                    // positions because 0 * NaN = NaN as in ATen)
+                    off[i] = INT_MIN;
+                    wnw[i] = wnw[i] * 0.0f; wne[i] = wne[i] * 0.0f; wsw[i] = wsw[i] * 0.0f; wse[i] = wse[i] * 0.0f;
                 }
+                // one plane at a time: interleaving the 8 independent divide chains costs >100 VGPRs
+                __builtin_amdgcn_sched_barrier(0);
             }
             // ---- block bounding box ---------------------------------------------------------
             bx0 = wave_min(bx0); by0 = wave_min(by0); bx1 = wave_max(bx1); by1 = wave_max(by1);
-            __syncthreads();  // previous group's window reads and s_bbox reads are done
             if (tid == 0) { s_bbox[0] = INT_MAX; s_bbox[1] = INT_MAX; s_bbox[2] = INT_MIN; s_bbox[3] = INT_MIN; }
             __syncthreads();
-            if ((tid & 63) == 0) {
+            if (lane == 0) {
                 atomicMin(&s_bbox[0], bx0); atomicMin(&s_bbox[1], by0);
                 atomicMax(&s_bbox[2], bx1); atomicMax(&s_bbox[3], by1);
             }
             __syncthreads();
-            Bbox w{s_bbox[0], s_bbox[1], s_bbox[2], s_bbox[3]};
-            const bool empty = w.x0 > w.x1;  // every sample of the group is fully out of bounds
-            if (empty) { w.x0 = 0; w.x1 = 0; w.y0 = 0; w.y1 = 0; }
-            const int WC = ((w.x1 - w.x0 + 2) + 15) & ~15;  // +1 east tap, pitch multiple of 16
-            const int WR = w.y1 - w.y0 + 2;                  // +1 south tap
-            const int ntex = WC * WR;
-            if (ntex > NTEX_MAX) {  // block-uniform: leave the tile to the gather kernel
+            int wx0 = s_bbox[0], wy0 = s_bbox[1], wx1 = s_bbox[2], wy1 = s_bbox[3];
+            const bool empty = wx0 > wx1;  // every sample of the super group is fully out of bounds
+            if (empty) { wx0 = 0; wx1 = 0; wy0 = 0; wy1 = 0; }
+            const int WC = ((wx1 - wx0 + 2) + 15) & ~15;  // +1 east tap, pitch multiple of 16
+            const int WR = wy1 - wy0 + 2;                  // +1 south tap
+            const int ncb = WC >> 4;
+            const int nsub = ((WR + 15) >> 4) * ncb;
+            if (WC * WR > NTEX_MAX || nsub > SLOTS) {  // block-uniform: leave the tile to the gather kernel
                 if (tid == 0) tile_flags[b * gridDim.x + tile] = 1;
                 return;
             }
-            int off[KP];
 #pragma unroll
             for (int i = 0; i < KP; ++i) {
-                const bool oob = tx[i] == INT_MIN;
-                off[i] = oob ? 0 : (tyy[i] - w.y0) * WC + (tx[i] - w.x0);
-                if (oob) {  // keep NaN weights (NaN position), zero finite ones
-                    wnw[i] = wnw[i] * 0.0f; wne[i] = wne[i] * 0.0f; wsw[i] = wsw[i] * 0.0f; wse[i] = wse[i] * 0.0f;
-                }
+                const int fy0 = off[i] >> 16, fx0 = (int)(short)(off[i] & 0xffff);
+                off[i] = (off[i] == INT_MIN) ? 0 : (fy0 - wy0) * WC + (fx0 - wx0);
             }
             float acc[KP];
 #pragma unroll
             for (int i = 0; i < KP; ++i) acc[i] = 0.0f;
 
-            // ---- channel chunks ---------------------------------------------------------------
-            for (int ch = 0; ch < nchunk; ++ch) {
-                if (ch > 0) __syncthreads();  // readers of the previous chunk are done
-                const int cbase = ch * 4 * CG;
-                // stage the window (zeros outside the image / beyond C); WC is a multiple of 16, so
-                // the 16x16 thread grid walks it without integer division
-                const int c0 = cbase;
+            // ---- channel chunks (4 channels each), software pipelined ------------------------
+            // Staging uses raw buffer loads: a wave-uniform descriptor + scalar channel offset + one
+            // per-lane texel offset that is loop invariant.  Out-of-image texels carry an offset
+            // beyond the descriptor's range, for which the hardware returns 0 -- the zero padding.
+            int so[SLOTS];
+            {
+                int rb = 0, cb = 0;
 #pragma unroll
-                for (int g = 0; g < CG; ++g) {
-                    const int c = c0 + 4 * g;
-                    for (int row = ly; row < WR; row += TILE) {
-                        const int gy = w.y0 + row;
-                        const bool yin = gy >= 0 && gy < a.H && !empty;
-                        for (int col = lx; col < WC; col += TILE) {
-                            const int gx = w.x0 + col;
-                            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (yin && gx >= 0 && gx < a.W) {
-                                const float* s = srcv + (size_t)c * HW + gy * a.W + gx;
-                                val.x = (c + 0 < a.C) ? s[0] : 0.f;
-                                val.y = (c + 1 < a.C) ? s[(size_t)HW] : 0.f;
-                                val.z = (c + 2 < a.C) ? s[2 * (size_t)HW] : 0.f;
-                                val.w = (c + 3 < a.C) ? s[3 * (size_t)HW] : 0.f;
-                            }
-                            win[g * NTEX_MAX + row * WC + col] = val;
-                        }
+                for (int sl = 0; sl < SLOTS; ++sl) {
+                    so[sl] = 0x7fffffff;
+                    if (sl < nsub) {  // uniform
+                        const int row = rb * 16 + sy, col = cb * 16 + sx;
+                        const int gx = wx0 + col, gy = wy0 + row;
+                        const bool inb = !empty && row < WR && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;
+                        so[sl] = inb ? (gy * a.W + gx) * 4 : 0x7fffffff;
+                        if (++cb == ncb) { cb = 0; ++rb; }
                     }
                 }
-                // stage the reference features of the tile
+            }
+            float4 st_w[SLOTS];
+            float4 st_r;
+            auto prefetch = [&](int ch) {
+                const int c = ch * 4;
+                const bool k1 = c + 1 < a.C, k2 = c + 2 < a.C, k3 = c + 3 < a.C;  // uniform channel tail
+                const int s0 = c * HW * 4;
+                const int s1 = k1 ? s0 + HW * 4 : s0, s2 = k2 ? s0 + 2 * HW * 4 : s0, s3 = k3 ? s0 + 3 * HW * 4 : s0;
 #pragma unroll
-                for (int g = 0; g < CG; ++g) {
-                    const int c = cbase + 4 * g;
-                    const float* r = refb + (size_t)c * HW + p;
-                    float4 val;
-                    val.x = (c + 0 < a.C) ? r[0] : 0.f;
-                    val.y = (c + 1 < a.C) ? r[(size_t)HW] : 0.f;
-                    val.z = (c + 2 < a.C) ? r[2 * (size_t)HW] : 0.f;
-                    val.w = (c + 3 < a.C) ? r[3 * (size_t)HW] : 0.f;
-                    reft[g * 256 + tid] = val;
+                for (int sl = 0; sl < SLOTS; ++sl) {
+                    if (sl < nsub) {  // uniform
+                        const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, so[sl], s0, 0));
+                        const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, so[sl], s1, 0));
+                        const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, so[sl], s2, 0));
+                        const float v3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, so[sl], s3, 0));
+                        st_w[sl] = make_float4(v0, v1, v2, v3);  // raw: no use of the data before commit()
+                    }
                 }
-                __syncthreads();
+                if (pgl == 0) {  // wave 0 stages the tile's reference features
+                    const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ref_rsrc, p * 4, s0, 0));
+                    const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ref_rsrc, p * 4, s1, 0));
+                    const float q2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ref_rsrc, p * 4, s2, 0));
+                    const float q3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ref_rsrc, p * 4, s3, 0));
+                    st_r = make_float4(q0, q1, q2, q3);
+                }
+            };
+            auto commit = [&](int bufi, int ch) {
+                // channels beyond C were fetched from a clamped (valid) plane: zero them here, after the
+                // compute of the previous chunk, so that nothing waits on the loads while they fly
+                const int c = ch * 4;
+                const bool k1 = c + 1 < a.C, k2 = c + 2 < a.C, k3 = c + 3 < a.C;
+                float4* wb = win + bufi * NTEX_MAX;
+                int rb = 0, cb = 0;
 #pragma unroll
-                for (int g = 0; g < CG; ++g) {
-                    const float4 rf = reft[g * 256 + tid];
-                    const float4* wg = win + g * NTEX_MAX;
+                for (int sl = 0; sl < SLOTS; ++sl) {
+                    if (sl < nsub) {
+                        const int row = rb * 16 + sy, col = cb * 16 + sx;
+                        if (row < WR)
+                            wb[row * WC + col] = make_float4(st_w[sl].x, k1 ? st_w[sl].y : 0.f, k2 ? st_w[sl].z : 0.f,
+                                                             k3 ? st_w[sl].w : 0.f);
+                        if (++cb == ncb) { cb = 0; ++rb; }
+                    }
+                }
+                if (pgl == 0)
+                    reft[bufi * 64 + lane] = make_float4(st_r.x, k1 ? st_r.y : 0.f, k2 ? st_r.z : 0.f, k3 ? st_r.w : 0.f);
+            };
+            prefetch(0);
+            __syncthreads();  // previous super group / view finished reading both buffers
+            commit(0, 0);
+            __syncthreads();
+            for (int ch = 0; ch < nchunk; ++ch) {
+                const int cur = ch & 1;
+#if !defined(PDEPTH_ABLATE_STAGING)
+                if (ch + 1 < nchunk) prefetch(ch + 1);  // in flight while this chunk is computed
+#endif
+#if !defined(PDEPTH_ABLATE_COMPUTE)
+                {
+                    const float4 rf = reft[cur * 64 + lane];
+                    const float4* wg = win + cur * NTEX_MAX;
 #pragma unroll
                     for (int i = 0; i < KP; ++i) {
+                        // cap the taps in flight at two planes (32 VGPRs): left alone the scheduler hoists
+                        // all 32 ds_read_b128 of the chunk and spills the geometry
+                        if ((i & 1) == 0) __builtin_amdgcn_sched_barrier(0);
                         const float4 s00 = wg[off[i]];
                         const float4 s01 = wg[off[i] + 1];
                         const float4 s10 = wg[off[i] + WC];
@@ -204,70 +248,96 @@ __global__ __launch_bounds__(256, 2) void sweep_tiled_kernel(SweepArgs a, float*
     }
                         PDEPTH_TAP(x) PDEPTH_TAP(y) PDEPTH_TAP(z) PDEPTH_TAP(w)
 #undef PDEPTH_TAP
+                        // pin the accumulation here: IR-level sinking otherwise moves the fma chains of all
+                        // 8 planes behind the last load and keeps 128 tap registers alive
+                        if (i & 1) asm volatile("" : "+v"(acc[i - 1]), "+v"(acc[i]));
                     }
                 }
+#endif
+#if !defined(PDEPTH_ABLATE_STAGING)
+                if (ch + 1 < nchunk) commit(cur ^ 1, ch + 1);
+#endif
+                __syncthreads();
             }
             // channels beyond C were staged as zeros on both sides: they add (0-0)^2 = 0, except for
             // NaN-weight samples where they add NaN -- which the reference produces as well.
-            if (live) {
 #pragma unroll
-                for (int i = 0; i < KP; ++i) {
-                    if (k0 + i < a.D) {
-                        float* o = bufp + (size_t)(k0 + i) * HW;
-                        const float c = acc[i] / a.sigma;
-                        *o = (v == 0) ? (0.0f + c) : (*o + c);
-                    }
+            for (int i = 0; i < KP; ++i) {
+                if (kw + i < a.D) {
+                    float* o = costs + (size_t)(kw + i) * 64 + lane;  // owned by this thread only
+                    const float c = acc[i] / a.sigma;
+                    *o = (v == 0) ? (0.0f + c) : (*o + c);
                 }
             }
         }
     }
+    __syncthreads();
 
-    // ---- epilogue: log-softmax over D + expectation from the pixel's own costs ---------------
-    if (!live) return;
-    if (a.cost_out && a.cost_out != buf) {
-        float* o = a.cost_out + (size_t)b * a.D * HW + p;
-        for (int k = 0; k < a.D; ++k) o[(size_t)k * HW] = bufp[(size_t)k * HW];
-    }
+    // ---- epilogue from LDS: cost store, log-softmax over D, expectation ----------------------
+    // wave w handles planes k = w, w+4, w+8, ... of the tile's 64 pixels
+    float* cout = (a.cost_out && live) ? a.cost_out + (size_t)b * a.D * HW + p : nullptr;
+    if (cout)
+        for (int k = pgl; k < a.D; k += NPG) cout[(size_t)k * HW] = costs[k * 64 + lane];
     if (a.logp_out || a.depth_out) {
         float m = -INFINITY;
-        for (int k = 0; k < a.D; ++k) m = fmaxf(m, bufp[(size_t)k * HW]);
+        for (int k = pgl; k < a.D; k += NPG) m = fmaxf(m, costs[k * 64 + lane]);
+        red[pgl * 64 + lane] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[lane], red[64 + lane]), fmaxf(red[128 + lane], red[192 + lane]));
+        __syncthreads();
         float s = 0.0f;
-        for (int k = 0; k < a.D; ++k) s = s + expf(bufp[(size_t)k * HW] - m);
+        for (int k = pgl; k < a.D; k += NPG) s = s + expf(costs[k * 64 + lane] - m);
+        red[pgl * 64 + lane] = s;
+        __syncthreads();
+        s = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+        __syncthreads();
         const float ls = logf(s);
         float e = 0.0f;
-        float* o = a.logp_out ? a.logp_out + (size_t)b * a.D * HW + p : nullptr;
-        for (int k = 0; k < a.D; ++k) {
-            const float lp = (bufp[(size_t)k * HW] - m) - ls;  // read before the (aliasing) store
+        float* o = (a.logp_out && live) ? a.logp_out + (size_t)b * a.D * HW + p : nullptr;
+        for (int k = pgl; k < a.D; k += NPG) {
+            const float lp = (costs[k * 64 + lane] - m) - ls;
             if (o) o[(size_t)k * HW] = lp;
             e = e + a.d_candi[k] * expf(lp);
         }
-        if (a.depth_out) a.depth_out[(size_t)b * HW + p] = e;
+        if (a.depth_out) {
+            red[pgl * 64 + lane] = e;
+            __syncthreads();
+            if (pgl == 0 && live)
+                a.depth_out[(size_t)b * HW + p] = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+        }
     }
 }
 
-size_t sweep_tiled_workspace_bytes(int B, int D, int H, int W, bool need_scratch) {
-    const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-    size_t bytes = ((size_t)B * tiles * sizeof(int) + 255) & ~(size_t)255;
-    if (need_scratch) bytes += (size_t)B * D * H * W * sizeof(float);
-    return bytes;
+static size_t tiled_lds_bytes(int D) {
+    return (size_t)(NBUF * NTEX_MAX + NBUF * 64) * sizeof(float4) + (size_t)(D + NPG) * 64 * sizeof(float);
+}
+
+// Largest D whose cost tile fits LDS next to the window (2 blocks per CU).
+int sweep_tiled_max_planes() { return 160; }
+
+size_t sweep_tiled_workspace_bytes(int B, int H, int W) {
+    const size_t tiles = (size_t)((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+    return ((size_t)B * tiles * sizeof(int) + 255) & ~(size_t)255;
 }
 
 // Launches the tiled kernel, then the gather kernel on the tiles it flagged.
 hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t stream) {
-    const int tiles_x = (a.W + TILE - 1) / TILE, tiles_y = (a.H + TILE - 1) / TILE;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const int tiles = tiles_x * tiles_y;
     int* flags = reinterpret_cast<int*>(workspace);
-    const size_t flag_bytes = ((size_t)a.B * tiles * sizeof(int) + 255) & ~(size_t)255;
-    float* buf = a.logp_out ? a.logp_out : a.cost_out;
-    if (!buf) buf = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + flag_bytes);
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)a.B * tiles * sizeof(int), stream);
     if (e != hipSuccess) return e;
-    const size_t lds = (size_t)(CG * NTEX_MAX + CG * 256) * sizeof(float4);
+    const size_t lds = tiled_lds_bytes(a.D);
     dim3 grid(tiles, a.B);
-    if (a.metric == 0)
-        hipLaunchKernelGGL(sweep_tiled_kernel<0>, grid, dim3(256), lds, stream, a, buf, flags, tiles_x);
-    else
-        hipLaunchKernelGGL(sweep_tiled_kernel<1>, grid, dim3(256), lds, stream, a, buf, flags, tiles_x);
+    if (a.metric == 0) {
+        auto kern = sweep_tiled_kernel<0>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, flags, tiles_x);
+    } else {
+        auto kern = sweep_tiled_kernel<1>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, flags, tiles_x);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_sweep_direct_flagged(a, flags, tiles_x, tiles, stream);
