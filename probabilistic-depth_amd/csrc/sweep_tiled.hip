@@ -39,6 +39,7 @@ constexpr int KP = 8;             // planes per group
 constexpr int SG = NPG * KP;      // planes per super group
 constexpr int NBUF = 2;           // LDS window buffers
 constexpr int NTEX_MAX = 1024;    // window texels per buffer (LDS: NTEX_MAX*NBUF*16 B = 32 KB)
+constexpr int PGRP = 4;           // planes whose taps are in flight together (PGRP*16 VGPRs)
 constexpr int SLOTS = 6;          // 16x16 sub-blocks of a window (register-staged prefetch)
 
 __device__ __forceinline__ int wave_min(int v) {
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void sweep_tiled_kernel(SweepArgs a, int* _
                     for (int i = 0; i < KP; ++i) {
                         // cap the taps in flight at two planes (32 VGPRs): left alone the scheduler hoists
                         // all 32 ds_read_b128 of the chunk and spills the geometry
-                        if ((i & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+                        if ((i & (PGRP - 1)) == 0) __builtin_amdgcn_sched_barrier(0);
                         const float4 s00 = wg[off[i]];
                         const float4 s01 = wg[off[i] + 1];
                         const float4 s10 = wg[off[i] + WC];
@@ -250,7 +251,10 @@ __global__ __launch_bounds__(256, 2) void sweep_tiled_kernel(SweepArgs a, int* _
 #undef PDEPTH_TAP
                         // pin the accumulation here: IR-level sinking otherwise moves the fma chains of all
                         // 8 planes behind the last load and keeps 128 tap registers alive
-                        if (i & 1) asm volatile("" : "+v"(acc[i - 1]), "+v"(acc[i]));
+                        if ((i & (PGRP - 1)) == PGRP - 1) {
+#pragma unroll
+                            for (int q = 0; q < PGRP; ++q) asm volatile("" : "+v"(acc[i - q]));
+                        }
                     }
                 }
 #endif

@@ -1,0 +1,45 @@
+"""Evaluation harness: the counterpart of DefaultTrainer._validate_with_gt for the hot path.
+
+Reproduces the model call + depth regression of the reference's eval loop
+(trainer/default_trainer.py:171-321): ``model([inp])[0]`` -> ``prev_output = interpolate(output_refined[-1],
+0.25, 'nearest')`` (:221) -> per item ``dpv_to_depthmap(output[-1][b])`` and
+``dpv_to_depthmap(output_refined[-1][b])`` (:229-233) -- with the per-item Python loop replaced by one
+batched expectation launch per resolution.  Dataset IO, ground-truth metrics and visualisation are out
+of scope.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def move_input(model_input, device):
+    return {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in model_input.items()}
+
+
+@torch.no_grad()
+def eval_step(model, model_input, prev_output=None):
+    """One frame of the eval loop.  Returns dict(output, depth_lowres [B,h,w], depth_refined [B,H,W],
+    prev_output [B,D,h,w] for the next frame)."""
+    model_input = dict(model_input)
+    model_input["prev_output"] = prev_output
+    out = model([model_input])[0]
+    d_candi = model_input["d_candi"]
+    nxt = F.interpolate(out["output_refined"][-1].detach(), scale_factor=0.25, mode="nearest")
+    return {
+        "output": out,
+        "depth_lowres": ops.dpv_expect(out["output"][-1], d_candi, BV_log=True),
+        "depth_refined": ops.dpv_expect(out["output_refined"][-1], d_candi, BV_log=True),
+        "prev_output": nxt,
+    }
+
+
+@torch.no_grad()
+def eval_trajectory(model, frames):
+    """Chained frames of one trajectory (prev_output fed back, reset at frame 0: default_trainer.py:200-202)."""
+    prev, results = None, []
+    for inp in frames:
+        r = eval_step(model, inp, prev)
+        prev = r["prev_output"]
+        results.append(r)
+    return results

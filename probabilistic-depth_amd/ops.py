@@ -53,8 +53,17 @@ def sweep_dpv(ref, src, K, R, t, rays, cxcy, d_candi, sigma, feat_dist="L2", alg
 
 
 def dpv_reduce(logits, d_candi, want_logp=True, want_depth=True, inplace=False):
-    """(logp, depth) from logits [B,D,H,W]: log_softmax(dim=1) + dpv_to_depthmap(BV_log=True)."""
-    return _native.dpv_reduce(logits, d_candi_tensor(d_candi, logits.device), want_logp, want_depth, inplace)
+    """(logp, depth) from logits [B,D,H,W]: log_softmax(dim=1) + dpv_to_depthmap(BV_log=True).
+
+    d_candi may be None when only the log-softmax is wanted (want_depth=False).
+    """
+    if d_candi is None:
+        if want_depth:
+            raise RuntimeError("dpv_reduce: d_candi is required for the depth output")
+        dc = torch.zeros(logits.shape[1], dtype=torch.float32, device=logits.device)
+    else:
+        dc = d_candi_tensor(d_candi, logits.device)
+    return _native.dpv_reduce(logits, dc, want_logp, want_depth, inplace)
 
 
 def dpv_expect(dpv, d_candi, BV_log=False):

@@ -82,3 +82,101 @@ def make_batch(config_id, B, first_item=0, **kw):
     out = {k: torch.stack([it[k] for it in items]) for k in ("ref", "src", "K", "R", "t", "rays", "cxcy")}
     out["d_candi"] = items[0]["d_candi"]
     return out
+
+
+def seed_weights(model, seed=0, gain=0.5):
+    """Deterministic weights keyed by parameter NAME (no checkpoint is available offline).
+
+    Every floating-point state-dict entry is regenerated from a generator seeded with
+    (seed, crc32(name)), so two implementations with the same parameter names and shapes -- this
+    package's host model and the reference's -- end up with identical weights regardless of the order
+    their constructors consumed the global RNG.  Convolution weights ~ gain * N(0, 2/fan_out) (the
+    reference's init rule, damped: with BatchNorm in eval mode on near-identity statistics the
+    16-block residual trunk otherwise amplifies activations to ~1e5 and every DPV degenerates to
+    one-hot), BatchNorm statistics close to identity.  Returns the number of tensors written.
+    """
+    import zlib
+
+    def fill(name, t):
+        g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(name.encode())) & 0x7FFFFFFF)
+        leaf = name.rsplit(".", 1)[-1]
+        if t.dim() >= 3:  # conv / transposed conv weight
+            n = t.shape[0]
+            for k in t.shape[2:]:
+                n *= k
+            val = torch.randn(t.shape, generator=g) * (gain * math.sqrt(2.0 / n))
+        elif leaf == "running_var":
+            val = 1.0 + 0.1 * torch.rand(t.shape, generator=g)
+        elif leaf == "weight":  # norm scale
+            val = 1.0 + 0.05 * torch.randn(t.shape, generator=g)
+        else:  # biases, running_mean
+            val = 0.05 * torch.randn(t.shape, generator=g)
+        t.copy_(val.to(t.dtype))
+
+    n = 0
+    with torch.no_grad():
+        items = list(model.state_dict().items())
+        # the reference keeps Base3D's residual blocks in a plain list (not in its state_dict)
+        b3d = getattr(model, "based_3d", None)
+        if b3d is not None and isinstance(getattr(b3d, "dres_modules", None), list):
+            for i, m in enumerate(b3d.dres_modules):
+                items += [("based_3d.dres_modules.%d.%s" % (i, k), v) for k, v in m.state_dict().items()]
+        for name, t in items:
+            if t.is_floating_point():
+                fill(name, t)
+                n += 1
+    return n
+
+
+class Cfg(dict):
+    """Attribute-style dict (stand-in for the reference's EasyDict, which is not installed here)."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        for k, v in list(self.items()):
+            if isinstance(v, dict) and not isinstance(v, Cfg):
+                self[k] = Cfg(v)
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def default_cfg(nmode="default", ndepth=64, feature_dim=64, model_name="base"):
+    """The hot-path keys of configs/default_mono.json."""
+    return Cfg({"data": {"model_name": model_name},
+                "var": {"sigma_soft_max": 10.0, "feature_dim": feature_dim, "nmode": nmode, "ndepth": ndepth,
+                        "bn_avg": True, "d_min": 5.0, "d_max": 40.0, "qpower": 1.0}})
+
+
+def make_model_input(seed, B=1, V=1, H=256, W=256, D=64, pose="mono", dw=4):
+    """The reference's model_input dict (kittiloader/batch_scheduler.py:147-283) with synthetic content.
+
+    rgb [B,V+1,3,H,W] (reference view last), intrinsics [B,3,3] and unit_ray [B,3,h*w] at the 1/dw sweep
+    resolution, src_cam_poses [B,V+1,4,4] (last = identity), d_candi float64, prev_output None.
+    """
+    rng = np.random.default_rng(seed)
+    h, w = H // dw, W // dw
+    cam = _view.camera_from_fov(w, h, HFOV, VFOV)
+    K32 = cam["intrinsic_M"].astype(np.float32)
+    poses = np.tile(np.eye(4, dtype=np.float32), (B, V + 1, 1, 1))
+    for b in range(B):
+        for v in range(V):
+            R, t = make_pose(pose, rng)
+            poses[b, v, :3, :3] = R
+            poses[b, v, :3, 3] = t
+    base = rng.standard_normal((B, 1, 3, H, W), dtype=np.float32)
+    rgb = 0.8 * base + 0.2 * rng.standard_normal((B, V + 1, 3, H, W), dtype=np.float32)
+    return {
+        "rgb": torch.from_numpy(rgb),
+        "intrinsics": torch.from_numpy(np.tile(K32, (B, 1, 1))),
+        "unit_ray": cam["unit_ray_array_2D"][None].repeat(B, 1, 1),
+        "src_cam_poses": torch.from_numpy(poses),
+        "d_candi": powerf(5.0, 40.0, D, 1.0),
+        "prev_output": None,
+    }

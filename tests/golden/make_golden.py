@@ -150,6 +150,37 @@ def main():
         g7["rays_%dx%d" % (ww, hh)] = r.numpy()
         g7["K_%dx%d" % (ww, hh)] = Kk
     save("g7_host.npz", **g7)
+    # ---- G8: whole-model captures (reference BaseModel on the CPU, name-seeded weights) ----------
+    import models.models as ref_models  # noqa: F401
+    import models.get_model as ref_get_model
+    from pdepth_amd import synth as S
+    torch.nn.Module.cuda = lambda self, *a, **k: self  # reference Base3D calls .cuda(id) in its ctor
+    g8 = {}
+    for nmode in ("default", "default_feedback"):
+        cfg = S.default_cfg(nmode)
+        torch.manual_seed(0)
+        model = ref_get_model.get_model(cfg, 0)
+        S.seed_weights(model, seed=8)
+        model.eval()
+        keys = list(model.state_dict().keys())
+        g8[nmode + "_state_keys"] = np.array(keys)
+        g8[nmode + "_state_shapes"] = np.array([repr(tuple(v.shape)) for v in model.state_dict().values()])
+        prev = None
+        for frame in range(2 if nmode == "default_feedback" else 1):
+            inp = S.make_model_input(8000 + frame, B=1, V=1, H=256, W=256, D=64, pose="mono")
+            inp["prev_output"] = prev
+            with torch.no_grad():
+                out = model([inp])[0]
+                if nmode == "default" and frame == 0:
+                    _, costv, _, _ = model.forward_encoder(inp)
+                    g8["default_cost_sub"] = costv.numpy()[:, ::4, ::2, ::2]
+            tag = "%s_f%d" % (nmode, frame)
+            g8[tag + "_logdpv_sub"] = out["output"][-1].numpy()[:, ::4, ::2, ::2]
+            g8[tag + "_depth_low"] = img_utils.dpv_to_depthmap(out["output"][-1], inp["d_candi"], BV_log=True).numpy()
+            g8[tag + "_depth_ref"] = img_utils.dpv_to_depthmap(out["output_refined"][-1], inp["d_candi"], BV_log=True).numpy()
+            prev = F.interpolate(out["output_refined"][-1].detach(), scale_factor=0.25, mode="nearest")
+    save("g8_model.npz", **g8)
+
     print("golden fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
