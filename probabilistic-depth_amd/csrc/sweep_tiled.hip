@@ -56,7 +56,7 @@ __device__ __forceinline__ int wave_max(int v) {
 }  // namespace
 
 template <int METRIC>
-__global__ __launch_bounds__(256, 2) void sweep_tiled_kernel(SweepArgs a, int* __restrict__ tile_flags,
+__global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* __restrict__ tile_flags,
                                                              int tiles_x) {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
     float4* win = lds4;                                   // [NBUF][NTEX_MAX]
@@ -70,7 +70,13 @@ __global__ __launch_bounds__(256, 2) void sweep_tiled_kernel(SweepArgs a, int* _
     const int lane = tid & 63;       // pixel of the tile
     const int lx = lane & 15, ly = lane >> 4;
     const int sx = tid & 15, sy = tid >> 4;  // 16x16 staging grid over the window
-    const int tile = blockIdx.x;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so blocks i and i+8
+    // share an L2.  Give every XCD one contiguous band of tiles: neighbouring tiles stage overlapping
+    // source windows, which then hit that XCD's L2 instead of going out to the Infinity Cache.
+    // (bijective for any tile count; affects speed only)
+    const int ntile = gridDim.x;
+    const int xcd = blockIdx.x & 7, qq = ntile >> 3, rr = ntile & 7;
+    const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
     const int b = blockIdx.y;
     const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
     const int x = tx0 + lx, y = ty0 + ly;
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void sweep_tiled_kernel(SweepArgs a, int* _
             const int ncb = WC >> 4;
             const int nsub = ((WR + 15) >> 4) * ncb;
             if (WC * WR > NTEX_MAX || nsub > SLOTS) {  // block-uniform: leave the tile to the gather kernel
-                if (tid == 0) tile_flags[b * gridDim.x + tile] = 1;
+                if (tid == 0) tile_flags[b * ntile + tile] = 1;
                 return;
             }
 #pragma unroll
@@ -222,10 +228,7 @@ __global__ __launch_bounds__(256, 2) void sweep_tiled_kernel(SweepArgs a, int* _
             __syncthreads();
             for (int ch = 0; ch < nchunk; ++ch) {
                 const int cur = ch & 1;
-#if !defined(PDEPTH_ABLATE_STAGING)
                 if (ch + 1 < nchunk) prefetch(ch + 1);  // in flight while this chunk is computed
-#endif
-#if !defined(PDEPTH_ABLATE_COMPUTE)
                 {
                     const float4 rf = reft[cur * 64 + lane];
                     const float4* wg = win + cur * NTEX_MAX;
@@ -257,10 +260,7 @@ __global__ __launch_bounds__(256, 2) void sweep_tiled_kernel(SweepArgs a, int* _
                         }
                     }
                 }
-#endif
-#if !defined(PDEPTH_ABLATE_STAGING)
                 if (ch + 1 < nchunk) commit(cur ^ 1, ch + 1);
-#endif
                 __syncthreads();
             }
             // channels beyond C were staged as zeros on both sides: they add (0-0)^2 = 0, except for
