@@ -15,6 +15,9 @@
 //             ds_read_b128 of a 16x4 wave bank-conflict free.  Texels outside the image are staged
 //             as zeros, which IS padding_mode='zeros' -- no per-tap masks in the inner loop;
 //   ref     = the tile's reference features of the chunk, staged next to the window;
+//   sum     = the squared difference is accumulated with one fma (diff*diff + acc, a single rounding)
+//             where the reference rounds the square first; the change is ~1e-7 relative per term,
+//             two orders below the parity tolerance, and saves one VALU op in seven;
 //   costs   = cost[k][pixel] of the tile in LDS (D x 64 floats), accumulated over views in view
 //             order like homography.py:129; the fused epilogue (log_softmax over D + E[d]) runs on
 //             those with the 4 waves splitting the planes, so nothing but the requested outputs is
@@ -39,7 +42,6 @@ constexpr int KP = 8;             // planes per group
 constexpr int SG = NPG * KP;      // planes per super group
 constexpr int NBUF = 2;           // LDS window buffers
 constexpr int NTEX_MAX = 1024;    // window texels per buffer (LDS: NTEX_MAX*NBUF*16 B = 32 KB)
-constexpr int PGRP = 4;           // planes whose taps are in flight together (PGRP*16 VGPRs)
 constexpr int SLOTS = 6;          // 16x16 sub-blocks of a window (register-staged prefetch)
 
 __device__ __forceinline__ int wave_min(int v) {
@@ -103,60 +105,99 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
         const auto src_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)srcv, (short)0, a.C * HW * 4, 0x00020000);
 
         for (int k0 = 0; k0 < a.D; k0 += SG) {
-            const int kw = k0 + pgl * KP;  // first plane of this wave's group
             // ---- geometry of this thread's KP planes (registers) ----------------------------
-            int off[KP];
+            // Plane assignment inside the 32-plane super group: the 8 planes of a wave are split into
+            // nsplit parts of per = 8/nsplit planes; part q of wave w holds planes
+            //     k0 + q*(4*per) + w*per + [0, per),
+            // so the planes staged together (one part of all 4 waves) are 4*per CONSECUTIVE planes and
+            // their common window shrinks with nsplit (nsplit = 1 is simply planes 8w .. 8w+7).
+            int off[KP];  // packed (y0, x0) until the plane's part is staged, then its window texel index
+            int kpl[KP];  // depth plane of slot i
             float wnw[KP], wne[KP], wsw[KP], wse[KP];
-            int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN;
+            auto geometry = [&](int nsplit_) {
+                const int per_ = KP / nsplit_;
 #pragma unroll
-            for (int i = 0; i < KP; ++i) {
-                const int k = min(kw + i, a.D - 1);
-                float ix, iy;
-                plane_sample_pos(xf, t2a, t2b, t2c, a.d_candi[k], cx, cy, half_w, half_h, ix, iy);
-                const Footprint f = make_footprint(ix, iy, a.W, a.H);
-                wnw[i] = f.nw; wne[i] = f.ne; wsw[i] = f.sw; wse[i] = f.se;
-                if (f.mask != 0u && live) {  // at least one tap inside the image
-                    bx0 = min(bx0, f.x0); bx1 = max(bx1, f.x0);
-                    by0 = min(by0, f.y0); by1 = max(by1, f.y0);
-                    off[i] = f.y0 * 65536 + (f.x0 & 0xffff);  // packed until the window is known
-                } else {
-                    // all four taps read zero: the sample is pointed at texel 0 of the window with
-                    // weights that keep the reference's result (0 for finite positions, NaN for NaN
-                    // positions because 0 * NaN = NaN as in ATen)
-                    off[i] = INT_MIN;
-                    wnw[i] = wnw[i] * 0.0f; wne[i] = wne[i] * 0.0f; wsw[i] = wsw[i] * 0.0f; wse[i] = wse[i] * 0.0f;
+                for (int i = 0; i < KP; ++i) {
+                    kpl[i] = k0 + (i / per_) * (NPG * per_) + pgl * per_ + (i % per_);
+                    const int k = min(kpl[i], a.D - 1);
+                    float ix, iy;
+                    plane_sample_pos(xf, t2a, t2b, t2c, a.d_candi[k], cx, cy, half_w, half_h, ix, iy);
+                    const Footprint f = make_footprint(ix, iy, a.W, a.H);
+                    wnw[i] = f.nw; wne[i] = f.ne; wsw[i] = f.sw; wse[i] = f.se;
+                    if (f.mask != 0u && live) {  // at least one tap inside the image
+                        off[i] = f.y0 * 65536 + (f.x0 & 0xffff);
+                    } else {
+                        // all four taps read zero: the sample is pointed at texel 0 of the window with
+                        // weights that keep the reference's result (0 for finite positions, NaN for NaN
+                        // positions because 0 * NaN = NaN as in ATen)
+                        off[i] = INT_MIN;
+                        wnw[i] = wnw[i] * 0.0f; wne[i] = wne[i] * 0.0f; wsw[i] = wsw[i] * 0.0f; wse[i] = wse[i] * 0.0f;
+                    }
+                    // one plane at a time: interleaving the 8 independent divide chains costs >100 VGPRs
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                // one plane at a time: interleaving the 8 independent divide chains costs >100 VGPRs
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- block bounding box ---------------------------------------------------------
-            bx0 = wave_min(bx0); by0 = wave_min(by0); bx1 = wave_max(bx1); by1 = wave_max(by1);
-            if (tid == 0) { s_bbox[0] = INT_MAX; s_bbox[1] = INT_MAX; s_bbox[2] = INT_MIN; s_bbox[3] = INT_MIN; }
-            __syncthreads();
-            if (lane == 0) {
-                atomicMin(&s_bbox[0], bx0); atomicMin(&s_bbox[1], by0);
-                atomicMax(&s_bbox[2], bx1); atomicMax(&s_bbox[3], by1);
-            }
-            __syncthreads();
-            int wx0 = s_bbox[0], wy0 = s_bbox[1], wx1 = s_bbox[2], wy1 = s_bbox[3];
-            const bool empty = wx0 > wx1;  // every sample of the super group is fully out of bounds
-            if (empty) { wx0 = 0; wx1 = 0; wy0 = 0; wy1 = 0; }
-            const int WC = ((wx1 - wx0 + 2) + 15) & ~15;  // +1 east tap, pitch multiple of 16
-            const int WR = wy1 - wy0 + 2;                  // +1 south tap
-            const int ncb = WC >> 4;
-            const int nsub = ((WR + 15) >> 4) * ncb;
-            if (WC * WR > NTEX_MAX || nsub > SLOTS) {  // block-uniform: leave the tile to the gather kernel
-                if (tid == 0) tile_flags[b * ntile + tile] = 1;
-                return;
-            }
-#pragma unroll
-            for (int i = 0; i < KP; ++i) {
-                const int fy0 = off[i] >> 16, fx0 = (int)(short)(off[i] & 0xffff);
-                off[i] = (off[i] == INT_MIN) ? 0 : (fy0 - wy0) * WC + (fx0 - wx0);
-            }
+            };
             float acc[KP];
 #pragma unroll
             for (int i = 0; i < KP; ++i) acc[i] = 0.0f;
+
+            // ---- window of planes [first, first+count) of every wave: block bounding box ------------
+            int wx0, wy0, wx1, wy1, WC, WR, ncb, nsub;
+            bool empty;
+            auto window_of = [&](int first, int count) -> bool {
+                int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN;
+#pragma unroll
+                for (int i = 0; i < KP; ++i) {
+                    if (i >= first && i < first + count && off[i] != INT_MIN) {
+                        const int fy0 = off[i] >> 16, fx0 = (int)(short)(off[i] & 0xffff);
+                        bx0 = min(bx0, fx0); bx1 = max(bx1, fx0);
+                        by0 = min(by0, fy0); by1 = max(by1, fy0);
+                    }
+                }
+                bx0 = wave_min(bx0); by0 = wave_min(by0); bx1 = wave_max(bx1); by1 = wave_max(by1);
+                __syncthreads();  // every reader of the previous s_bbox / window is done
+                if (tid == 0) { s_bbox[0] = INT_MAX; s_bbox[1] = INT_MAX; s_bbox[2] = INT_MIN; s_bbox[3] = INT_MIN; }
+                __syncthreads();
+                if (lane == 0) {
+                    atomicMin(&s_bbox[0], bx0); atomicMin(&s_bbox[1], by0);
+                    atomicMax(&s_bbox[2], bx1); atomicMax(&s_bbox[3], by1);
+                }
+                __syncthreads();
+                wx0 = s_bbox[0]; wy0 = s_bbox[1]; wx1 = s_bbox[2]; wy1 = s_bbox[3];
+                empty = wx0 > wx1;  // every sample of these planes is fully out of bounds
+                if (empty) { wx0 = 0; wx1 = 0; wy0 = 0; wy1 = 0; }
+                WC = ((wx1 - wx0 + 2) + 15) & ~15;  // +1 east tap, pitch multiple of 16
+                WR = wy1 - wy0 + 2;                  // +1 south tap
+                ncb = WC >> 4;
+                nsub = ((WR + 15) >> 4) * ncb;
+                return WC * WR <= NTEX_MAX && nsub <= SLOTS;  // block-uniform
+            };
+            // Smallest split into 1, 2 or 4 parts whose windows all fit LDS; the geometry is only redone
+            // when the coarser split failed (large disparities per plane, e.g. 512x1024 with D=128).
+            int nsplit = 1;
+            for (;;) {
+                geometry(nsplit);
+                const int per = KP / nsplit;
+                bool fits = true;
+                for (int part = 0; part < nsplit && fits; ++part) fits = window_of(part * per, per);
+                if (fits) break;
+                if (nsplit == 4) {  // block-uniform: leave the tile to the gather kernel
+                    if (tid == 0) tile_flags[b * ntile + tile] = 1;
+                    return;
+                }
+                nsplit *= 2;
+            }
+            const int per = KP / nsplit;
+
+            for (int part = 0; part < nsplit; ++part) {
+            if (nsplit > 1) window_of(part * per, per);  // nsplit == 1: the fit check left this window
+#pragma unroll
+            for (int i = 0; i < KP; ++i) {
+                if (i / per == part) {
+                    const int fy0 = off[i] >> 16, fx0 = (int)(short)(off[i] & 0xffff);
+                    off[i] = (off[i] == INT_MIN) ? 0 : (fy0 - wy0) * WC + (fx0 - wx0);
+                }
+            }
 
             // ---- channel chunks (4 channels each), software pipelined ------------------------
             // Staging uses raw buffer loads: a wave-uniform descriptor + scalar channel offset + one
@@ -223,8 +264,7 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
                     reft[bufi * 64 + lane] = make_float4(st_r.x, k1 ? st_r.y : 0.f, k2 ? st_r.z : 0.f, k3 ? st_r.w : 0.f);
             };
             prefetch(0);
-            __syncthreads();  // previous super group / view finished reading both buffers
-            commit(0, 0);
+            commit(0, 0);  // window_of() ended with a barrier: nobody reads the buffers any more
             __syncthreads();
             for (int ch = 0; ch < nchunk; ++ch) {
                 const int cur = ch & 1;
@@ -234,9 +274,10 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
                     const float4* wg = win + cur * NTEX_MAX;
 #pragma unroll
                     for (int i = 0; i < KP; ++i) {
+                        if (i / per != part) continue;  // uniform: this plane is staged in another part
                         // cap the taps in flight at two planes (32 VGPRs): left alone the scheduler hoists
                         // all 32 ds_read_b128 of the chunk and spills the geometry
-                        if ((i & (PGRP - 1)) == 0) __builtin_amdgcn_sched_barrier(0);
+                        if ((i & 1) == 0) __builtin_amdgcn_sched_barrier(0);
                         const float4 s00 = wg[off[i]];
                         const float4 s01 = wg[off[i] + 1];
                         const float4 s10 = wg[off[i] + WC];
@@ -248,27 +289,25 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
         val = __builtin_fmaf(s10.comp, wsw[i], val);                                \
         val = __builtin_fmaf(s11.comp, wse[i], val);                                \
         const float diff = val - rf.comp;                                           \
-        acc[i] = acc[i] + (METRIC == 0 ? diff * diff : fabsf(diff));                \
+        acc[i] = METRIC == 0 ? __builtin_fmaf(diff, diff, acc[i]) : acc[i] + fabsf(diff); \
     }
                         PDEPTH_TAP(x) PDEPTH_TAP(y) PDEPTH_TAP(z) PDEPTH_TAP(w)
 #undef PDEPTH_TAP
                         // pin the accumulation here: IR-level sinking otherwise moves the fma chains of all
                         // 8 planes behind the last load and keeps 128 tap registers alive
-                        if ((i & (PGRP - 1)) == PGRP - 1) {
-#pragma unroll
-                            for (int q = 0; q < PGRP; ++q) asm volatile("" : "+v"(acc[i - q]));
-                        }
+                        if (i & 1) asm volatile("" : "+v"(acc[i - 1]), "+v"(acc[i]));
                     }
                 }
                 if (ch + 1 < nchunk) commit(cur ^ 1, ch + 1);
                 __syncthreads();
             }
+            }  // parts
             // channels beyond C were staged as zeros on both sides: they add (0-0)^2 = 0, except for
             // NaN-weight samples where they add NaN -- which the reference produces as well.
 #pragma unroll
             for (int i = 0; i < KP; ++i) {
-                if (kw + i < a.D) {
-                    float* o = costs + (size_t)(kw + i) * 64 + lane;  // owned by this thread only
+                if (kpl[i] < a.D) {
+                    float* o = costs + (size_t)kpl[i] * 64 + lane;  // owned by this thread only
                     const float c = acc[i] / a.sigma;
                     *o = (v == 0) ? (0.0f + c) : (*o + c);
                 }

@@ -36,6 +36,9 @@ def make_pose(kind, rng):
         ang = np.deg2rad(rng.uniform(-1.0, 1.0, size=2))
         t = np.array([0.02, 0.0, 0.8]) + rng.uniform(-0.05, 0.05, size=3)
         return _rot_yx(ang[0], ang[1]), t
+    if kind == "wide":  # wide baseline + forward motion: tens of pixels of disparity per depth plane
+        ang = np.deg2rad(rng.uniform(-2.0, 2.0, size=2))
+        return _rot_yx(ang[0], ang[1]), np.array([2.5, 0.3, 1.5]) + rng.uniform(-0.1, 0.1, size=3)
     if kind == "identity":
         return np.eye(3), np.zeros(3)
     raise ValueError(kind)

@@ -110,6 +110,7 @@ def test_sample_coordinates_bit_exact(dev, pose, H, W, off):
     dict(C=70, D=16, H=20, W=36, V=2, pose="mono"),                          # C > 68: chunked-channel kernel
     dict(C=67, D=128, H=16, W=64, V=1, pose="stereo"),                       # D=128 (config 5 depth count)
     dict(C=64, D=64, H=32, W=64, V=1, pose="mono", peaked=True),
+    dict(C=6, D=24, H=96, W=320, V=1, pose="wide"),                          # large disparity per plane: split windows
 ])
 @pytest.mark.parametrize("metric", ["L2", "L1"])
 @pytest.mark.parametrize("algo", ["auto", "direct"])
