@@ -151,6 +151,32 @@ int pdepth_warp_feature_f32(const pdepth_sweep_desc *desc, const pdepth_camera *
 int pdepth_sample_coords_f32(const pdepth_sweep_desc *desc, const pdepth_camera *cam,
                              const float *d_candi, float *ix, float *iy, void *stream);
 
+/*
+ * DPV Bayesian fusion of the upsample mode: replaces gen_dpv_withmask (utils/img_utils.py:360-375, with
+ * gen_soft_label_torch :31-47 and gen_uniform :49-50) followed by the fuse / renormalise / clamp / log
+ * lines of BaseModel.forward_int (models/models.py:666-672).
+ *   logp [B,D,H,W] log-DPV of the network, dmaps [B,H,W] sparse depth, masks [B,H,W] validity (channel 0
+ *   of the reference's [B,1,H,W]), var = 0.3 in the reference, eps = torch.finfo(float).eps.
+ *   fused [B,D,H,W] (clamped probabilities) and logfused [B,D,H,W]; either may be NULL, not both.
+ */
+int pdepth_dpv_fuse_f32(const float *logp, const float *dmaps, const float *masks, const float *d_candi,
+                        int32_t B, int32_t D, int32_t H, int32_t W, float var, float eps, float *fused,
+                        float *logfused, void *stream);
+
+/*
+ * Forward of the reference's native correlation operator: replaces correlation_forward_cuda
+ * (models/correlation_package/correlation_cuda.cc:10-87; kernel correlation_cuda_kernel.cu:41-114) with the
+ * same argument meaning.  Supported: kernel_size == 1, stride1 == 1, pad_size == max_displacement,
+ * max_displacement / stride2 <= 4 (PWCLite uses pad 4, k 1, d 4, s1 = s2 = 1: models/pwclite.py:123-125);
+ * other values return PDEPTH_E_ARG.  corr_multiply is accepted and ignored like in the reference kernel.
+ *   input1, input2 [B,C,H,W]; output [B, (2*(d/s2)+1)^2, H, W], channel (dy+r)*(2r+1)+(dx+r), mean over C.
+ * The reference's rbot1/rbot2 scratch tensors (zero-padded NHWC repacks) are not needed.
+ */
+int pdepth_correlation_forward_f32(const float *input1, const float *input2, int32_t B, int32_t C, int32_t H,
+                                   int32_t W, int32_t pad_size, int32_t kernel_size, int32_t max_displacement,
+                                   int32_t stride1, int32_t stride2, int32_t corr_multiply, float *output,
+                                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

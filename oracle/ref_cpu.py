@@ -25,7 +25,8 @@ import torch.nn.functional as F
 
 __all__ = [
     "powerf", "unit_rays", "intrinsics_from_fov", "plane_coords", "sweep_cost",
-    "warp_feature", "log_dpv", "dpv_to_depthmap", "sweep_dpv", "sample_coords",
+    "warp_feature", "log_dpv", "dpv_to_depthmap", "sweep_dpv", "sample_coords", "gen_dpv_withmask", "dpv_fuse",
+    "correlation",
 ]
 
 
@@ -191,3 +192,53 @@ def sweep_dpv(feat_ref, feat_src, d_candi, R, t, K, rays, cx, cy, sigma, metric=
     cost = sweep_cost(feat_ref, feat_src, d_candi, R, t, K, rays, cx, cy, sigma, metric)
     logp = log_dpv(cost)
     return cost, logp, dpv_to_depthmap(logp, d_candi, BV_log=True)
+
+
+# --------------------------------------------------------------------------------------
+# "next" rows: DPV Bayesian fusion and the correlation op
+# --------------------------------------------------------------------------------------
+EPSILON = torch.finfo(float).eps  # utils/img_utils.py:12
+
+
+def gen_dpv_withmask(dmaps, masks, d_candi, var=0.3):
+    """Gaussian soft label blended with the uniform DPV by the validity mask -> [B,D,H,W].
+
+    utils/img_utils.py:360-375 (per item: gen_soft_label_torch :31-47 with zero_invalid=True,
+    gen_uniform :49-50, blend :371, clamp :374).
+    """
+    out = []
+    truth_var = torch.tensor(var)
+    d = torch.tensor(d_candi).float()
+    for b in range(dmaps.shape[0]):
+        dmap = dmaps[b]
+        mask = masks[b, 0].unsqueeze(0)
+        dexp = d.unsqueeze(-1).unsqueeze(-1).repeat(1, dmap.shape[0], dmap.shape[1])
+        sigma = torch.sqrt(truth_var)
+        dists = torch.exp(-torch.pow(torch.abs(dexp - dmap), 2.0) / (2 * torch.pow(sigma, 2.0)))
+        dists = dists / torch.sum(dists, dim=0)
+        dists[dists != dists] = -1
+        uni = torch.ones((d.shape[0], dmap.shape[0], dmap.shape[1])) / d.shape[0]
+        out.append((dists * mask + uni * (1.0 - mask)).unsqueeze(0))
+    return torch.clamp(torch.cat(out), EPSILON, 1.0)
+
+
+def dpv_fuse(logp, dmaps, masks, d_candi, var=0.3):
+    """(fused, log fused) as in BaseModel.forward_int, nmode default_upsample: models/models.py:663-672."""
+    tofuse = gen_dpv_withmask(dmaps, masks, d_candi, var)
+    fused = torch.exp(logp + torch.log(tofuse))
+    fused = fused / torch.sum(fused, dim=1).unsqueeze(1)
+    fused = torch.clamp(fused, EPSILON, 1.0)
+    return fused, torch.log(fused)
+
+
+def correlation(x1, x2, max_displacement=4):
+    """81-channel mean-over-C correlation: models/correlation_native.py:13-23 (its own self-check pins
+    it to the CUDA op at atol 1e-7, :64)."""
+    B, C, H, W = x1.shape
+    n = 2 * max_displacement + 1
+    x2p = F.pad(x2, [max_displacement] * 4)
+    cv = []
+    for i in range(n):
+        for j in range(n):
+            cv.append(torch.mean(x1 * x2p[:, :, i:i + H, j:j + W], 1, keepdim=True))
+    return torch.cat(cv, 1)

@@ -24,6 +24,7 @@ EXPORTED_SYMBOLS = (
     "pdepth_abi_version", "pdepth_last_error", "pdepth_sweep_workspace_bytes",
     "pdepth_sweep_cost_f32", "pdepth_sweep_dpv_f32", "pdepth_dpv_reduce_f32",
     "pdepth_dpv_expect_f32", "pdepth_warp_feature_f32", "pdepth_sample_coords_f32",
+    "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32",
 )
 
 
@@ -103,8 +104,12 @@ def load():
                                             c_void_p]
     lib.pdepth_sample_coords_f32.argtypes = [POINTER(SweepDesc), POINTER(Camera), c_void_p, c_void_p, c_void_p,
                                              c_void_p]
+    lib.pdepth_dpv_fuse_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                        c_float, c_float, c_void_p, c_void_p, c_void_p]
+    lib.pdepth_correlation_forward_f32.argtypes = [c_void_p, c_void_p] + [c_int32] * 10 + [c_void_p, c_void_p]
     for fn in ("pdepth_sweep_cost_f32", "pdepth_sweep_dpv_f32", "pdepth_dpv_reduce_f32",
-               "pdepth_dpv_expect_f32", "pdepth_warp_feature_f32", "pdepth_sample_coords_f32"):
+               "pdepth_dpv_expect_f32", "pdepth_warp_feature_f32", "pdepth_sample_coords_f32",
+               "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32"):
         getattr(lib, fn).restype = c_int
     if lib.pdepth_abi_version() != 1:
         raise RuntimeError("libpdepth_hip.so ABI version mismatch")
@@ -293,3 +298,40 @@ def sample_coords(K, R, t, rays, cxcy, d_candi, H, W, blas_mode=None):
     _check(rc, lib)
     del keep
     return ix, iy
+
+
+def dpv_fuse(logp, dmaps, masks, d_candi, var, eps, want_fused=True, want_log=True):
+    """logp [B,D,H,W], dmaps [B,H,W], masks [B,H,W] -> (fused | None, log fused | None)."""
+    lib = load()
+    _dev(logp, "logp")
+    logp, dmaps, masks, d_candi = (t.contiguous() for t in (logp, dmaps, masks, d_candi))
+    B, D, H, W = logp.shape
+    if tuple(dmaps.shape) != (B, H, W) or tuple(masks.shape) != (B, H, W) or d_candi.numel() != D:
+        raise RuntimeError("dpv_fuse: dmaps/masks must be [B,H,W] and d_candi [D]")
+    fused = torch.empty_like(logp) if want_fused else None
+    logf = torch.empty_like(logp) if want_log else None
+    with torch.cuda.device(logp.device):
+        rc = lib.pdepth_dpv_fuse_f32(_dev(logp, "logp"), _dev(dmaps, "dmaps"), _dev(masks, "masks"),
+                                     _dev(d_candi, "d_candi"), B, D, H, W, float(var), float(eps),
+                                     fused.data_ptr() if want_fused else None, logf.data_ptr() if want_log else None,
+                                     _stream(logp.device))
+    _check(rc, lib)
+    return fused, logf
+
+
+def correlation_forward(x1, x2, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply=1):
+    """x1, x2 [B,C,H,W] -> [B,(2*(d/s2)+1)^2,H,W] (mean over C of shifted products)."""
+    lib = load()
+    _dev(x1, "input1"), _dev(x2, "input2")
+    if x1.shape != x2.shape or x1.dim() != 4:
+        raise RuntimeError("correlation: inputs must be two [B,C,H,W] tensors of the same shape")
+    x1, x2 = x1.contiguous(), x2.contiguous()
+    B, C, H, W = x1.shape
+    nd = 2 * (max_displacement // max(stride2, 1)) + 1
+    out = torch.empty((B, nd * nd, H, W), dtype=torch.float32, device=x1.device)
+    with torch.cuda.device(x1.device):
+        rc = lib.pdepth_correlation_forward_f32(x1.data_ptr(), x2.data_ptr(), B, C, H, W, int(pad_size), int(kernel_size),
+                                                int(max_displacement), int(stride1), int(stride2), int(corr_multiply),
+                                                out.data_ptr(), _stream(x1.device))
+    _check(rc, lib)
+    return out

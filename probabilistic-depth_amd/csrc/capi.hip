@@ -159,4 +159,30 @@ int pdepth_sample_coords_f32(const pdepth_sweep_desc* desc, const pdepth_camera*
     return launched(pdepth::launch_sample_coords(a, ix, iy, (hipStream_t)stream), "pdepth_sample_coords_f32");
 }
 
+int pdepth_dpv_fuse_f32(const float* logp, const float* dmaps, const float* masks, const float* d_candi,
+                        int32_t B, int32_t D, int32_t H, int32_t W, float var, float eps, float* fused,
+                        float* logfused, void* stream) {
+    if (!logp || !dmaps || !masks || !d_candi) return fail(PDEPTH_E_ARG, "pdepth_dpv_fuse_f32: null input");
+    if (!fused && !logfused) return fail(PDEPTH_E_ARG, "pdepth_dpv_fuse_f32: no output requested");
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(PDEPTH_E_ARG, "pdepth_dpv_fuse_f32: non-positive dimension");
+    if (!(var > 0.0f)) return fail(PDEPTH_E_ARG, "pdepth_dpv_fuse_f32: var must be positive");
+    return launched(pdepth::launch_dpv_fuse(logp, dmaps, masks, d_candi, B, D, H, W, var, eps, fused, logfused,
+                                            (hipStream_t)stream), "pdepth_dpv_fuse_f32");
+}
+
+int pdepth_correlation_forward_f32(const float* input1, const float* input2, int32_t B, int32_t C, int32_t H,
+                                   int32_t W, int32_t pad_size, int32_t kernel_size, int32_t max_displacement,
+                                   int32_t stride1, int32_t stride2, int32_t corr_multiply, float* output,
+                                   void* stream) {
+    (void)corr_multiply;
+    if (!input1 || !input2 || !output) return fail(PDEPTH_E_ARG, "pdepth_correlation_forward_f32: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(PDEPTH_E_ARG, "pdepth_correlation_forward_f32: non-positive dimension");
+    if (kernel_size != 1 || stride1 != 1 || stride2 < 1 || pad_size != max_displacement || max_displacement < 1 ||
+        max_displacement % stride2 != 0 || max_displacement / stride2 > pdepth::correlation_max_radius())
+        return fail(PDEPTH_E_ARG, "pdepth_correlation_forward_f32: unsupported configuration (pad %d, kernel %d, "
+                    "max_displacement %d, stride1 %d, stride2 %d)", pad_size, kernel_size, max_displacement, stride1, stride2);
+    return launched(pdepth::launch_correlation_forward(input1, input2, B, C, H, W, max_displacement / stride2, stride2,
+                                                       output, (hipStream_t)stream), "pdepth_correlation_forward_f32");
+}
+
 }  // extern "C"

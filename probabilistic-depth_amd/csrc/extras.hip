@@ -1,0 +1,140 @@
+// "Next" rows of SURVEY.md section 8(f): DPV Bayesian fusion and the FlowNet/PWC correlation op.
+//
+// dpv_fuse   -- upsample mode (models/models.py:666-672 with utils/img_utils.py:31-47, :360-375): build the
+//               Gaussian soft label of a sparse depth map over the depth candidates, blend it with the
+//               uniform DPV by the validity mask, multiply it into the network's DPV, renormalise, clamp,
+//               take the log -- one kernel, one read of the log-DPV, two writes, instead of ~12 passes.
+// correlation -- forward of the reference's only native operator (models/correlation_package/
+//               correlation_cuda_kernel.cu:41-114; semantics pinned by models/correlation_native.py:13-23):
+//               out[b, (dy+r)*(2r+1) + (dx+r), y, x] = mean_c x1[b,c,y,x] * x2[b,c,y+dy*s2,x+dx*s2] (zero padded).
+//               It is dead code w.r.t. get_model (only PWCLite uses it), provided for completeness.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace pdepth {
+
+__global__ __launch_bounds__(256) void dpv_fuse_kernel(const float* __restrict__ logp,
+                                                       const float* __restrict__ dmaps,
+                                                       const float* __restrict__ masks,
+                                                       const float* __restrict__ dc, int D, int HW, float var,
+                                                       float eps, float* __restrict__ fused,
+                                                       float* __restrict__ logfused) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const int b = blockIdx.y;
+    const float dmap = dmaps[(size_t)b * HW + pix];
+    const float mask = masks[(size_t)b * HW + pix];
+    const float inv_mask = 1.0f - mask;
+    const float sigma = sqrtf(var);
+    const float two_var = 2.0f * (sigma * sigma);  // 2 * torch.pow(sig, 2)
+    const float uni = 1.0f / (float)D;
+    const float* lp = logp + (size_t)b * D * HW + pix;
+    float sumg = 0.0f;
+    for (int k = 0; k < D; ++k) {
+        const float a = fabsf(dc[k] - dmap);
+        sumg = sumg + expf(-(a * a) / two_var);
+    }
+    auto tofuse = [&](int k) {
+        const float a = fabsf(dc[k] - dmap);
+        float t = expf(-(a * a) / two_var) / sumg;
+        if (t != t) t = -1.0f;                       // zero_invalid (img_utils.py:45)
+        const float m = t * mask + uni * inv_mask;   // img_utils.py:371
+        return fminf(fmaxf(m, eps), 1.0f);            // clamp(eps, 1) keeps NaN out like torch.clamp
+    };
+    float sumf = 0.0f;
+    for (int k = 0; k < D; ++k) sumf = sumf + expf(lp[(size_t)k * HW] + logf(tofuse(k)));
+    float* of = fused ? fused + (size_t)b * D * HW + pix : nullptr;
+    float* ol = logfused ? logfused + (size_t)b * D * HW + pix : nullptr;
+    for (int k = 0; k < D; ++k) {
+        float f = expf(lp[(size_t)k * HW] + logf(tofuse(k))) / sumf;
+        f = fminf(fmaxf(f, eps), 1.0f);
+        if (of) of[(size_t)k * HW] = f;
+        if (ol) ol[(size_t)k * HW] = logf(f);
+    }
+}
+
+hipError_t launch_dpv_fuse(const float* logp, const float* dmaps, const float* masks, const float* d_candi,
+                           int B, int D, int H, int W, float var, float eps, float* fused, float* logfused,
+                           hipStream_t stream) {
+    dim3 grid((H * W + 255) / 256, B);
+    hipLaunchKernelGGL(dpv_fuse_kernel, grid, dim3(256), 0, stream, logp, dmaps, masks, d_candi, D, H * W, var, eps,
+                       fused, logfused);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// correlation forward: block = 16x16 output pixels; the x2 halo tile and the x1 tile of a channel chunk
+// are staged in LDS; every thread keeps all (2r+1)^2 <= 81 displacement sums of its pixel in registers.
+// ---------------------------------------------------------------------------------------------------
+constexpr int CT = 16;       // tile edge
+constexpr int CCH = 8;       // channels per chunk
+constexpr int RMAX = 4;      // max displacement radius (in units of stride2) held in registers: 81 sums
+
+template <int R>
+__global__ __launch_bounds__(256) void correlation_fwd_kernel(const float* __restrict__ x1,
+                                                              const float* __restrict__ x2, int C, int H, int W,
+                                                              int s2, float* __restrict__ out) {
+    extern __shared__ float smem[];
+    const int halo = R * s2;
+    const int TWH = CT + 2 * halo;           // halo tile edge
+    float* t2 = smem;                        // [CCH][TWH][TWH]
+    float* t1 = smem + CCH * TWH * TWH;      // [CCH][CT*CT]
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int x0 = blockIdx.x * CT, y0 = blockIdx.y * CT;
+    const int b = blockIdx.z;
+    const int x = x0 + tx, y = y0 + ty;
+    const int HW = H * W;
+    constexpr int ND = 2 * R + 1;
+    float acc[ND * ND];
+#pragma unroll
+    for (int i = 0; i < ND * ND; ++i) acc[i] = 0.0f;
+    for (int c0 = 0; c0 < C; c0 += CCH) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < CCH * TWH * TWH; idx += 256) {
+            const int cc = idx / (TWH * TWH), rem = idx - cc * TWH * TWH;
+            const int ry = rem / TWH, rx = rem - ry * TWH;
+            const int gx = x0 - halo + rx, gy = y0 - halo + ry, c = c0 + cc;
+            t2[idx] = (c < C && gx >= 0 && gx < W && gy >= 0 && gy < H) ? x2[((size_t)b * C + c) * HW + gy * W + gx] : 0.0f;
+        }
+        for (int cc = 0; cc < CCH; ++cc) {
+            const int c = c0 + cc;
+            t1[cc * 256 + threadIdx.x] = (c < C && x < W && y < H) ? x1[((size_t)b * C + c) * HW + y * W + x] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < CCH; ++cc) {
+            const float a = t1[cc * 256 + threadIdx.x];
+            const float* row = t2 + cc * TWH * TWH + (ty + halo) * TWH + (tx + halo);
+#pragma unroll
+            for (int dy = -R; dy <= R; ++dy)
+#pragma unroll
+                for (int dx = -R; dx <= R; ++dx)
+                    acc[(dy + R) * ND + (dx + R)] = __builtin_fmaf(a, row[dy * s2 * TWH + dx * s2], acc[(dy + R) * ND + (dx + R)]);
+        }
+    }
+    if (x < W && y < H) {
+        const float inv = 1.0f / (float)C;
+#pragma unroll
+        for (int i = 0; i < ND * ND; ++i) out[((size_t)b * ND * ND + i) * HW + y * W + x] = acc[i] * inv;
+    }
+}
+
+hipError_t launch_correlation_forward(const float* x1, const float* x2, int B, int C, int H, int W, int radius,
+                                      int stride2, float* out, hipStream_t stream) {
+    dim3 grid((W + CT - 1) / CT, (H + CT - 1) / CT, B);
+    const int TWH = CT + 2 * radius * stride2;
+    const size_t lds = (size_t)(CCH * TWH * TWH + CCH * 256) * sizeof(float);
+    switch (radius) {
+        case 1: hipLaunchKernelGGL(correlation_fwd_kernel<1>, grid, dim3(256), lds, stream, x1, x2, C, H, W, stride2, out); break;
+        case 2: hipLaunchKernelGGL(correlation_fwd_kernel<2>, grid, dim3(256), lds, stream, x1, x2, C, H, W, stride2, out); break;
+        case 3: hipLaunchKernelGGL(correlation_fwd_kernel<3>, grid, dim3(256), lds, stream, x1, x2, C, H, W, stride2, out); break;
+        case 4: hipLaunchKernelGGL(correlation_fwd_kernel<4>, grid, dim3(256), lds, stream, x1, x2, C, H, W, stride2, out); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+int correlation_max_radius() { return RMAX; }
+
+}  // namespace pdepth

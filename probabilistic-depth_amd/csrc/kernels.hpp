@@ -48,4 +48,12 @@ hipError_t launch_dpv_expect(const float* dpv, const float* d_candi, int B, int 
 hipError_t launch_warp_feature(const SweepArgs& a, float* out, hipStream_t stream);
 hipError_t launch_sample_coords(const SweepArgs& a, float* ix, float* iy, hipStream_t stream);
 
+// extras.hip
+hipError_t launch_dpv_fuse(const float* logp, const float* dmaps, const float* masks, const float* d_candi,
+                           int B, int D, int H, int W, float var, float eps, float* fused, float* logfused,
+                           hipStream_t stream);
+hipError_t launch_correlation_forward(const float* x1, const float* x2, int B, int C, int H, int W, int radius,
+                                      int stride2, float* out, hipStream_t stream);
+int correlation_max_radius();
+
 }  // namespace pdepth

@@ -310,11 +310,11 @@ class BaseModel(nn.Module):
         if self.nmode == "default_upsample":
             BV_cur, _, feats, _ = self.forward_encoder(model_input)
             feats.append(model_input["rgb"][:, -1])
-            tofuse = gen_dpv_withmask(model_input["dmaps"], model_input["masks"], model_input["d_candi"], 0.3)
-            fused = torch.exp(BV_cur + torch.log(tofuse))
-            fused = torch.clamp(fused / torch.sum(fused, dim=1).unsqueeze(1), EPSILON, 1.0)
+            # gen_dpv_withmask + fuse + renormalise + clamp + log (models.py:663-672) in one kernel
+            fused, log_fused = ops.dpv_fuse(BV_cur, model_input["dmaps"], model_input["masks"],
+                                            model_input["d_candi"], var=0.3, eps=EPSILON)
             BV_refined = self.base_decoder(fused, img_features=feats)
-            return {"output": [torch.log(fused), BV_cur], "output_refined": [BV_refined], "flow": None,
+            return {"output": [log_fused, BV_cur], "output_refined": [BV_refined], "flow": None,
                     "flow_refined": None}
         if self.nmode == "default_feedback":
             BV_cur, _, last, _, warped = self.forward_exp(model_input)

@@ -80,3 +80,23 @@ def warp_feature(src, K, R, t, rays, cxcy, d_candi, blas=None):
 def sample_coords(K, R, t, rays, cxcy, d_candi, H, W, blas=None):
     return _native.sample_coords(K, R, t, rays, cxcy, d_candi_tensor(d_candi, K.device), H, W,
                                  blas_mode=BLAS_MODES[blas])
+
+
+def dpv_fuse(logp, dmaps, masks, d_candi, var=0.3, eps=None, want_fused=True, want_log=True):
+    """Bayesian fusion of a log-DPV with the Gaussian soft label of a sparse depth map.
+
+    utils/img_utils.py:360-375 (gen_dpv_withmask) + models/models.py:666-672 in one kernel.
+    masks may be [B,1,H,W] (reference layout, channel 0 is used) or [B,H,W].
+    Returns (fused probabilities | None, log fused | None).
+    """
+    if eps is None:
+        eps = torch.finfo(float).eps  # reference: utils/img_utils.py:12
+    if masks.dim() == 4:
+        masks = masks[:, 0]
+    return _native.dpv_fuse(logp, dmaps.float(), masks.float(), d_candi_tensor(d_candi, logp.device), var, eps,
+                            want_fused, want_log)
+
+
+def correlation(x1, x2, pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1, corr_multiply=1):
+    """Forward of the reference's native correlation op (models/correlation_package/correlation.py:47-61)."""
+    return _native.correlation_forward(x1, x2, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply)

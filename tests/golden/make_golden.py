@@ -181,6 +181,25 @@ def main():
             prev = F.interpolate(out["output_refined"][-1].detach(), scale_factor=0.25, mode="nearest")
     save("g8_model.npz", **g8)
 
+    # ---- G9: correlation (reference's pure-PyTorch twin of its CUDA op) ---------------------------
+    import models.correlation_native as corr_native
+    x1, x2 = torch.randn(2, 32, 12, 16), torch.randn(2, 32, 12, 16)
+    save("g9_correlation.npz", x1=x1.numpy(), x2=x2.numpy(), out=corr_native.Correlation(max_displacement=4)(x1, x2).numpy())
+
+    # ---- G10: DPV Bayesian fusion of the upsample mode (models/models.py:663-672) -----------------
+    D10, h10, w10 = 64, 24, 40
+    d10 = img_utils.powerf(5.0, 40.0, D10, 1.0)
+    bv = F.log_softmax(torch.randn(2, D10, h10, w10) * 2.0, dim=1)
+    dm = torch.rand(2, h10, w10) * 30.0 + 6.0
+    mk = (torch.rand(2, 1, h10, w10) > 0.6).float()
+    dm = dm * mk[:, 0]
+    tofuse = img_utils.gen_dpv_withmask(dm, mk, d10, 0.3)
+    fused = torch.exp(bv + torch.log(tofuse))
+    fused = fused / torch.sum(fused, dim=1).unsqueeze(1)
+    fused = torch.clamp(fused, img_utils.epsilon, 1.)
+    save("g10_dpv_fuse.npz", logp=bv.numpy(), dmaps=dm.numpy(), masks=mk.numpy(), d_candi=d10, tofuse=tofuse.numpy(),
+         fused=fused.numpy(), logfused=torch.log(fused).numpy())
+
     print("golden fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

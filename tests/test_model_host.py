@@ -99,3 +99,25 @@ def test_default_model_forward():
         out = m([inp])[0]
     assert out["output"][0].shape == (2, 64, 16, 24) and out["output_refined"][0].shape == (2, 64, 64, 96)
     assert (torch.exp(out["output"][0]).sum(1) - 1).abs().max().item() < 1e-5
+
+
+@pytest.mark.gpu
+def test_upsample_mode_fuses_sparse_depth():
+    """nmode default_upsample: output[0] = log of (DPV x Gaussian soft label of the sparse depth), renormalised
+    (models/models.py:659-678); checked against the oracle's restatement applied to the model's own BV_cur."""
+    from oracle import ref_cpu as O
+    dev = torch.device("cuda:0")
+    model = get_model(synth.default_cfg("default_upsample"), 0)
+    synth.seed_weights(model, seed=8)
+    model = model.to(dev).eval()
+    inp = synth.make_model_input(8100, B=2, V=1, H=256, W=256, D=64, pose="mono")
+    g = torch.Generator().manual_seed(1)
+    masks = (torch.rand(2, 1, 64, 64, generator=g) > 0.7).float()
+    inp["dmaps"] = (torch.rand(2, 64, 64, generator=g) * 30 + 6) * masks[:, 0]
+    inp["masks"] = masks
+    with torch.no_grad():
+        out = model([harness.move_input(inp, dev)])[0]
+    fused_log, bv_cur = out["output"]
+    want_fused, want_log = O.dpv_fuse(bv_cur.cpu(), inp["dmaps"], inp["masks"], inp["d_candi"], 0.3)
+    np.testing.assert_allclose(fused_log.cpu().numpy(), want_log.numpy(), rtol=1e-5, atol=3e-5)
+    assert out["output_refined"][0].shape == (2, 64, 256, 256)

@@ -1,0 +1,63 @@
+"""DPV Bayesian fusion (rank 2) and the correlation op forward (rank 3)."""
+import numpy as np
+import pytest
+import torch
+
+import pdepth_amd  # noqa: F401
+from pdepth_amd import ops
+from pdepth_amd.models.correlation import Correlation
+from oracle import ref_cpu as O
+from util import golden, same_cpu_as_golden
+
+
+def test_oracle_correlation_matches_reference_fixture():
+    g = golden("g9_correlation.npz")
+    out = O.correlation(torch.from_numpy(g["x1"]), torch.from_numpy(g["x2"]), 4)
+    if same_cpu_as_golden(g):
+        assert np.array_equal(out.numpy(), g["out"])
+    else:
+        np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-6, atol=1e-7)
+
+
+def test_oracle_dpv_fuse_matches_reference_fixture():
+    g = golden("g10_dpv_fuse.npz")
+    logp, dm, mk = (torch.from_numpy(g[k]) for k in ("logp", "dmaps", "masks"))
+    tofuse = O.gen_dpv_withmask(dm, mk, g["d_candi"], 0.3)
+    fused, logf = O.dpv_fuse(logp, dm, mk, g["d_candi"], 0.3)
+    if same_cpu_as_golden(g):
+        assert np.array_equal(tofuse.numpy(), g["tofuse"]) and np.array_equal(fused.numpy(), g["fused"])
+        assert np.array_equal(logf.numpy(), g["logfused"])
+    else:
+        np.testing.assert_allclose(fused.numpy(), g["fused"], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_hip_correlation_forward():
+    g = golden("g9_correlation.npz")
+    dev = torch.device("cuda:0")
+    out = Correlation(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1)(
+        torch.from_numpy(g["x1"]).to(dev), torch.from_numpy(g["x2"]).to(dev))
+    assert out.shape == (2, 81, 12, 16)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-5, atol=1e-6)  # tolerance 1e-6
+    # ragged size, other radius, stride2 = 2, against the oracle restatement
+    x1, x2 = torch.randn(1, 19, 21, 35), torch.randn(1, 19, 21, 35)
+    got = ops.correlation(x1.to(dev), x2.to(dev), pad_size=2, max_displacement=2).cpu()
+    np.testing.assert_allclose(got.numpy(), O.correlation(x1, x2, 2).numpy(), rtol=1e-5, atol=1e-6)
+    got = ops.correlation(x1.to(dev), x2.to(dev), pad_size=4, max_displacement=4, stride2=2).cpu()
+    want = O.correlation(x1, x2, 4).reshape(1, 9, 9, 21, 35)[:, ::2, ::2].reshape(1, 25, 21, 35)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError, match="unsupported configuration"):
+        ops.correlation(x1.to(dev), x2.to(dev), kernel_size=3)
+    with pytest.raises(RuntimeError, match="backward is not implemented"):
+        Correlation()(x1.to(dev).requires_grad_(), x2.to(dev))
+
+
+@pytest.mark.gpu
+def test_hip_dpv_fuse():
+    g = golden("g10_dpv_fuse.npz")
+    dev = torch.device("cuda:0")
+    fused, logf = ops.dpv_fuse(torch.from_numpy(g["logp"]).to(dev), torch.from_numpy(g["dmaps"]).to(dev),
+                               torch.from_numpy(g["masks"]).to(dev), g["d_candi"], var=0.3)
+    np.testing.assert_allclose(fused.cpu().numpy(), g["fused"], rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(logf.cpu().numpy(), g["logfused"], rtol=1e-5, atol=2e-5)
+    assert (fused.sum(1) - 1).abs().max().item() < 1e-4
