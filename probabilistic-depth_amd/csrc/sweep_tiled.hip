@@ -15,9 +15,11 @@
 //             ds_read_b128 of a 16x4 wave bank-conflict free.  Texels outside the image are staged
 //             as zeros, which IS padding_mode='zeros' -- no per-tap masks in the inner loop;
 //   ref     = the tile's reference features of the chunk, staged next to the window;
-//   sum     = the squared difference is accumulated with one fma (diff*diff + acc, a single rounding)
-//             where the reference rounds the square first; the change is ~1e-7 relative per term,
-//             two orders below the parity tolerance, and saves one VALU op in seven;
+//   sum     = five VALU ops per (pixel, plane, channel): the reference feature enters the bilinear fma
+//             chain as its initial addend (diff = fma(s00,nw,-r) ... fma(s11,se,.)) and the square is
+//             accumulated with one fma.  The reference rounds the interpolated value and the square
+//             separately (7 ops); the difference is ~1e-7 relative per term, two orders below the
+//             parity tolerance (the gather kernel of sweep_direct.hip keeps the reference's op order);
 //   costs   = cost[k][pixel] of the tile in LDS (D x 64 floats), accumulated over views in view
 //             order like homography.py:129; the fused epilogue (log_softmax over D + E[d]) runs on
 //             those with the 4 waves splitting the planes, so nothing but the requested outputs is
@@ -244,9 +246,11 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
                 }
             };
             auto commit = [&](int bufi, int ch) {
-                // channels beyond C were fetched from a clamped (valid) plane: zero them here, after the
-                // compute of the previous chunk, so that nothing waits on the loads while they fly
+                // Channels beyond C were fetched from a clamped (valid) plane and must read as zero; that
+                // only concerns the last chunk, and it is done here -- after the compute of the previous
+                // chunk -- so that nothing waits on the loads while they fly.
                 const int c = ch * 4;
+                const bool tail = c + 3 >= a.C;  // uniform
                 const bool k1 = c + 1 < a.C, k2 = c + 2 < a.C, k3 = c + 3 < a.C;
                 float4* wb = win + bufi * NTEX_MAX;
                 int rb = 0, cb = 0;
@@ -254,14 +258,19 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
                 for (int sl = 0; sl < SLOTS; ++sl) {
                     if (sl < nsub) {
                         const int row = rb * 16 + sy, col = cb * 16 + sx;
-                        if (row < WR)
-                            wb[row * WC + col] = make_float4(st_w[sl].x, k1 ? st_w[sl].y : 0.f, k2 ? st_w[sl].z : 0.f,
-                                                             k3 ? st_w[sl].w : 0.f);
+                        if (row < WR) {
+                            float4 val = st_w[sl];
+                            if (tail) val = make_float4(val.x, k1 ? val.y : 0.f, k2 ? val.z : 0.f, k3 ? val.w : 0.f);
+                            wb[row * WC + col] = val;
+                        }
                         if (++cb == ncb) { cb = 0; ++rb; }
                     }
                 }
-                if (pgl == 0)
-                    reft[bufi * 64 + lane] = make_float4(st_r.x, k1 ? st_r.y : 0.f, k2 ? st_r.z : 0.f, k3 ? st_r.w : 0.f);
+                if (pgl == 0) {
+                    float4 val = st_r;
+                    if (tail) val = make_float4(val.x, k1 ? val.y : 0.f, k2 ? val.z : 0.f, k3 ? val.w : 0.f);
+                    reft[bufi * 64 + lane] = val;
+                }
             };
             prefetch(0);
             commit(0, 0);  // window_of() ended with a barrier: nobody reads the buffers any more
@@ -284,11 +293,10 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
                         const float4 s11 = wg[off[i] + WC + 1];
 #define PDEPTH_TAP(comp)                                                            \
     {                                                                               \
-        float val = s00.comp * wnw[i];                                              \
-        val = __builtin_fmaf(s01.comp, wne[i], val);                                \
-        val = __builtin_fmaf(s10.comp, wsw[i], val);                                \
-        val = __builtin_fmaf(s11.comp, wse[i], val);                                \
-        const float diff = val - rf.comp;                                           \
+        float diff = __builtin_fmaf(s00.comp, wnw[i], -rf.comp);                    \
+        diff = __builtin_fmaf(s01.comp, wne[i], diff);                              \
+        diff = __builtin_fmaf(s10.comp, wsw[i], diff);                              \
+        diff = __builtin_fmaf(s11.comp, wse[i], diff);                              \
         acc[i] = METRIC == 0 ? __builtin_fmaf(diff, diff, acc[i]) : acc[i] + fabsf(diff); \
     }
                         PDEPTH_TAP(x) PDEPTH_TAP(y) PDEPTH_TAP(z) PDEPTH_TAP(w)
