@@ -44,7 +44,7 @@ constexpr int KP = 8;             // planes per group
 constexpr int SG = NPG * KP;      // planes per super group
 constexpr int NBUF = 2;           // LDS window buffers
 constexpr int NTEX_MAX = 1024;    // window texels per buffer (LDS: NTEX_MAX*NBUF*16 B = 32 KB)
-constexpr int SLOTS = 6;          // 16x16 sub-blocks of a window (register-staged prefetch)
+constexpr int SLOTS = 4;          // sub-blocks of a window (256 texels each, register-staged prefetch)
 
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
@@ -73,7 +73,6 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
     const int pgl = tid >> 6;        // plane group of this wave
     const int lane = tid & 63;       // pixel of the tile
     const int lx = lane & 15, ly = lane >> 4;
-    const int sx = tid & 15, sy = tid >> 4;  // 16x16 staging grid over the window
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so blocks i and i+8
     // share an L2.  Give every XCD one contiguous band of tiles: neighbouring tiles stage overlapping
     // source windows, which then hit that XCD's L2 instead of going out to the Infinity Cache.
@@ -145,6 +144,7 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
 
             // ---- window of planes [first, first+count) of every wave: block bounding box ------------
             int wx0, wy0, wx1, wy1, WC, WR, ncb, nsub;
+            int glog = 4;  // log2 of the staging grid width: the 256 threads walk the window as 16x16, 32x8 or 64x4
             bool empty;
             auto window_of = [&](int first, int count) -> bool {
                 int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN;
@@ -170,8 +170,14 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
                 if (empty) { wx0 = 0; wx1 = 0; wy0 = 0; wy1 = 0; }
                 WC = ((wx1 - wx0 + 2) + 15) & ~15;  // +1 east tap, pitch multiple of 16
                 WR = wy1 - wy0 + 2;                  // +1 south tap
-                ncb = WC >> 4;
-                nsub = ((WR + 15) >> 4) * ncb;
+                // staging grid shape with the fewest sub-blocks (windows are usually wide and short)
+                nsub = INT_MAX;
+#pragma unroll
+                for (int gl = 4; gl <= 6; ++gl) {
+                    const int gw = 1 << gl, gh = 256 >> gl;
+                    const int n = ((WR + gh - 1) / gh) * ((WC + gw - 1) >> gl);
+                    if (n < nsub) { nsub = n; glog = gl; ncb = (WC + gw - 1) >> gl; }
+                }
                 return WC * WR <= NTEX_MAX && nsub <= SLOTS;  // block-uniform
             };
             // Smallest split into 1, 2 or 4 parts whose windows all fit LDS; the geometry is only redone
@@ -212,9 +218,9 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
                 for (int sl = 0; sl < SLOTS; ++sl) {
                     so[sl] = 0x7fffffff;
                     if (sl < nsub) {  // uniform
-                        const int row = rb * 16 + sy, col = cb * 16 + sx;
+                        const int row = rb * (256 >> glog) + (tid >> glog), col = (cb << glog) + (tid & ((1 << glog) - 1));
                         const int gx = wx0 + col, gy = wy0 + row;
-                        const bool inb = !empty && row < WR && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;
+                        const bool inb = !empty && row < WR && col < WC && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;
                         so[sl] = inb ? (gy * a.W + gx) * 4 : 0x7fffffff;
                         if (++cb == ncb) { cb = 0; ++rb; }
                     }
@@ -257,8 +263,8 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
 #pragma unroll
                 for (int sl = 0; sl < SLOTS; ++sl) {
                     if (sl < nsub) {
-                        const int row = rb * 16 + sy, col = cb * 16 + sx;
-                        if (row < WR) {
+                        const int row = rb * (256 >> glog) + (tid >> glog), col = (cb << glog) + (tid & ((1 << glog) - 1));
+                        if (row < WR && col < WC) {
                             float4 val = st_w[sl];
                             if (tail) val = make_float4(val.x, k1 ? val.y : 0.f, k2 ? val.z : 0.f, k3 ? val.w : 0.f);
                             wb[row * WC + col] = val;
