@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
                         off[i] = INT_MIN;
                         wnw[i] = wnw[i] * 0.0f; wne[i] = wne[i] * 0.0f; wsw[i] = wsw[i] * 0.0f; wse[i] = wse[i] * 0.0f;
                     }
-                    // one plane at a time: interleaving the 8 independent divide chains costs >100 VGPRs
-                    __builtin_amdgcn_sched_barrier(0);
+                    // two planes at a time: interleaving all 8 independent divide chains costs >100 VGPRs
+                    if (i & 1) __builtin_amdgcn_sched_barrier(0);
                 }
             };
             float acc[KP];
