@@ -177,6 +177,17 @@ int pdepth_correlation_forward_f32(const float *input1, const float *input2, int
                                    int32_t stride1, int32_t stride2, int32_t corr_multiply, float *output,
                                    void *stream);
 
+/*
+ * Depth-map driven inverse warp (forward only): replaces the sampling part of inverse_warp
+ * (utils/inverse_warp.py:174-210 with pixel2cam :26-40 and cam2pixel :43-69), used by the training losses
+ * (losses/loss_blocks.py:116,151).  The host supplies Kinv = intrinsics.inverse() [B,3,3] and
+ * proj = intrinsics @ pose_mat [B,3,4] (:193-203); img [B,C,H,W], depth [B,H,W] ->
+ * out [B,C,H,W] (bilinear, zeros padding, grid_sample's default align_corners=False) and
+ * valid [B,H,W] as bytes (|normalised coordinate| <= 1, :208), valid may be NULL.
+ */
+int pdepth_inverse_warp_f32(const float *img, const float *depth, const float *Kinv, const float *proj,
+                            int32_t B, int32_t C, int32_t H, int32_t W, float *out, uint8_t *valid, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

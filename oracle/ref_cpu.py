@@ -26,7 +26,7 @@ import torch.nn.functional as F
 __all__ = [
     "powerf", "unit_rays", "intrinsics_from_fov", "plane_coords", "sweep_cost",
     "warp_feature", "log_dpv", "dpv_to_depthmap", "sweep_dpv", "sample_coords", "gen_dpv_withmask", "dpv_fuse",
-    "correlation",
+    "correlation", "inverse_warp",
 ]
 
 
@@ -242,3 +242,23 @@ def correlation(x1, x2, max_displacement=4):
         for j in range(n):
             cv.append(torch.mean(x1 * x2p[:, :, i:i + H, j:j + W], 1, keepdim=True))
     return torch.cat(cv, 1)
+
+
+def inverse_warp(img, depth, pose_mat, intrinsics):
+    """Depth-driven inverse warp for a [B,4,4] or [B,3,4] pose -> (warped, valid).
+
+    utils/inverse_warp.py:174-210: pixel2cam (:26-40), K @ pose (:200), cam2pixel (:43-69: Z clamped at 1e-3,
+    normalisation with (w-1)/(h-1)), F.grid_sample with default align_corners, validity = |grid| <= 1 (:208).
+    """
+    b, _, h, w = img.shape
+    i_range = torch.arange(0, h).view(1, h, 1).expand(1, h, w).type_as(depth)
+    j_range = torch.arange(0, w).view(1, 1, w).expand(1, h, w).type_as(depth)
+    pix = torch.stack((j_range, i_range, torch.ones(1, h, w).type_as(depth)), dim=1)
+    cam = torch.matmul(intrinsics.inverse(), pix.expand(b, 3, h, w).reshape(b, 3, -1)).reshape(b, 3, h, w)
+    cam = cam * depth.unsqueeze(1)
+    proj = torch.matmul(intrinsics, pose_mat[:, 0:3, :])
+    pc = torch.matmul(proj[:, :, :3], cam.reshape(b, 3, -1)) + proj[:, :, -1:]
+    Z = pc[:, 2].clamp(min=1e-3)
+    grid = torch.stack([2 * (pc[:, 0] / Z) / (w - 1) - 1, 2 * (pc[:, 1] / Z) / (h - 1) - 1], dim=2).reshape(b, h, w, 2)
+    out = F.grid_sample(img, grid, padding_mode="zeros", mode="bilinear", align_corners=False)
+    return out, grid.abs().max(dim=-1)[0] <= 1

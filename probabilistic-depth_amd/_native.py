@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = (
     "pdepth_abi_version", "pdepth_last_error", "pdepth_sweep_workspace_bytes",
     "pdepth_sweep_cost_f32", "pdepth_sweep_dpv_f32", "pdepth_dpv_reduce_f32",
     "pdepth_dpv_expect_f32", "pdepth_warp_feature_f32", "pdepth_sample_coords_f32",
-    "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32",
+    "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32", "pdepth_inverse_warp_f32",
 )
 
 
@@ -107,9 +107,10 @@ def load():
     lib.pdepth_dpv_fuse_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                         c_float, c_float, c_void_p, c_void_p, c_void_p]
     lib.pdepth_correlation_forward_f32.argtypes = [c_void_p, c_void_p] + [c_int32] * 10 + [c_void_p, c_void_p]
+    lib.pdepth_inverse_warp_f32.argtypes = [c_void_p] * 4 + [c_int32] * 4 + [c_void_p] * 3
     for fn in ("pdepth_sweep_cost_f32", "pdepth_sweep_dpv_f32", "pdepth_dpv_reduce_f32",
                "pdepth_dpv_expect_f32", "pdepth_warp_feature_f32", "pdepth_sample_coords_f32",
-               "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32"):
+               "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32", "pdepth_inverse_warp_f32"):
         getattr(lib, fn).restype = c_int
     if lib.pdepth_abi_version() != 1:
         raise RuntimeError("libpdepth_hip.so ABI version mismatch")
@@ -335,3 +336,20 @@ def correlation_forward(x1, x2, pad_size, kernel_size, max_displacement, stride1
                                                 out.data_ptr(), _stream(x1.device))
     _check(rc, lib)
     return out
+
+
+def inverse_warp(img, depth, Kinv, proj):
+    """img [B,C,H,W], depth [B,H,W], Kinv [B,3,3], proj [B,3,4] -> (warped [B,C,H,W], valid bool [B,H,W])."""
+    lib = load()
+    _dev(img, "img")
+    img, depth, Kinv, proj = (t.contiguous() for t in (img, depth, Kinv, proj))
+    B, C, H, W = img.shape
+    if tuple(depth.shape) != (B, H, W) or tuple(Kinv.shape) != (B, 3, 3) or tuple(proj.shape) != (B, 3, 4):
+        raise RuntimeError("inverse_warp: expected depth [B,H,W], Kinv [B,3,3], proj [B,3,4]")
+    out = torch.empty_like(img)
+    valid = torch.empty((B, H, W), dtype=torch.uint8, device=img.device)
+    with torch.cuda.device(img.device):
+        rc = lib.pdepth_inverse_warp_f32(_dev(img, "img"), _dev(depth, "depth"), _dev(Kinv, "Kinv"), _dev(proj, "proj"),
+                                         B, C, H, W, out.data_ptr(), valid.data_ptr(), _stream(img.device))
+    _check(rc, lib)
+    return out, valid.bool()

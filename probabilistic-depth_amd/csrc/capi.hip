@@ -185,4 +185,12 @@ int pdepth_correlation_forward_f32(const float* input1, const float* input2, int
                                                        output, (hipStream_t)stream), "pdepth_correlation_forward_f32");
 }
 
+int pdepth_inverse_warp_f32(const float* img, const float* depth, const float* Kinv, const float* proj, int32_t B,
+                            int32_t C, int32_t H, int32_t W, float* out, uint8_t* valid, void* stream) {
+    if (!img || !depth || !Kinv || !proj || !out) return fail(PDEPTH_E_ARG, "pdepth_inverse_warp_f32: null pointer");
+    if (B <= 0 || C <= 0 || H <= 1 || W <= 1) return fail(PDEPTH_E_ARG, "pdepth_inverse_warp_f32: bad dimension");
+    return launched(pdepth::launch_inverse_warp(img, depth, Kinv, proj, B, C, H, W, out, valid, (hipStream_t)stream),
+                    "pdepth_inverse_warp_f32");
+}
+
 }  // extern "C"

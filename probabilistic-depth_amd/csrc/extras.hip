@@ -137,4 +137,62 @@ hipError_t launch_correlation_forward(const float* x1, const float* x2, int B, i
 
 int correlation_max_radius() { return RMAX; }
 
+// ---------------------------------------------------------------------------------------------------
+// inverse_warp forward (utils/inverse_warp.py:174-210): depth-map driven warp used by the training losses
+// (losses/loss_blocks.py:116,151).  pixel2cam (:26-40), cam2pixel (:43-69, Z clamped at 1e-3, coordinates
+// normalised with (w-1), (h-1)), then F.grid_sample with its default align_corners=False, zeros padding.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void inverse_warp_kernel(const float* __restrict__ img,
+                                                           const float* __restrict__ depth,
+                                                           const float* __restrict__ Kinv,
+                                                           const float* __restrict__ proj, int C, int H, int W,
+                                                           float* __restrict__ out, unsigned char* __restrict__ valid) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int HW = H * W;
+    if (pix >= HW) return;
+    const int b = blockIdx.y;
+    const int y = pix / W, x = pix - y * W;
+    const float* ki = Kinv + b * 9;
+    const float* pr = proj + b * 12;
+    const float fx = (float)x, fy = (float)y, d = depth[(size_t)b * HW + pix];
+    float cam[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        cam[i] = __builtin_fmaf(ki[i * 3 + 2], 1.0f, __builtin_fmaf(ki[i * 3 + 1], fy, ki[i * 3 + 0] * fx)) * d;
+    float pc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        pc[i] = __builtin_fmaf(pr[i * 4 + 2], cam[2], __builtin_fmaf(pr[i * 4 + 1], cam[1], pr[i * 4 + 0] * cam[0])) + pr[i * 4 + 3];
+    const float Z = fmaxf(pc[2], 1e-3f);
+    const float xn = 2.0f * (pc[0] / Z) / (float)(W - 1) - 1.0f;
+    const float yn = 2.0f * (pc[1] / Z) / (float)(H - 1) - 1.0f;
+    if (valid) valid[(size_t)b * HW + pix] = (fmaxf(fabsf(xn), fabsf(yn)) <= 1.0f) ? 1 : 0;
+    const float ix = __builtin_fmaf(xn + 1.0f, (float)W / 2.0f, -0.5f);
+    const float iy = __builtin_fmaf(yn + 1.0f, (float)H / 2.0f, -0.5f);
+    const float xf = floorf(ix), yf = floorf(iy);
+    const float w = ix - xf, e = 1.0f - w, n = iy - yf, s = 1.0f - n;
+    const float nw = s * e, ne = s * w, sw = n * e, se = n * w;
+    const bool finite = (ix == ix) && (iy == iy);
+    const int x0 = (int)fminf(fmaxf(xf, -2.0f), (float)(W + 1)), y0 = (int)fminf(fmaxf(yf, -2.0f), (float)(H + 1));
+    const bool xi0 = x0 >= 0 && x0 < W, xi1 = x0 + 1 >= 0 && x0 + 1 < W;
+    const bool yi0 = y0 >= 0 && y0 < H, yi1 = y0 + 1 >= 0 && y0 + 1 < H;
+    const float* ib = img + (size_t)b * C * HW + (y0 * W + x0);
+    float* ob = out + (size_t)b * C * HW + pix;
+    for (int c = 0; c < C; ++c) {
+        const float* p = ib + (size_t)c * HW;
+        const float v00 = (finite && xi0 && yi0) ? p[0] : 0.0f;
+        const float v01 = (finite && xi1 && yi0) ? p[1] : 0.0f;
+        const float v10 = (finite && xi0 && yi1) ? p[W] : 0.0f;
+        const float v11 = (finite && xi1 && yi1) ? p[W + 1] : 0.0f;
+        ob[(size_t)c * HW] = __builtin_fmaf(v11, se, __builtin_fmaf(v10, sw, __builtin_fmaf(v01, ne, v00 * nw)));
+    }
+}
+
+hipError_t launch_inverse_warp(const float* img, const float* depth, const float* Kinv, const float* proj, int B,
+                               int C, int H, int W, float* out, unsigned char* valid, hipStream_t stream) {
+    dim3 grid((H * W + 255) / 256, B);
+    hipLaunchKernelGGL(inverse_warp_kernel, grid, dim3(256), 0, stream, img, depth, Kinv, proj, C, H, W, out, valid);
+    return hipGetLastError();
+}
+
 }  // namespace pdepth

@@ -200,6 +200,23 @@ def main():
     save("g10_dpv_fuse.npz", logp=bv.numpy(), dmaps=dm.numpy(), masks=mk.numpy(), d_candi=d10, tofuse=tofuse.numpy(),
          fused=fused.numpy(), logfused=torch.log(fused).numpy())
 
+    # ---- G11: inverse_warp (training-loss warp named by the north star) ----------------------------
+    import utils.inverse_warp as iw
+    hh, ww = 20, 28
+    img11 = torch.randn(2, 3, hh, ww)
+    dep11 = torch.rand(2, hh, ww) * 20 + 4
+    K11 = torch.tensor([[[30.0, 0, 14.2], [0, 28.0, 9.7], [0, 0, 1]]]).repeat(2, 1, 1)
+    pose44 = torch.eye(4).repeat(2, 1, 1)
+    pose44[0, :3, :3] = torch.from_numpy(_rot(0.03, -0.02, 0.01).astype(np.float32)); pose44[0, :3, 3] = torch.tensor([0.4, -0.1, 0.3])
+    pose44[1, :3, 3] = torch.tensor([-0.6, 0.05, -0.2])
+    pose6 = torch.tensor([[0.2, -0.1, 0.3, 0.02, -0.03, 0.01], [-0.4, 0.0, 0.1, -0.01, 0.02, 0.04]])
+    o44, v44 = iw.inverse_warp(img11, dep11, pose44, K11)
+    o6e, v6e = iw.inverse_warp(img11, dep11, pose6, K11, rotation_mode="euler")
+    o6q, v6q = iw.inverse_warp(img11, dep11, pose6, K11, rotation_mode="quat")
+    save("g11_inverse_warp.npz", img=img11.numpy(), depth=dep11.numpy(), K=K11.numpy(), pose44=pose44.numpy(),
+         pose6=pose6.numpy(), out44=o44.numpy(), valid44=v44.numpy(), out6e=o6e.numpy(), valid6e=v6e.numpy(),
+         out6q=o6q.numpy(), valid6q=v6q.numpy())
+
     print("golden fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -61,3 +61,29 @@ def test_hip_dpv_fuse():
     np.testing.assert_allclose(fused.cpu().numpy(), g["fused"], rtol=2e-5, atol=1e-9)
     np.testing.assert_allclose(logf.cpu().numpy(), g["logfused"], rtol=1e-5, atol=2e-5)
     assert (fused.sum(1) - 1).abs().max().item() < 1e-4
+
+
+def test_oracle_inverse_warp_matches_reference_fixture():
+    g = golden("g11_inverse_warp.npz")
+    out, valid = O.inverse_warp(torch.from_numpy(g["img"]), torch.from_numpy(g["depth"]), torch.from_numpy(g["pose44"]),
+                                torch.from_numpy(g["K"]))
+    np.testing.assert_allclose(out.numpy(), g["out44"], rtol=1e-5, atol=1e-5)
+    assert (valid.numpy() != g["valid44"]).mean() < 0.01
+
+
+@pytest.mark.gpu
+def test_hip_inverse_warp():
+    from pdepth_amd.utils import inverse_warp as iw
+    g = golden("g11_inverse_warp.npz")
+    dev = torch.device("cuda:0")
+    img, dep, K = (torch.from_numpy(g[k]).to(dev) for k in ("img", "depth", "K"))
+    for pose_key, mode, okey, vkey in (("pose44", "euler", "out44", "valid44"), ("pose6", "euler", "out6e", "valid6e"),
+                                       ("pose6", "quat", "out6q", "valid6q")):
+        out, valid = iw.inverse_warp(img, dep, torch.from_numpy(g[pose_key]).to(dev), K, rotation_mode=mode)
+        assert out.shape == (2, 3, 20, 28) and valid.dtype == torch.bool
+        np.testing.assert_allclose(out.cpu().numpy(), g[okey], rtol=1e-4, atol=2e-4)
+        assert (valid.cpu().numpy() != g[vkey]).mean() < 0.01  # a coordinate exactly at +-1 may flip by rounding
+    with pytest.raises(NotImplementedError):
+        iw.inverse_warp(img, dep, torch.from_numpy(g["pose44"]).to(dev), K, padding_mode="border")
+    with pytest.raises(AssertionError, match="wrong size for depth"):
+        iw.inverse_warp(img, dep[:, None], torch.from_numpy(g["pose44"]).to(dev), K)
