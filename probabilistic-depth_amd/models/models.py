@@ -25,7 +25,6 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..utils import img_utils
 
 EPSILON = torch.finfo(float).eps  # reference: utils/img_utils.py:12
 
@@ -197,20 +196,6 @@ class Base3D(nn.Module):
         if prob:
             res, _ = ops.dpv_reduce(res.contiguous(), None, want_logp=True, want_depth=False, inplace=True)
         return res
-
-
-# ------------------------------------------------------------------------------------------------
-# DPV fusion helpers of the upsample mode (utils/img_utils.py:31-47, :360-375) -- torch ops on device
-# ------------------------------------------------------------------------------------------------
-def gen_dpv_withmask(dmaps, masks, d_candi, var=0.3):
-    d = torch.as_tensor(np.asarray(d_candi), dtype=torch.float32, device=dmaps.device).view(1, -1, 1, 1)
-    sigma = torch.sqrt(torch.tensor(var, device=dmaps.device))
-    dists = torch.exp(-torch.pow(torch.abs(d - dmaps.unsqueeze(1)), 2.0) / (2 * torch.pow(sigma, 2.0)))
-    dists = dists / torch.sum(dists, dim=1, keepdim=True)
-    dists[dists != dists] = -1
-    uni = torch.ones_like(dists) / d.shape[1]
-    mask = masks[:, :1]
-    return torch.clamp(dists * mask + uni * (1.0 - mask), EPSILON, 1.0)
 
 
 # ------------------------------------------------------------------------------------------------
