@@ -66,5 +66,29 @@ def main():
     print(json.dumps({"case": "warp_feature B=4 V=2 D=64 64x128", "ms": ms, "algorithmic_GBps": byt / ms / 1e6}), flush=True)
 
 
+def model_cases():
+    """BASELINE config 4 (mono_feedback, 5 chained frames, B=1, 256x512 image -> 64x128 sweep) and the
+    plain eval model: whole-model time per frame (MIOpen convs included) next to the hot-path kernels."""
+    import time
+    from pdepth_amd import harness
+    from pdepth_amd.models import get_model
+    for nmode in ("default", "default_feedback"):
+        model = get_model(synth.default_cfg(nmode), 0)
+        synth.seed_weights(model, seed=8)
+        model = model.cuda().eval()
+        frames = [harness.move_input(synth.make_model_input(4000 + i, B=1, V=1, H=256, W=512, D=64, pose="mono"), "cuda")
+                  for i in range(5)]
+        harness.eval_trajectory(model, frames)  # warm-up (MIOpen find)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            harness.eval_trajectory(model, frames)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 15 * 1e3
+        print(json.dumps({"case": "cfg4-style whole model nmode=%s, 5-frame trajectory, B=1, 256x512 image" % nmode,
+                          "ms_per_frame": ms, "frames_per_s": 1e3 / ms}), flush=True)
+
+
 if __name__ == "__main__":
     main()
+    model_cases()
