@@ -223,3 +223,43 @@ def test_full_size_properties(dev):
     oc, _, _ = oracle_batch({**strip, "ref": b["ref"][:1], "src": b["src"][:1], "K": b["K"][:1], "R": b["R"][:1],
                              "t": b["t"][:1], "rays": b["rays"][:1], "cxcy": b["cxcy"][:1]})
     np.testing.assert_allclose(cost[:1].cpu().numpy(), oc.numpy(), rtol=COST_RTOL, atol=COST_ATOL)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(C=1, D=1, H=1, W=1, V=1),      # smallest possible problem
+    dict(C=3, D=2, H=1, W=37, V=1),     # a single row
+    dict(C=3, D=5, H=29, W=1, V=2),     # a single column
+    dict(C=2, D=160, H=6, W=20, V=1),   # largest D of the LDS-tiled kernel
+    dict(C=2, D=161, H=6, W=20, V=1),   # one more: AUTO switches to the gather kernel
+    dict(C=2, D=512, H=4, W=16, V=1),   # largest D of the gather kernel
+])
+def test_extreme_shapes(dev, cfg):
+    b = synth.make_batch(51, 1, pose="mono", **cfg)
+    ocost, ologp, odepth = oracle_batch(b)
+    d = to_dev(b, dev)
+    for algo in ("auto", "direct"):
+        cost, logp, depth = ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"],
+                                          d["d_candi"], 10.0, want_cost=True, algo=algo)
+        np.testing.assert_allclose(cost.cpu().numpy(), ocost.numpy(), rtol=COST_RTOL, atol=COST_ATOL)
+        assert (depth.cpu() - odepth).abs().max().item() <= DEPTH_ATOL
+
+
+def test_argument_errors(dev):
+    b = to_dev(synth.make_batch(52, 1, C=4, D=8, H=8, W=8, V=1), dev)
+    args = [b["ref"], b["src"], b["K"], b["R"], b["t"], b["rays"], b["cxcy"], b["d_candi"], 10.0]
+    with pytest.raises(Exception, match="undefined metric"):
+        ops.sweep_cost(*args, feat_dist="cosine")
+    with pytest.raises(RuntimeError, match="exceeds"):
+        ops.sweep_cost(*args[:7], synth.powerf(5, 40, 513, 1.0), 10.0)
+    with pytest.raises(RuntimeError, match="expected float32"):
+        ops.sweep_cost(b["ref"].double(), *args[1:])
+    with pytest.raises(RuntimeError, match="does not match"):
+        ops.sweep_cost(b["ref"], b["src"][:, :, :3], *args[2:])
+    with pytest.raises(RuntimeError, match="expected shape"):
+        ops.sweep_cost(b["ref"], b["src"], b["K"][:, :2], *args[3:])
+    with pytest.raises(RuntimeError, match="sigma"):
+        ops.sweep_cost(*args[:8], 0.0)
+    # non-contiguous inner layout is copied, not rejected
+    ref_t = b["ref"].permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)
+    assert not ref_t.is_contiguous()
+    assert torch.equal(ops.sweep_cost(ref_t, *args[1:]), ops.sweep_cost(*args))
