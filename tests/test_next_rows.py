@@ -67,7 +67,10 @@ def test_oracle_inverse_warp_matches_reference_fixture():
     g = golden("g11_inverse_warp.npz")
     out, valid = O.inverse_warp(torch.from_numpy(g["img"]), torch.from_numpy(g["depth"]), torch.from_numpy(g["pose44"]),
                                 torch.from_numpy(g["K"]))
-    np.testing.assert_allclose(out.numpy(), g["out44"], rtol=1e-5, atol=1e-5)
+    # another host's BLAS rounds K^-1 @ pix and K @ pose differently (see csrc/geometry.hpp): sample positions
+    # move by an ulp and the warped random image by ~1e-4
+    tol = 1e-5 if same_cpu_as_golden(g) else 5e-4
+    np.testing.assert_allclose(out.numpy(), g["out44"], rtol=tol, atol=tol)
     assert (valid.numpy() != g["valid44"]).mean() < 0.01
 
 
