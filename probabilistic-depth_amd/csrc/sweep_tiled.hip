@@ -1,7 +1,7 @@
 // LDS-tiled plane sweep: the fast path of pdepth_sweep_{cost,dpv}_f32.
 //
-// Same arithmetic as sweep_direct.hip (reference op order, bit-faithful sample positions) but the
-// bilinear taps come from LDS instead of global memory.
+// Same bit-faithful sample positions and bilinear weights as sweep_direct.hip, but the taps come from
+// LDS instead of global memory and the per-channel arithmetic is folded into five fma-class ops.
 //
 //   block   = 16x4 reference pixels x 4 plane groups = 256 threads.  Wave w of the block owns the
 //             same 64 pixels (lane = 16 wide x 4 tall) and plane group w: KP = 8 consecutive depth
@@ -28,7 +28,8 @@
 // Consecutive planes hit neighbouring texels, so a super group's window is only a few texels larger
 // than the tile and each source texel is staged from L2 a handful of times per chunk instead of being
 // gathered 4 x D times.  A block whose window does not fit (extreme poses) raises its tile flag and
-// leaves the tile to the gather kernel of sweep_direct.hip -- results are identical.
+// leaves the tile to the gather kernel of sweep_direct.hip; a window that is merely too large is first
+// split into 2 or 4 parts of consecutive planes.  Both kernels agree to rounding (~1e-7 relative per term).
 #include <hip/hip_runtime.h>
 
 #include "geometry.hpp"
