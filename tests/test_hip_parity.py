@@ -263,3 +263,41 @@ def test_argument_errors(dev):
     ref_t = b["ref"].permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)
     assert not ref_t.is_contiguous()
     assert torch.equal(ops.sweep_cost(ref_t, *args[1:]), ops.sweep_cost(*args))
+
+
+def test_fuzz_tiled_against_gather(dev):
+    """Random shapes / poses / intrinsics: the LDS-tiled kernel (with window splitting and per-tile fallback)
+    must agree with the gather kernel, which evaluates every pixel independently in the reference's op order.
+    Catches windowing / splitting / zero-padding mistakes that the handful of structured cases could miss."""
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for case in range(120):
+        H, W = int(rng.integers(3, 70)), int(rng.integers(3, 110))
+        C, D, V = int(rng.integers(1, 12)), int(rng.integers(1, 80)), int(rng.integers(1, 4))
+        b = synth.make_batch(60 + case, 1, C=C, D=D, H=H, W=W, V=V, pose="mono",
+                             cx_off=float(rng.uniform(-2, 2)), cy_off=float(rng.uniform(-1, 1)))
+        kind = case % 4
+        if kind == 1:    # strong rotation + sideways motion: slanted epipolar lines, large windows
+            ang = rng.uniform(-0.25, 0.25, size=3)
+            cz, sz = np.cos(ang[2]), np.sin(ang[2])
+            Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], dtype=np.float32)
+            b["R"][0, 0] = torch.from_numpy(Rz) @ b["R"][0, 0]
+            b["t"][0, 0] = torch.from_numpy(rng.uniform(-2.5, 2.5, size=3).astype(np.float32))
+        elif kind == 2:  # mostly out of the image / behind the camera
+            b["t"][0, 0] = torch.from_numpy(rng.uniform(-30, 30, size=3).astype(np.float32))
+        elif kind == 3:  # non-monotonic, clustered depth candidates
+            b["d_candi"] = np.sort(rng.uniform(0.5, 60.0, size=D))[::-1].copy() if case % 8 == 3 else rng.uniform(2.0, 50.0, size=D)
+        d = to_dev(b, dev)
+        args = (d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 7.5)
+        ca, la, da = ops.sweep_dpv(*args, want_cost=True, algo="auto")
+        cd, ld, dd = ops.sweep_dpv(*args, want_cost=True, algo="direct")
+        ca, cd = ca.cpu().numpy(), cd.cpu().numpy()
+        assert np.array_equal(np.isnan(ca), np.isnan(cd)), f"case {case}: NaN pattern differs"
+        scale = max(1.0, float(np.nanmax(np.abs(cd))) if np.isfinite(cd).any() else 1.0)
+        err = float(np.nanmax(np.abs(ca - cd))) / scale if np.isfinite(cd).any() else 0.0
+        worst = max(worst, err)
+        assert err < 2e-5, f"case {case} (kind {kind}, {H}x{W}, C={C}, D={D}, V={V}): tiled vs gather differ by {err:.3e} (relative)"
+        fin = np.isfinite(dd.cpu().numpy())
+        if fin.any():
+            assert np.abs(da.cpu().numpy() - dd.cpu().numpy())[fin].max() < 2e-3 * max(1.0, float(np.max(b["d_candi"])) / 40.0)
+    print(f"fuzz: worst relative cost difference tiled vs gather {worst:.2e}")

@@ -112,3 +112,20 @@ def test_undefined_metric_raises():
     with pytest.raises(Exception, match="undefined metric"):
         O.sweep_cost(it["ref"][None], it["src"][None], it["d_candi"], it["R"], it["t"], it["K"], it["rays"],
                      1.0, 1.0, 10.0, metric="cosine")
+
+
+def test_c_restatement_agrees_with_torch_oracle():
+    """oracle/sweep_ref.c (fp64 arithmetic at the fp32 sample positions) vs the op-for-op torch oracle: the gap
+    is the reference's own fp32 rounding noise (cost ~4e-6, depth ~2e-5 on N(0,1) features)."""
+    import pdepth_amd
+    from oracle import c_ref
+    it = synth.make_item(77, C=67, D=64, H=24, W=40, V=2, pose="mono", cx_off=0.7)
+    K = it["K"]
+    cost, logp, depth = O.sweep_dpv(it["ref"][None], it["src"][None], it["d_candi"], it["R"], it["t"], K, it["rays"],
+                                    K.numpy()[0, 2], K.numpy()[1, 2], 10.0)
+    sep = pdepth_amd._native.host_blas_mode() == pdepth_amd._native.BLAS_SEPARATE
+    c64, l64, d64 = c_ref.sweep_dpv_f64(it["ref"].numpy(), it["src"].numpy(), K.numpy(), it["R"].numpy(),
+                                        it["t"].numpy(), it["rays"].numpy(), K.numpy()[0, 2], K.numpy()[1, 2],
+                                        it["d_candi"], 10.0, blas_separate=int(sep))
+    assert np.abs(cost.numpy()[0] - c64).max() < 5e-5
+    assert np.abs(depth.numpy()[0] - d64).max() < 1e-4
