@@ -127,7 +127,7 @@ def main():
                                    f"algo={a.algo}", "global_batch": a.batch * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "fused sweep+DPV", "kernel_ms": kern_ms,
+                         "kernel": "fused sweep+DPV = pack_c4_kernel (source re-layout pre-pass) + sweep_tiled_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "per_rank_kernel_ms": [float(x) for x in allm[:, 1]],
             "gather_fallback_tiles": pdepth_amd._native.fallback_tiles(hi - lo, cfg["H"], cfg["W"]),

@@ -52,7 +52,9 @@ enum { PDEPTH_METRIC_L2 = 0, PDEPTH_METRIC_L1 = 1 };
  * (probabilistic-depth_amd/_native.py host_blas_mode()). */
 enum { PDEPTH_BLAS_FMA = 0, PDEPTH_BLAS_SEPARATE = 1 };
 
-/* algorithm selector for the sweep kernels */
+/* algorithm selector for the sweep kernels (pdepth_sample_coords_f32 reports the positions of the same
+ * selector: AUTO = explicit shared-reciprocal fma divide chain, DIRECT = compiler IEEE divides; the two are
+ * bit-identical for every position within reach of the image, tests/test_hip_parity.py) */
 enum {
     PDEPTH_ALGO_AUTO = 0,   /* fastest algorithm valid for the given geometry          */
     PDEPTH_ALGO_DIRECT = 1  /* per-plane bilinear gather, reference op order (any pose) */
@@ -114,7 +116,9 @@ int pdepth_sweep_dpv_f32(const pdepth_sweep_desc *desc, const pdepth_camera *cam
                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* Bytes of scratch the two sweep entry points need for `desc` (0 for ALGO_DIRECT); the workspace
- * must be 256-byte aligned.  ALGO_AUTO without it returns PDEPTH_E_WORKSPACE. */
+ * must be 256-byte aligned.  ALGO_AUTO without it returns PDEPTH_E_WORKSPACE.  For ALGO_AUTO it holds
+ * one flag per 16x4 tile and a channel-group-planar copy of the source views
+ * (B*V*ceil(C/4)*H*W*16 bytes, written by a pre-pass of every call) -- size it once per shape and reuse it. */
 size_t pdepth_sweep_workspace_bytes(const pdepth_sweep_desc *desc);
 
 /*

@@ -282,15 +282,18 @@ def warp_feature(src, K, R, t, rays, cxcy, d_candi, blas_mode=None):
     return out
 
 
-def sample_coords(K, R, t, rays, cxcy, d_candi, H, W, blas_mode=None):
-    """Diagnostic: (ix, iy) [B,V,D,H,W] sample positions handed to the bilinear sampler."""
+def sample_coords(K, R, t, rays, cxcy, d_candi, H, W, blas_mode=None, algo=ALGO_AUTO):
+    """Diagnostic: (ix, iy) [B,V,D,H,W] sample positions handed to the bilinear sampler.
+
+    algo selects the arithmetic of the sweep kernel of the same name: ALGO_AUTO = the shared-reciprocal divide
+    chain of the LDS-tiled kernel, ALGO_DIRECT = the compiler's IEEE divides of the gather kernel."""
     lib = load()
     _dev(K, "K")
     B, V = R.shape[0], R.shape[1]
     d_candi = d_candi.contiguous()
     D = d_candi.numel()
     cam, keep = _camera(K, R, t, rays, cxcy, B, V, H * W)
-    desc = SweepDesc(B, V, 1, D, H, W, 0, 0, _blas(blas_mode), 1.0, 0, 0, H * W)
+    desc = SweepDesc(B, V, 1, D, H, W, 0, int(algo), _blas(blas_mode), 1.0, 0, 0, H * W)
     ix = torch.empty((B, V, D, H, W), dtype=torch.float32, device=K.device)
     iy = torch.empty_like(ix)
     with torch.cuda.device(K.device):

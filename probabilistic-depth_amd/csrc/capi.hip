@@ -45,6 +45,7 @@ pdepth::SweepArgs make_args(const pdepth_sweep_desc* d, const pdepth_camera* cam
     a.d_candi = d_candi;
     a.B = d->B; a.V = d->V; a.C = d->C; a.D = d->D; a.H = d->H; a.W = d->W;
     a.metric = d->metric; a.sigma = d->sigma; a.blas_mode = d->blas_mode;
+    a.fast_div = d->algo == PDEPTH_ALGO_AUTO;
     a.ref_bstride = d->ref_bstride; a.src_bstride = d->src_bstride; a.src_vstride = d->src_vstride;
     return a;
 }
@@ -54,9 +55,10 @@ int launched(hipError_t e, const char* who) {
     return PDEPTH_OK;
 }
 
-// The tiled kernel needs one int per 16x4 tile (flags of tiles left to the gather kernel).
+// The tiled kernel needs one int per 16x4 tile (flags of tiles left to the gather kernel) plus the
+// channel-group-planar copy of the source views it stages from.
 size_t tiled_ws_bytes(const pdepth_sweep_desc* d) {
-    return pdepth::sweep_tiled_workspace_bytes(d->B, d->H, d->W);
+    return pdepth::sweep_tiled_workspace_bytes(d->B, d->V, d->C, d->H, d->W);
 }
 
 int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const float* ref,
@@ -78,7 +80,7 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
     a.cost_out = cost; a.logp_out = logp; a.depth_out = depth;
     // the tiled kernel addresses one view through a 32-bit buffer descriptor (C*H*W*4 bytes < 2^31)
     if (d->algo == PDEPTH_ALGO_AUTO && d->D <= pdepth::sweep_tiled_max_planes() &&
-        (long long)d->C * d->H * d->W * 4 < (1ll << 31)) {
+        (long long)((d->C + 3) / 4) * d->H * d->W * 16 < (1ll << 31)) {
         const size_t need = tiled_ws_bytes(d);
         if (!workspace || workspace_bytes < need)
             return fail(PDEPTH_E_WORKSPACE, "%s: ALGO_AUTO needs %zu bytes of workspace (got %zu); "

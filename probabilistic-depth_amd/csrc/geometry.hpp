@@ -88,6 +88,47 @@ __device__ __forceinline__ void plane_sample_pos(const ViewXform& x, float t2a, 
     iy = __builtin_fmaf(gy + 1.0f, half_h, -0.5f);
 }
 
+// The same position with the divides spelled out.  hipcc lowers an IEEE fp32 divide n/d to
+//     d' = div_scale(d), n' = div_scale(n), y0 = rcp(d'), e = fma(-d', y0, 1), y = fma(e, y0, y0),
+//     q0 = n'*y, r0 = fma(-d', q0, n'), q1 = fma(r0, y, q0), r1 = fma(-d', q1, n'),
+//     q = div_fmas(r1, y, q1), div_fixup
+// where div_scale / div_fmas / div_fixup only act on operands near the ends of the exponent range (they
+// are the identity for |d|, |n/d| within 2^+-96 or so and finite).  Positions in that range -- every
+// position that can land within reach of the image -- therefore come out bit-identical from the plain
+// fma chain below, and it lets the two divides by den share y (rcp + 2 fma) and the divides by the
+// wave-uniform cx, cy use reciprocals refined once per thread (refined_rcp).  Outside the range the
+// chain yields NaN or a huge value where IEEE yields inf / a huge value; both classify as "all taps
+// out of bounds" downstream, with NaN weights in exactly the cases where the reference has them
+// (inf - floor(inf) = NaN).  tests/test_hip_parity.py compares both variants bit for bit.
+__device__ __forceinline__ float refined_rcp(float d) {
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+__device__ __forceinline__ float div_core(float n, float d, float y) {
+    const float q0 = n * y;
+    const float r0 = __builtin_fmaf(-d, q0, n);
+    const float q1 = __builtin_fmaf(r0, y, q0);
+    const float r1 = __builtin_fmaf(-d, q1, n);
+    return __builtin_fmaf(r1, y, q1);
+}
+__device__ __forceinline__ void plane_sample_pos_fast(const ViewXform& x, float t2a, float t2b,
+                                                      float t2c, float d, float cx, float cy,
+                                                      float rcx, float rcy, float half_w,
+                                                      float half_h, float& ix, float& iy) {
+    const float px = x.kt[0] + t2a * d;
+    const float py = x.kt[1] + t2b * d;
+    const float pz = x.kt[2] + t2c * d;
+    const float den = pz + 1e-10f;
+    const float y = refined_rcp(den);
+    const float u = div_core(px, den, y);
+    const float v = div_core(py, den, y);
+    const float gx = div_core(u - cx, cx, rcx);
+    const float gy = div_core(v - cy, cy, rcy);
+    ix = __builtin_fmaf(gx + 1.0f, half_w, -0.5f);
+    iy = __builtin_fmaf(gy + 1.0f, half_h, -0.5f);
+}
+
 // Bilinear footprint of a sample position: top-left texel, the four weights and a 4-bit
 // in-bounds mask (bit0 nw, bit1 ne, bit2 sw, bit3 se).  Positions that are NaN or far
 // outside the image get mask 0 (all taps read as zero, like padding_mode='zeros').

@@ -23,6 +23,7 @@ struct SweepArgs {
     int B, V, C, D, H, W;
     int metric;
     int blas_mode;
+    int fast_div;      // 1: shared-reciprocal divide chain (geometry.hpp), 0: compiler's IEEE divides
     float sigma;
     long long ref_bstride, src_bstride, src_vstride;
 };
@@ -34,7 +35,7 @@ hipError_t launch_sweep_direct_flagged(const SweepArgs& a, const int* tile_flags
 int sweep_direct_max_planes(int C);
 
 // sweep_tiled.hip
-size_t sweep_tiled_workspace_bytes(int B, int H, int W);
+size_t sweep_tiled_workspace_bytes(int B, int V, int C, int H, int W);
 int sweep_tiled_max_planes();
 hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t stream);
 

@@ -8,13 +8,19 @@
 //             planes of the current "super group" of 4*KP = 32 planes.  The per-plane geometry of a
 //             thread (tap offset into the LDS window + 4 bilinear weights, 8 planes) lives in
 //             registers and is computed ONCE per (pixel, plane, view);
+//   source  = a pre-pass (pack_c4_kernel, HBM-rate) re-lays every source view from NCHW to channel-group-
+//             planar [C/4][H][W] float4 texels in the workspace, zero padded to a multiple of 4 channels;
 //   window  = bounding box of every tap the block touches in the current super group, staged four
-//             channels at a time into LDS as float4 texels [row][col] (double buffered: chunk ch+1
-//             travels global -> registers while chunk ch is computed from LDS; one barrier per
-//             chunk).  The row pitch is a multiple of 16 texels, which makes the per-lane
-//             ds_read_b128 of a 16x4 wave bank-conflict free.  Texels outside the image are staged
-//             as zeros, which IS padding_mode='zeros' -- no per-tap masks in the inner loop;
-//   ref     = the tile's reference features of the chunk, staged next to the window;
+//             channels at a time into LDS as float4 texels [row][col] by LDS-DMA (buffer_load_dwordx4 ...
+//             lds: a wave-instruction moves 64 texels = 1 KiB, no registers, no ds_write), double
+//             buffered: chunk ch+1 is in flight while chunk ch is computed; one barrier per chunk.  The
+//             DMA is issued from inline asm with hand-counted s_waitcnt, because the compiler would
+//             otherwise drain it in front of every ds_read.  Texels outside the image are fetched with an
+//             out-of-range buffer offset and arrive as zeros, which IS padding_mode='zeros' -- no per-tap
+//             masks in the inner loop.  The row pitch is a multiple of 16 texels;
+//   taps    = software pipelined over the wave's planes: the four ds_read_b128 of plane i+1 are in flight
+//             while the 20 fma of plane i execute; the window buffer is an immediate of the ds_read;
+//   ref     = the tile's reference features of the chunk (wave w moves channel 4*ch+w by LDS-DMA from NCHW);
 //   sum     = five VALU ops per (pixel, plane, channel): the reference feature enters the bilinear fma
 //             chain as its initial addend (diff = fma(s00,nw,-r) ... fma(s11,se,.)) and the square is
 //             accumulated with one fma.  The reference rounds the interpolated value and the square
@@ -43,9 +49,15 @@ constexpr int TW = 16, TH = 4;    // tile (pixels); one wave covers it
 constexpr int NPG = 4;            // plane groups per block (= waves)
 constexpr int KP = 8;             // planes per group
 constexpr int SG = NPG * KP;      // planes per super group
-constexpr int NBUF = 2;           // LDS window buffers
-constexpr int NTEX_MAX = 1024;    // window texels per buffer (LDS: NTEX_MAX*NBUF*16 B = 32 KB)
-constexpr int SLOTS = 4;          // sub-blocks of a window (256 texels each, register-staged prefetch)
+constexpr int NBUF = 2;           // LDS window buffers: chunk ch+1 is in flight (LDS-DMA) while chunk ch is computed
+#ifndef PDEPTH_NTEX   // experiment knobs (tools/variants.sh): window texels per buffer, blocks per CU
+#define PDEPTH_NTEX 1024
+#endif
+#ifndef PDEPTH_OCC
+#define PDEPTH_OCC 3
+#endif
+constexpr int NTEX_MAX = PDEPTH_NTEX;    // window texels per buffer (LDS: NTEX_MAX*NBUF*16 B = 32 KB)
+constexpr int SLOTS = (PDEPTH_NTEX + 255) / 256;          // sub-blocks of a window (256 texels each = one DMA pass of the block)
 
 __device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
@@ -58,20 +70,50 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// LDS-DMA issued from inline asm: the compiler must not know that these loads write LDS, or it drains them
+// (s_waitcnt vmcnt(0)) in front of the next ds_read of the other buffer and nothing overlaps.  The waits are
+// counted by hand (wait_vm) in front of the barrier that publishes a buffer.
+__device__ __forceinline__ void dma_b128(v4i rsrc, unsigned lds_addr, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ void dma_b32(v4i rsrc, unsigned lds_addr, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// raw barrier: every LDS access of this wave has completed, but VMEM (the DMA of later chunks) stays in flight
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ v4i make_rsrc(const void* base, int bytes) {
+    const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+    v4i r;
+    r.x = (int)(unsigned)p; r.y = (int)(unsigned)(p >> 32) & 0xffff; r.z = bytes; r.w = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+
 }  // namespace
 
 template <int METRIC>
-__global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* __restrict__ tile_flags,
-                                                             int tiles_x) {
+__global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a, const float4* __restrict__ packed,
+                                                              int* __restrict__ tile_flags, int tiles_x) {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
     float4* win = lds4;                                   // [NBUF][NTEX_MAX]
-    float4* reft = lds4 + NBUF * NTEX_MAX;                // [NBUF][64]
-    float* costs = reinterpret_cast<float*>(reft + NBUF * 64);  // [D][64]
+    float* reft = reinterpret_cast<float*>(lds4 + NBUF * NTEX_MAX);  // [NBUF][4 channels][64 pixels]
+    float* costs = reft + NBUF * 256;                     // [D][64]
     float* red = costs + (size_t)a.D * 64;                // [NPG][64]
+    float* dcl = red + NPG * 64;                          // [D] depth candidates (read wave-uniformly, per plane)
     __shared__ int s_bbox[4];
 
     const int tid = threadIdx.x;
-    const int pgl = tid >> 6;        // plane group of this wave
+    const int pgl = __builtin_amdgcn_readfirstlane(tid >> 6);  // plane group of this wave (wave-uniform)
     const int lane = tid & 63;       // pixel of the tile
     const int lx = lane & 15, ly = lane >> 4;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so blocks i and i+8
@@ -97,12 +139,16 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
 
     const float cx = a.cxcy[b * 2 + 0], cy = a.cxcy[b * 2 + 1];
     const float half_w = (float)a.W / 2.0f, half_h = (float)a.H / 2.0f;
+    const float rcx = refined_rcp(cx), rcy = refined_rcp(cy);
     const float r0 = a.rays[((size_t)b * 3 + 0) * HW + p];
     const float r1 = a.rays[((size_t)b * 3 + 1) * HW + p];
     const float r2 = a.rays[((size_t)b * 3 + 2) * HW + p];
     const float* refb = a.ref + (size_t)b * a.ref_bstride;
-    const auto ref_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)refb, (short)0, a.C * HW * 4, 0x00020000);
+    const v4i ref_rsrc = make_rsrc(refb, a.C * HW * 4);
     const int nchunk = (a.C + 3) / 4;
+    for (int k = tid; k < a.D; k += 256) dcl[k] = a.d_candi[k];
+    __syncthreads();
+    const int win_lds0 = (int)lds_addr_of(win);
 
     for (int v = 0; v < a.V; ++v) {
         ViewXform xf;
@@ -110,8 +156,8 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
                         a.blas_mode, xf);
         float t2a, t2b, t2c;
         ray_term2(xf, r0, r1, r2, t2a, t2b, t2c);
-        const float* srcv = a.src + (size_t)b * a.src_bstride + (size_t)v * a.src_vstride;
-        const auto src_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)srcv, (short)0, a.C * HW * 4, 0x00020000);
+        const float4* srcv = packed + ((size_t)b * a.V + v) * nchunk * HW;  // [C/4][H][W] float4 texels
+        const v4i src_rsrc = make_rsrc(srcv, nchunk * HW * 16);
 
         for (int k0 = 0; k0 < a.D; k0 += SG) {
             // ---- geometry of this thread's KP planes (registers) ----------------------------
@@ -124,13 +170,13 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
             int kpl[KP];  // depth plane of slot i
             float wnw[KP], wne[KP], wsw[KP], wse[KP];
             auto geometry = [&](int nsplit_) {
-                const int per_ = KP / nsplit_;
+                const int lper = nsplit_ == 1 ? 3 : nsplit_ == 2 ? 2 : 1;  // log2(planes per part and wave)
 #pragma unroll
                 for (int i = 0; i < KP; ++i) {
-                    kpl[i] = k0 + (i / per_) * (NPG * per_) + pgl * per_ + (i % per_);
+                    kpl[i] = k0 + ((i >> lper) << (lper + 2)) + (pgl << lper) + (i & ((1 << lper) - 1));
                     const int k = min(kpl[i], a.D - 1);
                     float ix, iy;
-                    plane_sample_pos(xf, t2a, t2b, t2c, a.d_candi[k], cx, cy, half_w, half_h, ix, iy);
+                    plane_sample_pos_fast(xf, t2a, t2b, t2c, dcl[k], cx, cy, rcx, rcy, half_w, half_h, ix, iy);
                     const Footprint f = make_footprint(ix, iy, a.W, a.H);
                     wnw[i] = f.nw; wne[i] = f.ne; wsw[i] = f.sw; wse[i] = f.se;
                     if (f.mask != 0u && live) {  // at least one tap inside the image
@@ -151,8 +197,7 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
             for (int i = 0; i < KP; ++i) acc[i] = 0.0f;
 
             // ---- window of planes [first, first+count) of every wave: block bounding box ------------
-            int wx0, wy0, wx1, wy1, WC, WR, ncb, nsub;
-            int glog = 4;  // log2 of the staging grid width: the 256 threads walk the window as 16x16, 32x8 or 64x4
+            int wx0, wy0, wx1, wy1, WC, WR;
             bool empty;
             auto window_of = [&](int first, int count) -> bool {
                 int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN;
@@ -178,15 +223,7 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
                 if (empty) { wx0 = 0; wx1 = 0; wy0 = 0; wy1 = 0; }
                 WC = ((wx1 - wx0 + 2) + 15) & ~15;  // +1 east tap, pitch multiple of 16
                 WR = wy1 - wy0 + 2;                  // +1 south tap
-                // staging grid shape with the fewest sub-blocks (windows are usually wide and short)
-                nsub = INT_MAX;
-#pragma unroll
-                for (int gl = 4; gl <= 6; ++gl) {
-                    const int gw = 1 << gl, gh = 256 >> gl;
-                    const int n = ((WR + gh - 1) / gh) * ((WC + gw - 1) >> gl);
-                    if (n < nsub) { nsub = n; glog = gl; ncb = (WC + gw - 1) >> gl; }
-                }
-                return WC * WR <= NTEX_MAX && nsub <= SLOTS;  // block-uniform
+                return WC * WR <= NTEX_MAX;   // block-uniform
             };
             // Smallest split into 1, 2 or 4 parts whose windows all fit LDS; the geometry is only redone
             // when the coarser split failed (large disparities per plane, e.g. 512x1024 with D=128).
@@ -211,117 +248,109 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
             for (int i = 0; i < KP; ++i) {
                 if (i / per == part) {
                     const int fy0 = off[i] >> 16, fx0 = (int)(short)(off[i] & 0xffff);
-                    off[i] = (off[i] == INT_MIN) ? 0 : (fy0 - wy0) * WC + (fx0 - wx0);
+                    // LDS byte address of the top-left tap in window buffer 0
+                    off[i] = win_lds0 + ((off[i] == INT_MIN) ? 0 : (fy0 - wy0) * WC + (fx0 - wx0)) * 16;
                 }
             }
 
-            // ---- channel chunks (4 channels each), software pipelined ------------------------
-            // Staging uses raw buffer loads: a wave-uniform descriptor + scalar channel offset + one
-            // per-lane texel offset that is loop invariant.  Out-of-image texels carry an offset
-            // beyond the descriptor's range, for which the hardware returns 0 -- the zero padding.
+            // ---- channel chunks (4 channels each), double buffered through LDS-DMA ------------
+            // The window is staged by buffer_load_dwordx4 ... lds: a wave-instruction moves 64 texels
+            // (1 KiB) from the packed source straight into 64 consecutive float4 slots of the LDS
+            // window, no registers involved.  Per lane only the texel's byte offset is needed, and it is
+            // invariant over the chunks (the channel group is the scalar offset).  Out-of-image texels
+            // carry an offset beyond the descriptor's range, for which the hardware delivers 0 -- the
+            // zero padding.
             int so[SLOTS];
-            {
-                int rb = 0, cb = 0;
 #pragma unroll
-                for (int sl = 0; sl < SLOTS; ++sl) {
-                    so[sl] = 0x7fffffff;
-                    if (sl < nsub) {  // uniform
-                        const int row = rb * (256 >> glog) + (tid >> glog), col = (cb << glog) + (tid & ((1 << glog) - 1));
-                        const int gx = wx0 + col, gy = wy0 + row;
-                        const bool inb = !empty && row < WR && col < WC && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;
-                        so[sl] = inb ? (gy * a.W + gx) * 4 : 0x7fffffff;
-                        if (++cb == ncb) { cb = 0; ++rb; }
-                    }
-                }
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int tl = sl * 256 + tid;
+                const int row = tl / WC, col = tl - row * WC;
+                const int gx = wx0 + col, gy = wy0 + row;
+                const bool inb = !empty && row < WR && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;
+                so[sl] = inb ? (gy * a.W + gx) * 16 : 0x7fffffff;
             }
-            float4 st_w[SLOTS];
-            float4 st_r;
-            auto prefetch = [&](int ch) {
-                const int c = ch * 4;
-                const bool k1 = c + 1 < a.C, k2 = c + 2 < a.C, k3 = c + 3 < a.C;  // uniform channel tail
-                const int s0 = c * HW * 4;
-                const int s1 = k1 ? s0 + HW * 4 : s0, s2 = k2 ? s0 + 2 * HW * 4 : s0, s3 = k3 ? s0 + 3 * HW * 4 : s0;
+            // reference features: wave w moves channel 4*ch + w of the tile's 64 pixels
+            const int ro = p * 4;
+            const unsigned win_lds = lds_addr_of(win + pgl * 64), ref_lds = lds_addr_of(reft + pgl * 64);
+            auto stage = [&](int bufi, int ch) {
+                const int soff = ch * HW * 16;
 #pragma unroll
-                for (int sl = 0; sl < SLOTS; ++sl) {
-                    if (sl < nsub) {  // uniform
-                        const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, so[sl], s0, 0));
-                        const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, so[sl], s1, 0));
-                        const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, so[sl], s2, 0));
-                        const float v3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src_rsrc, so[sl], s3, 0));
-                        st_w[sl] = make_float4(v0, v1, v2, v3);  // raw: no use of the data before commit()
-                    }
-                }
-                if (pgl == 0) {  // wave 0 stages the tile's reference features
-                    const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ref_rsrc, p * 4, s0, 0));
-                    const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ref_rsrc, p * 4, s1, 0));
-                    const float q2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ref_rsrc, p * 4, s2, 0));
-                    const float q3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ref_rsrc, p * 4, s3, 0));
-                    st_r = make_float4(q0, q1, q2, q3);
-                }
+                for (int sl = 0; sl < SLOTS; ++sl)
+                    if (sl * 256 + pgl * 64 < WC * WR)  // wave-uniform: this wave's 64 texels are part of the window
+                        dma_b128(src_rsrc, win_lds + (bufi * NTEX_MAX + sl * 256) * 16, so[sl], soff);
+                const int c = ch * 4 + pgl;
+                // channels beyond C: out of range => zeros (the packed source is zero padded as well)
+                dma_b32(ref_rsrc, ref_lds + bufi * 1024, c < a.C ? ro : 0x7fffffff, c < a.C ? c * HW * 4 : 0);
             };
-            auto commit = [&](int bufi, int ch) {
-                // Channels beyond C were fetched from a clamped (valid) plane and must read as zero; that
-                // only concerns the last chunk, and it is done here -- after the compute of the previous
-                // chunk -- so that nothing waits on the loads while they fly.
-                const int c = ch * 4;
-                const bool tail = c + 3 >= a.C;  // uniform
-                const bool k1 = c + 1 < a.C, k2 = c + 2 < a.C, k3 = c + 3 < a.C;
-                float4* wb = win + bufi * NTEX_MAX;
-                int rb = 0, cb = 0;
-#pragma unroll
-                for (int sl = 0; sl < SLOTS; ++sl) {
-                    if (sl < nsub) {
-                        const int row = rb * (256 >> glog) + (tid >> glog), col = (cb << glog) + (tid & ((1 << glog) - 1));
-                        if (row < WR && col < WC) {
-                            float4 val = st_w[sl];
-                            if (tail) val = make_float4(val.x, k1 ? val.y : 0.f, k2 ? val.z : 0.f, k3 ? val.w : 0.f);
-                            wb[row * WC + col] = val;
-                        }
-                        if (++cb == ncb) { cb = 0; ++rb; }
-                    }
-                }
-                if (pgl == 0) {
-                    float4 val = st_r;
-                    if (tail) val = make_float4(val.x, k1 ? val.y : 0.f, k2 ? val.z : 0.f, k3 ? val.w : 0.f);
-                    reft[bufi * 64 + lane] = val;
-                }
-            };
-            prefetch(0);
-            commit(0, 0);  // window_of() ended with a barrier: nobody reads the buffers any more
-            __syncthreads();
+            // Iteration ch: wait until this wave's DMA of chunk ch has landed, barrier (=> every wave's part of
+            // chunk ch is in LDS and every wave is done reading chunk ch-1), re-fill the buffer of chunk ch-1
+            // with chunk ch+1, compute chunk ch.  The two buffers get their own copy of the compute code so
+            // that the buffer base is an immediate of the ds_read (no per-chunk address arithmetic).
+            typedef const __attribute__((address_space(3))) v4f* lds_v4f;
+            const int WCB = WC * 16;
+            lds_barrier();  // every reader of the previous part / super group is done with the buffers
+            stage(0, 0);
             for (int ch = 0; ch < nchunk; ++ch) {
-                const int cur = ch & 1;
-                if (ch + 1 < nchunk) prefetch(ch + 1);  // in flight while this chunk is computed
+                wait_dma();
+                lds_barrier();
+                if (ch + 1 < nchunk) stage((ch + 1) & 1, ch + 1);
                 {
-                    const float4 rf = reft[cur * 64 + lane];
-                    const float4* wg = win + cur * NTEX_MAX;
-#pragma unroll
-                    for (int i = 0; i < KP; ++i) {
-                        if (i / per != part) continue;  // uniform: this plane is staged in another part
-                        // cap the taps in flight at two planes (32 VGPRs): left alone the scheduler hoists
-                        // all 32 ds_read_b128 of the chunk and spills the geometry
-                        if ((i & 1) == 0) __builtin_amdgcn_sched_barrier(0);
-                        const float4 s00 = wg[off[i]];
-                        const float4 s01 = wg[off[i] + 1];
-                        const float4 s10 = wg[off[i] + WC];
-                        const float4 s11 = wg[off[i] + WC + 1];
-#define PDEPTH_TAP(comp)                                                            \
+#define PDEPTH_TAP(T, comp)                                                         \
     {                                                                               \
-        float diff = __builtin_fmaf(s00.comp, wnw[i], -rf.comp);                    \
-        diff = __builtin_fmaf(s01.comp, wne[i], diff);                              \
-        diff = __builtin_fmaf(s10.comp, wsw[i], diff);                              \
-        diff = __builtin_fmaf(s11.comp, wse[i], diff);                              \
+        float diff = __builtin_fmaf(T[0].comp, wnw[i], -rf.comp);                   \
+        diff = __builtin_fmaf(T[1].comp, wne[i], diff);                             \
+        diff = __builtin_fmaf(T[2].comp, wsw[i], diff);                             \
+        diff = __builtin_fmaf(T[3].comp, wse[i], diff);                             \
         acc[i] = METRIC == 0 ? __builtin_fmaf(diff, diff, acc[i]) : acc[i] + fabsf(diff); \
     }
-                        PDEPTH_TAP(x) PDEPTH_TAP(y) PDEPTH_TAP(z) PDEPTH_TAP(w)
-#undef PDEPTH_TAP
-                        // pin the accumulation here: IR-level sinking otherwise moves the fma chains of all
-                        // 8 planes behind the last load and keeps 128 tap registers alive
-                        if (i & 1) asm volatile("" : "+v"(acc[i - 1]), "+v"(acc[i]));
+#define PDEPTH_LOAD(T, i_)                                                          \
+    {                                                                               \
+        const lds_v4f q0 = (lds_v4f)(size_t)(unsigned)(off[i_] + CUR * NTEX_MAX * 16);        \
+        const lds_v4f q1 = (lds_v4f)(size_t)(unsigned)(off[i_] + WCB + CUR * NTEX_MAX * 16);  \
+        T[0] = q0[0]; T[1] = q0[1]; T[2] = q1[0]; T[3] = q1[1];                     \
+    }
+                    // Software pipeline over the part's planes: the four taps of plane i+1 are in flight while
+                    // the 20 fma of plane i execute (two tap sets = 32 VGPRs).  The sched_barriers keep the
+                    // compiler from hoisting more loads (spills) or sinking the fma chains.
+#define PDEPTH_COMPUTE(PER, BASE)                                                                   \
+    {                                                                                               \
+        v4f ta[4], tb[4];                                                                           \
+        PDEPTH_LOAD(ta, BASE)                                                                       \
+        _Pragma("unroll") for (int i = BASE; i < BASE + PER; ++i) {                                 \
+            if (i + 1 < BASE + PER) {                                                               \
+                if ((i - BASE) & 1) PDEPTH_LOAD(ta, i + 1) else PDEPTH_LOAD(tb, i + 1)              \
+            }                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+            if ((i - BASE) & 1) { PDEPTH_TAP(tb, x) PDEPTH_TAP(tb, y) PDEPTH_TAP(tb, z) PDEPTH_TAP(tb, w) } \
+            else { PDEPTH_TAP(ta, x) PDEPTH_TAP(ta, y) PDEPTH_TAP(ta, z) PDEPTH_TAP(ta, w) }        \
+            asm volatile("" : "+v"(acc[i]));                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+        }                                                                                           \
+    }
+                    // (plane slots of a part and the buffer are compile-time constants in every instantiation)
+#define PDEPTH_CHUNK(CUR)                                                                           \
+    {                                                                                               \
+        const float* rp = reft + CUR * 256 + lane;                                                  \
+        const float4 rf = make_float4(rp[0], rp[64], rp[128], rp[192]);                             \
+        if (per == 8) PDEPTH_COMPUTE(8, 0)                                                          \
+        else if (per == 4) { if (part == 0) PDEPTH_COMPUTE(4, 0) else PDEPTH_COMPUTE(4, 4) }        \
+        else if (part == 0) PDEPTH_COMPUTE(2, 0)                                                    \
+        else if (part == 1) PDEPTH_COMPUTE(2, 2)                                                    \
+        else if (part == 2) PDEPTH_COMPUTE(2, 4)                                                    \
+        else PDEPTH_COMPUTE(2, 6)                                                                   \
+    }
+                    if (ch & 1) {
+                        constexpr int CUR = 1;
+                        PDEPTH_CHUNK(CUR)
+                    } else {
+                        constexpr int CUR = 0;
+                        PDEPTH_CHUNK(CUR)
                     }
+#undef PDEPTH_CHUNK
+#undef PDEPTH_COMPUTE
+#undef PDEPTH_TAP
+#undef PDEPTH_LOAD
                 }
-                if (ch + 1 < nchunk) commit(cur ^ 1, ch + 1);
-                __syncthreads();
             }
             }  // parts
             // channels beyond C were staged as zeros on both sides: they add (0-0)^2 = 0, except for
@@ -362,7 +391,7 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
         for (int k = pgl; k < a.D; k += NPG) {
             const float lp = (costs[k * 64 + lane] - m) - ls;
             if (o) o[(size_t)k * HW] = lp;
-            e = e + a.d_candi[k] * expf(lp);
+            e = e + dcl[k] * expf(lp);
         }
         if (a.depth_out) {
             red[pgl * 64 + lane] = e;
@@ -373,16 +402,41 @@ __global__ __launch_bounds__(256, 3) void sweep_tiled_kernel(SweepArgs a, int* _
     }
 }
 
+// NCHW -> channel-group-planar [C/4][H][W] float4 (channels beyond C are zero): what the sweep kernel stages
+// with 16-byte LDS-DMA.  One thread per (pixel, channel group); reads are 256-byte and writes 1-KiB wave
+// transactions.
+__global__ __launch_bounds__(256) void pack_c4_kernel(const float* __restrict__ src, long long bstride,
+                                                      long long vstride, int V, int C, int HW,
+                                                      float4* __restrict__ out) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const int g = blockIdx.y, bv = blockIdx.z;
+    const float* s = src + (size_t)(bv / V) * bstride + (size_t)(bv % V) * vstride + (size_t)g * 4 * HW + pix;
+    const int c = g * 4;
+    float4 o;
+    o.x = s[0];
+    o.y = c + 1 < C ? s[HW] : 0.0f;
+    o.z = c + 2 < C ? s[2 * (size_t)HW] : 0.0f;
+    o.w = c + 3 < C ? s[3 * (size_t)HW] : 0.0f;
+    out[((size_t)bv * gridDim.y + g) * HW + pix] = o;
+}
+
 static size_t tiled_lds_bytes(int D) {
-    return (size_t)(NBUF * NTEX_MAX + NBUF * 64) * sizeof(float4) + (size_t)(D + NPG) * 64 * sizeof(float);
+    return (size_t)(NBUF * NTEX_MAX + NBUF * 64) * sizeof(float4) + (size_t)(D + NPG) * 64 * sizeof(float) +
+           (size_t)D * sizeof(float);
 }
 
 // Largest D whose cost tile fits LDS next to the window (2 blocks per CU).
+
+// Largest D whose cost tile fits LDS next to the window buffers (2 blocks per CU).
 int sweep_tiled_max_planes() { return 160; }
 
-size_t sweep_tiled_workspace_bytes(int B, int H, int W) {
+static size_t flag_bytes(int B, int H, int W) {
     const size_t tiles = (size_t)((W + TW - 1) / TW) * ((H + TH - 1) / TH);
     return ((size_t)B * tiles * sizeof(int) + 255) & ~(size_t)255;
+}
+size_t sweep_tiled_workspace_bytes(int B, int V, int C, int H, int W) {
+    return flag_bytes(B, H, W) + (size_t)B * V * ((C + 3) / 4) * H * W * sizeof(float4);
 }
 
 // Launches the tiled kernel, then the gather kernel on the tiles it flagged.
@@ -390,6 +444,12 @@ hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t s
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const int tiles = tiles_x * tiles_y;
     int* flags = reinterpret_cast<int*>(workspace);
+    float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + flag_bytes(a.B, a.H, a.W));
+    {
+        const int HW = a.H * a.W;
+        dim3 pgrid((HW + 255) / 256, (a.C + 3) / 4, a.B * a.V);
+        hipLaunchKernelGGL(pack_c4_kernel, pgrid, dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V, a.C, HW, packed);
+    }
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)a.B * tiles * sizeof(int), stream);
     if (e != hipSuccess) return e;
     const size_t lds = tiled_lds_bytes(a.D);
@@ -397,11 +457,11 @@ hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t s
     if (a.metric == 0) {
         auto kern = sweep_tiled_kernel<0>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, flags, tiles_x);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, packed, flags, tiles_x);
     } else {
         auto kern = sweep_tiled_kernel<1>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, flags, tiles_x);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, packed, flags, tiles_x);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;

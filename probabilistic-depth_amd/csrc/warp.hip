@@ -58,9 +58,11 @@ __global__ __launch_bounds__(256) void sample_coords_kernel(SweepArgs a, float* 
     const float cx = a.cxcy[b * 2 + 0], cy = a.cxcy[b * 2 + 1];
     const float half_w = (float)a.W / 2.0f, half_h = (float)a.H / 2.0f;
     const size_t base = (((size_t)b * a.V + v) * a.D) * HW + pix;
+    const float rcx = refined_rcp(cx), rcy = refined_rcp(cy);
     for (int k = 0; k < a.D; ++k) {
         float ix, iy;
-        plane_sample_pos(xf, t2a, t2b, t2c, a.d_candi[k], cx, cy, half_w, half_h, ix, iy);
+        if (a.fast_div) plane_sample_pos_fast(xf, t2a, t2b, t2c, a.d_candi[k], cx, cy, rcx, rcy, half_w, half_h, ix, iy);
+        else plane_sample_pos(xf, t2a, t2b, t2c, a.d_candi[k], cx, cy, half_w, half_h, ix, iy);
         oix[base + (size_t)k * HW] = ix;
         oiy[base + (size_t)k * HW] = iy;
     }

@@ -77,8 +77,8 @@ def warp_feature(src, K, R, t, rays, cxcy, d_candi, blas=None):
                                 blas_mode=BLAS_MODES[blas])
 
 
-def sample_coords(K, R, t, rays, cxcy, d_candi, H, W, blas=None):
-    return _native.sample_coords(K, R, t, rays, cxcy, d_candi_tensor(d_candi, K.device), H, W,
+def sample_coords(K, R, t, rays, cxcy, d_candi, H, W, blas=None, algo=_native.ALGO_AUTO):
+    return _native.sample_coords(K, R, t, rays, cxcy, d_candi_tensor(d_candi, K.device), H, W, algo=algo,
                                  blas_mode=BLAS_MODES[blas])
 
 

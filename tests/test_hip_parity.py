@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import pdepth_amd  # noqa: F401
-from pdepth_amd import ops, synth
+from pdepth_amd import _native, ops, synth
 from pdepth_amd.utils import img_utils
 from pdepth_amd.warping import homography
 from oracle import ref_cpu as O
@@ -263,6 +263,45 @@ def test_argument_errors(dev):
     ref_t = b["ref"].permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)
     assert not ref_t.is_contiguous()
     assert torch.equal(ops.sweep_cost(ref_t, *args[1:]), ops.sweep_cost(*args))
+
+
+def test_fast_divide_chain_is_bit_identical_to_ieee(dev):
+    """The LDS-tiled kernel computes sample positions with an explicit fma divide chain that shares reciprocals
+    (geometry.hpp, plane_sample_pos_fast); the gather kernel lets the compiler emit IEEE divides.  Both are exposed
+    through pdepth_sample_coords_f32 (algo AUTO / DIRECT) and must agree bit for bit wherever the position is
+    finite and anywhere near the image -- over ordinary, strongly rotated, behind-the-camera and huge-baseline
+    poses, odd principal points and clustered depth candidates (about 10 M positions)."""
+    rng = np.random.default_rng(77)
+    total = 0
+    for case in range(60):
+        H, W = int(rng.integers(8, 90)), int(rng.integers(8, 160))
+        D, V = int(rng.integers(4, 96)), int(rng.integers(1, 4))
+        b = synth.make_batch(900 + case, 1, C=1, D=D, H=H, W=W, V=V, pose=("mono", "stereo", "wide")[case % 3],
+                             cx_off=float(rng.uniform(-3, 3)), cy_off=float(rng.uniform(-2, 2)))
+        kind = case % 5
+        if kind == 1:
+            ang = rng.uniform(-0.4, 0.4)
+            cz, sz = np.cos(ang), np.sin(ang)
+            b["R"][0, 0] = torch.tensor([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], dtype=torch.float32) @ b["R"][0, 0]
+            b["t"][0, 0] = torch.from_numpy(rng.uniform(-3, 3, size=3).astype(np.float32))
+        elif kind == 2:
+            b["t"][0, 0] = torch.from_numpy(rng.uniform(-40, 40, size=3).astype(np.float32))
+        elif kind == 3:
+            b["d_candi"] = rng.uniform(0.3, 80.0, size=D)
+        elif kind == 4:
+            b["t"][0, 0] = torch.from_numpy((rng.uniform(-1, 1, size=3) * 1e-3).astype(np.float32))
+        d = to_dev(b, dev)
+        args = (d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], H, W)
+        fx, fy = ops.sample_coords(*args, algo=_native.ALGO_AUTO)
+        ex, ey = ops.sample_coords(*args, algo=_native.ALGO_DIRECT)
+        near = (ex.abs() < 1e6) & (ey.abs() < 1e6)   # exponent-range corner cases only exist far outside
+        bad = int(((fx != ex) | (fy != ey))[near].sum())
+        assert bad == 0, f"case {case}: {bad} of {int(near.sum())} positions differ between the divide variants"
+        far = ~near
+        # far outside (or NaN): both variants must still classify the sample as out of bounds / NaN alike
+        assert bool(((fx.isnan() | (fx.abs() >= 1e6) | (fy.abs() >= 1e6) | fy.isnan())[far]).all())
+        total += int(near.sum())
+    assert total > 5_000_000
 
 
 def test_fuzz_tiled_against_gather(dev):

@@ -2,7 +2,9 @@
 import csv, glob, os, sys, collections
 root = sys.argv[1]
 def find(pattern):
-    return sorted(glob.glob(os.path.join(root, pattern), recursive=True))
+    # gpurun merges every call's output into the same directory: keep the newest run only
+    fs = sorted(glob.glob(os.path.join(root, pattern), recursive=True), key=os.path.getmtime)
+    return fs[-1:]
 for f in find("trace/**/*kernel_stats.csv"):
     print("== kernel stats:", os.path.relpath(f, root))
     for i, row in enumerate(csv.reader(open(f))):
@@ -14,7 +16,7 @@ for sub in ("pmc1", "pmc2", "pmc3", "pmc4"):
             acc[row["Kernel_Name"][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
         print("== counters:", sub)
         for k, cs in acc.items():
-            if "sweep" not in k and "dpv" not in k: continue
+            if "sweep" not in k and "dpv" not in k and "pack_c4" not in k: continue
             print("  kernel", k)
             for c, v in sorted(cs.items()):
                 print("     %-24s mean/dispatch %.4g  (n=%d)" % (c, sum(v) / len(v), len(v)))
