@@ -80,7 +80,7 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
     a.cost_out = cost; a.logp_out = logp; a.depth_out = depth;
     // the tiled kernel addresses one view through a 32-bit buffer descriptor (C*H*W*4 bytes < 2^31)
     if (d->algo == PDEPTH_ALGO_AUTO && d->D <= pdepth::sweep_tiled_max_planes() &&
-        (long long)((d->C + 3) / 4) * d->H * d->W * 16 < (1ll << 31)) {
+        (long long)((d->C + 3) / 4 + 2) * d->H * d->W * 16 < (1ll << 31)) {
         const size_t need = tiled_ws_bytes(d);
         if (!workspace || workspace_bytes < need)
             return fail(PDEPTH_E_WORKSPACE, "%s: ALGO_AUTO needs %zu bytes of workspace (got %zu); "

@@ -57,18 +57,39 @@ constexpr int NBUF = 2;           // LDS window buffers: chunk ch+1 is in flight
 #define PDEPTH_OCC 3
 #endif
 constexpr int NTEX_MAX = PDEPTH_NTEX;    // window texels per buffer (LDS: NTEX_MAX*NBUF*16 B = 32 KB)
+constexpr int BUF_BYTES = NTEX_MAX * 16;   // one window buffer of the direct groups
+// Band mode (see "band group" in the kernel).  Its windows are small, so the 32 KB of the two direct-mode window
+// buffers (plus nothing else) are re-cut into a ring of BR stages of two channel groups each:
+//     [BR stages][2 chunks][BAND_TEX texels * 16 B]   window ring   (24 KB)
+//     [2 * BR chunks][4 channels][64 pixels] floats   reference ring (8 KB)
+// and, once the channel loop is done, the first 16 KB hold the X exchange buffer (NX_MAX slots of 256 B) while the
+// last stage -- the two Gram planes -- stays in ring slot BR-1.
+constexpr int BR = 4;                       // ring depth in stages (BR-1 stages in flight)
+constexpr int BAND_TEX = 192;               // window texels of a band group
+constexpr int BAND_CHUNK_BYTES = BAND_TEX * 16;
+constexpr int BAND_STAGE_BYTES = 2 * BAND_CHUNK_BYTES;
+constexpr int BAND_REF_OFF = BR * BAND_STAGE_BYTES;   // 24576
+constexpr int NX_MAX = 64;                  // box texels per pixel: X exchange buffer = 16 KB
+constexpr int XPW = NX_MAX / NPG;           // X accumulators per wave
+static_assert(BAND_REF_OFF + 2 * BR * 1024 <= 2 * BUF_BYTES, "band ring must fit the direct-mode window buffers");
+static_assert(NX_MAX * 256 <= (BR - 1) * BAND_STAGE_BYTES, "X exchange buffer must not reach the last ring slot");
 constexpr int SLOTS = (PDEPTH_NTEX + 255) / 256;          // sub-blocks of a window (256 texels each = one DMA pass of the block)
 
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v = min(v, __shfl_xor(v, s));
-    return v;
+// Wave-wide min / max with a scalar result, for fully active waves: four DPP steps make every row of 16 lanes
+// uniform (xor 1, xor 2, mirror within 8, mirror within 16), the four rows are combined on the scalar unit.
+// (__shfl_xor reductions go through the LDS crossbar, 6 dependent ds_bpermute each.)
+#define PDEPTH_DPP_STEP(OP, ctrl) v = OP(v, __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false))
+__device__ __forceinline__ int wave_min_s(int v) {
+    PDEPTH_DPP_STEP(min, 0xB1); PDEPTH_DPP_STEP(min, 0x4E); PDEPTH_DPP_STEP(min, 0x141); PDEPTH_DPP_STEP(min, 0x140);
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v = max(v, __shfl_xor(v, s));
-    return v;
+__device__ __forceinline__ int wave_max_s(int v) {
+    PDEPTH_DPP_STEP(max, 0xB1); PDEPTH_DPP_STEP(max, 0x4E); PDEPTH_DPP_STEP(max, 0x141); PDEPTH_DPP_STEP(max, 0x140);
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
+#undef PDEPTH_DPP_STEP
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -85,6 +106,13 @@ __device__ __forceinline__ void dma_b32(v4i rsrc, unsigned lds_addr, int voff, i
                  :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n in {0, 2, 4, 8} (the immediate must be a constant)
+__device__ __forceinline__ void wait_dma_but(int n) {
+    if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 // raw barrier: every LDS access of this wave has completed, but VMEM (the DMA of later chunks) stays in flight
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -110,7 +138,10 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
     float* costs = reft + NBUF * 256;                     // [D][64]
     float* red = costs + (size_t)a.D * 64;                // [NPG][64]
     float* dcl = red + NPG * 64;                          // [D] depth candidates (read wave-uniformly, per plane)
-    __shared__ int s_bbox[4];
+    float* dlo = dcl + a.D;                               // [D/16 + 1] min of d_candi[16 j .. D)
+    float* dhi = dlo + (a.D / 16 + 1);                    // [D/16 + 1] max of d_candi[16 j .. D)
+    __shared__ int s_bbox[2][NPG][4];  // per-wave bounding boxes of window_of(), double buffered by call parity
+    int bbox_parity = 0;
 
     const int tid = threadIdx.x;
     const int pgl = __builtin_amdgcn_readfirstlane(tid >> 6);  // plane group of this wave (wave-uniform)
@@ -148,6 +179,25 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
     const int nchunk = (a.C + 3) / 4;
     for (int k = tid; k < a.D; k += 256) dcl[k] = a.d_candi[k];
     __syncthreads();
+    {   // suffix min / max of the depth candidates per 16 planes: one wave, 16 lanes per segment
+        const int nseg = a.D / 16 + 1;
+        if (tid < 64) {
+            for (int s0 = 0; s0 < nseg; s0 += 4) {
+                const int seg = s0 + (tid >> 4), k = seg * 16 + (tid & 15);
+                float lo = (seg < nseg && k < a.D) ? dcl[k] : INFINITY, hi = (seg < nseg && k < a.D) ? dcl[k] : -INFINITY;
+#pragma unroll
+                for (int sh = 8; sh >= 1; sh >>= 1) { lo = fminf(lo, __shfl_xor(lo, sh)); hi = fmaxf(hi, __shfl_xor(hi, sh)); }
+                if ((tid & 15) == 0 && seg < nseg) { red[seg] = lo; red[64 + seg] = hi; }  // (red: free scratch here)
+            }
+        }
+        __syncthreads();
+        if (tid < nseg) {
+            float lo = INFINITY, hi = -INFINITY;
+            for (int j = tid; j < nseg; ++j) { lo = fminf(lo, red[j]); hi = fmaxf(hi, red[64 + j]); }
+            dlo[tid] = lo; dhi[tid] = hi;
+        }
+        __syncthreads();
+    }
     const int win_lds0 = (int)lds_addr_of(win);
 
     for (int v = 0; v < a.V; ++v) {
@@ -156,10 +206,52 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
                         a.blas_mode, xf);
         float t2a, t2b, t2c;
         ray_term2(xf, r0, r1, r2, t2a, t2b, t2c);
-        const float4* srcv = packed + ((size_t)b * a.V + v) * nchunk * HW;  // [C/4][H][W] float4 texels
-        const v4i src_rsrc = make_rsrc(srcv, nchunk * HW * 16);
+        // [C/4 + 2][H][W] float4 texels: the channel groups, then the two Gram planes of the band mode
+        const float4* srcv = packed + ((size_t)b * a.V + v) * (nchunk + 2) * HW;
+        const v4i src_rsrc = make_rsrc(srcv, (nchunk + 2) * HW * 16);
 
-        for (int k0 = 0; k0 < a.D; k0 += SG) {
+        // ---- band decision -------------------------------------------------------------------------
+        // Far planes move the sample by a fraction of a texel per plane: the taps of planes [ks, D) of one
+        // pixel all fall into a small box of source texels (a few columns x rows), far fewer texels than
+        // 4 taps x planes.  For those planes the L2 cost is evaluated in its correlation form
+        //     sum_c (sum_t w_t s_t[c] - r[c])^2 = w^T G w - 2 sum_t w_t X_t + |r|^2,
+        // X_t = <r, s_t> accumulated ONCE per (pixel, box texel) over the channels, G = Gram terms of the
+        // source texels (precomputed by the pre-pass, two extra planes of the packed source).  The box of a
+        // pixel is spanned by the positions at the smallest and largest depth of the range (the position
+        // moves monotonically along the epipolar line between them unless the plane through the camera
+        // centre is crossed -- checked), and every footprint is verified against it in the combine step; a
+        // violation hands the tile to the gather kernel.  ks = first multiple of 16 whose box has at most
+        // NX_MAX texels for every pixel of the tile; planes [0, ks) are evaluated directly.  L1 has no such form.
+        int ks = a.D;             // block-uniform: first plane of the band group (D: none)
+        int bbx0 = 0, bby0 = 0;   // per pixel: top-left texel of its box
+        int NC = 0, NR = 0;       // block-uniform box size
+        int gwx0 = 0, gwy0 = 0, gWC = 0, gWR = 0;  // staged window of the band group
+        if (METRIC == 0) {
+            for (int kc = 0; kc < a.D; kc += 16) {
+                const float dl = dlo[kc >> 4], dh = dhi[kc >> 4];
+                float ixl, iyl, ixh, iyh;
+                plane_sample_pos_fast(xf, t2a, t2b, t2c, dl, cx, cy, rcx, rcy, half_w, half_h, ixl, iyl);
+                plane_sample_pos_fast(xf, t2a, t2b, t2c, dh, cx, cy, rcx, rcy, half_w, half_h, ixh, iyh);
+                const float denl = (xf.kt[2] + t2c * dl) + 1e-10f, denh = (xf.kt[2] + t2c * dh) + 1e-10f;
+                const float big = fmaxf(fmaxf(fabsf(ixl), fabsf(iyl)), fmaxf(fabsf(ixh), fabsf(iyh)));
+                const bool ok = denl * denh > 0.0f && big < 1.0e6f;  // false for NaN as well
+                const int x0 = (int)floorf(fminf(ixl, ixh) - 1e-3f), x1 = (int)floorf(fmaxf(ixl, ixh) + 1e-3f) + 1;
+                const int y0 = (int)floorf(fminf(iyl, iyh) - 1e-3f), y1 = (int)floorf(fmaxf(iyl, iyh) + 1e-3f) + 1;
+                if (__builtin_amdgcn_ballot_w64(ok) != ~0ull) continue;  // some pixel crosses the pole / leaves the range
+                const int nc = wave_max_s(x1 - x0 + 1), nr = wave_max_s(y1 - y0 + 1);
+                if (nc * nr > NX_MAX) continue;
+                const int wx0_ = wave_min_s(x0), wy0_ = wave_min_s(y0);
+                const int wc_ = wave_max_s(x0) + nc - wx0_, wr_ = wave_max_s(y0) + nr - wy0_;
+                if (wc_ * wr_ <= BAND_TEX) {
+                    ks = kc; bbx0 = x0; bby0 = y0; NC = nc; NR = nr;
+                    gwx0 = wx0_; gwy0 = wy0_; gWC = wc_; gWR = wr_;
+                    break;
+                }
+            }
+        }
+        const int kend = ks;  // planes [0, kend) are evaluated directly
+
+        for (int k0 = 0; k0 < kend; k0 += SG) {
             // ---- geometry of this thread's KP planes (registers) ----------------------------
             // Plane assignment inside the 32-plane super group: the 8 planes of a wave are split into
             // nsplit parts of per = 8/nsplit planes; part q of wave w holds planes
@@ -174,7 +266,11 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
 #pragma unroll
                 for (int i = 0; i < KP; ++i) {
                     kpl[i] = k0 + ((i >> lper) << (lper + 2)) + (pgl << lper) + (i & ((1 << lper) - 1));
-                    const int k = min(kpl[i], a.D - 1);
+                    if (kpl[i] >= kend) {  // wave-uniform: not a plane of this group
+                        off[i] = INT_MIN; wnw[i] = 0.0f; wne[i] = 0.0f; wsw[i] = 0.0f; wse[i] = 0.0f;
+                        continue;
+                    }
+                    const int k = kpl[i];
                     float ix, iy;
                     plane_sample_pos_fast(xf, t2a, t2b, t2c, dcl[k], cx, cy, rcx, rcy, half_w, half_h, ix, iy);
                     const Footprint f = make_footprint(ix, iy, a.W, a.H);
@@ -209,16 +305,17 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
                         by0 = min(by0, fy0); by1 = max(by1, fy0);
                     }
                 }
-                bx0 = wave_min(bx0); by0 = wave_min(by0); bx1 = wave_max(bx1); by1 = wave_max(by1);
-                __syncthreads();  // every reader of the previous s_bbox / window is done
-                if (tid == 0) { s_bbox[0] = INT_MAX; s_bbox[1] = INT_MAX; s_bbox[2] = INT_MIN; s_bbox[3] = INT_MIN; }
+                bx0 = wave_min_s(bx0); by0 = wave_min_s(by0); bx1 = wave_max_s(bx1); by1 = wave_max_s(by1);
+                // one barrier per call: the slot written now was last read two calls ago, and every wave has
+                // passed the barrier of the previous call since
+                int (*sb)[4] = s_bbox[bbox_parity];
+                bbox_parity ^= 1;
+                if (lane == 0) { sb[pgl][0] = bx0; sb[pgl][1] = by0; sb[pgl][2] = bx1; sb[pgl][3] = by1; }
                 __syncthreads();
-                if (lane == 0) {
-                    atomicMin(&s_bbox[0], bx0); atomicMin(&s_bbox[1], by0);
-                    atomicMax(&s_bbox[2], bx1); atomicMax(&s_bbox[3], by1);
-                }
-                __syncthreads();
-                wx0 = s_bbox[0]; wy0 = s_bbox[1]; wx1 = s_bbox[2]; wy1 = s_bbox[3];
+                wx0 = min(min(sb[0][0], sb[1][0]), min(sb[2][0], sb[3][0]));
+                wy0 = min(min(sb[0][1], sb[1][1]), min(sb[2][1], sb[3][1]));
+                wx1 = max(max(sb[0][2], sb[1][2]), max(sb[2][2], sb[3][2]));
+                wy1 = max(max(sb[0][3], sb[1][3]), max(sb[2][3], sb[3][3]));
                 empty = wx0 > wx1;  // every sample of these planes is fully out of bounds
                 if (empty) { wx0 = 0; wx1 = 0; wy0 = 0; wy1 = 0; }
                 WC = ((wx1 - wx0 + 2) + 15) & ~15;  // +1 east tap, pitch multiple of 16
@@ -227,12 +324,14 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
             };
             // Smallest split into 1, 2 or 4 parts whose windows all fit LDS; the geometry is only redone
             // when the coarser split failed (large disparities per plane, e.g. 512x1024 with D=128).
-            int nsplit = 1;
+            // (a group of only 16 planes starts at nsplit = 2: part 0 is then exactly planes k0 .. k0+15)
+            int nsplit = kend - k0 <= 16 ? 2 : 1;
             for (;;) {
                 geometry(nsplit);
                 const int per = KP / nsplit;
                 bool fits = true;
-                for (int part = 0; part < nsplit && fits; ++part) fits = window_of(part * per, per);
+                for (int part = 0; part < nsplit && fits && k0 + part * NPG * per < kend; ++part)
+                    fits = window_of(part * per, per);
                 if (fits) break;
                 if (nsplit == 4) {  // block-uniform: leave the tile to the gather kernel
                     if (tid == 0) tile_flags[b * ntile + tile] = 1;
@@ -242,7 +341,7 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
             }
             const int per = KP / nsplit;
 
-            for (int part = 0; part < nsplit; ++part) {
+            for (int part = 0; part < nsplit && k0 + part * NPG * per < kend; ++part) {
             if (nsplit > 1) window_of(part * per, per);  // nsplit == 1: the fit check left this window
 #pragma unroll
             for (int i = 0; i < KP; ++i) {
@@ -264,7 +363,9 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
 #pragma unroll
             for (int sl = 0; sl < SLOTS; ++sl) {
                 const int tl = sl * 256 + tid;
-                const int row = tl / WC, col = tl - row * WC;
+                // floor(tl / WC): (tl + 0.5) / WC is at least 0.5 / WC away from an integer, far more than the
+                // rounding error of the product for tl < 4096
+                const int row = (int)(((float)tl + 0.5f) * __builtin_amdgcn_rcpf((float)WC)), col = tl - row * WC;
                 const int gx = wx0 + col, gy = wy0 + row;
                 const bool inb = !empty && row < WR && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;
                 so[sl] = inb ? (gy * a.W + gx) * 16 : 0x7fffffff;
@@ -357,12 +458,141 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
             // NaN-weight samples where they add NaN -- which the reference produces as well.
 #pragma unroll
             for (int i = 0; i < KP; ++i) {
-                if (kpl[i] < a.D) {
+                if (kpl[i] < kend) {
                     float* o = costs + (size_t)kpl[i] * 64 + lane;  // owned by this thread only
                     const float c = acc[i] / a.sigma;
                     *o = (v == 0) ? (0.0f + c) : (*o + c);
                 }
             }
+        }
+
+        // ---- band group: planes [ks, D) in correlation form --------------------------------------------
+        if (ks < a.D) {  // block-uniform
+            typedef const __attribute__((address_space(3))) v4f* lds_v4f;
+            typedef const __attribute__((address_space(3))) float* lds_f;
+            typedef __attribute__((address_space(3))) float* lds_fw;
+            const int NX = NC * NR;
+            const int WCW = gWC * gWR;  // <= BAND_TEX: one DMA instruction of waves 0..2 per chunk
+            const int trow = (int)(((float)tid + 0.5f) * __builtin_amdgcn_rcpf((float)gWC)), tcol = tid - trow * gWC;
+            const int tgx = gwx0 + tcol, tgy = gwy0 + trow;
+            const bool tin = tid < WCW && tgx >= 0 && tgx < a.W && tgy >= 0 && tgy < a.H;
+            const int so = tin ? (tgy * a.W + tgx) * 16 : 0x7fffffff;
+            const bool has_win = pgl * 64 < WCW;  // wave-uniform
+            const int ro = p * 4;
+            // Stage st = packed planes 2 st and 2 st + 1, except the last stage = the two Gram planes.
+            const int gstage = (nchunk + 1) / 2, nstage = gstage + 1;
+            const int shift = (BR - 1) - (nstage - 1) % BR;  // the last stage lands in ring slot BR-1
+            auto stage = [&](int st) {
+                const int q = (st + shift) % BR;
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    const int pl = st == gstage ? nchunk + hlf : 2 * st + hlf;  // packed plane
+                    const bool feat = st < gstage && pl < nchunk;              // a channel group (else Gram / nothing)
+                    if (has_win)
+                        dma_b128(src_rsrc, win_lds0 + q * BAND_STAGE_BYTES + hlf * BAND_CHUNK_BYTES + pgl * 1024,
+                                 (feat || st == gstage) ? so : 0x7fffffff, pl * HW * 16);
+                    const int c = pl * 4 + pgl;
+                    const bool rok = feat && c < a.C;
+                    dma_b32(ref_rsrc, win_lds0 + BAND_REF_OFF + ((2 * st + hlf) % (2 * BR)) * 1024 + pgl * 256,
+                            rok ? ro : 0x7fffffff, rok ? c * HW * 4 : 0);
+                }
+            };
+            const int ndma = has_win ? 4 : 2;  // DMA instructions of this wave per stage
+            // wave w accumulates the box texels j = w, w+4, w+8, ... (row-major in the NC x NR box)
+            const int base = win_lds0 + ((bby0 - gwy0) * gWC + (bbx0 - gwx0)) * 16;  // this pixel's box, ring slot 0, chunk 0
+            int xaddr[XPW];
+            float xacc[XPW];
+            {
+                int jr = 0, jc = pgl;
+#pragma unroll
+                for (int m = 0; m < XPW; ++m) {
+                    while (jc >= NC) { jc -= NC; ++jr; }
+                    xaddr[m] = jr < NR ? base + (jr * gWC + jc) * 16 : base;
+                    xacc[m] = 0.0f;
+                    jc += NPG;
+                }
+            }
+            float rr = 0.0f;  // |r|^2 of this pixel
+            lds_barrier();  // every reader of the previous group is done with the buffers
+            for (int st = 0; st < BR - 1 && st < nstage; ++st) stage(st);
+            for (int st = 0; st < nstage; ++st) {
+                wait_dma_but(ndma * min(BR - 2, nstage - 1 - st));  // stage st has landed, younger ones stay in flight
+                lds_barrier();
+                if (st + BR - 1 < nstage) stage(st + BR - 1);  // into the slot of stage st-1
+                if (st < gstage) {
+                    const int qoff = ((st + shift) % BR) * BAND_STAGE_BYTES;
+                    const float* rp0 = reinterpret_cast<const float*>(win) + BAND_REF_OFF / 4 + ((2 * st) % (2 * BR)) * 256 + lane;
+#pragma unroll
+                    for (int hlf = 0; hlf < 2; ++hlf) {
+                        if (2 * st + hlf < nchunk) {  // uniform
+                            const float* rp = rp0 + hlf * 256;
+                            const float4 rf = make_float4(rp[0], rp[64], rp[128], rp[192]);
+                            rr = __builtin_fmaf(rf.x, rf.x, rr); rr = __builtin_fmaf(rf.y, rf.y, rr);
+                            rr = __builtin_fmaf(rf.z, rf.z, rr); rr = __builtin_fmaf(rf.w, rf.w, rr);
+#pragma unroll
+                            for (int m0 = 0; m0 < XPW; m0 += 4) {
+                                if (pgl + NPG * m0 < NX) {  // uniform: this group of four box texels exists
+                                    v4f t[4];
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u)
+                                        t[u] = *(lds_v4f)(size_t)(unsigned)(xaddr[m0 + u] + qoff + hlf * BAND_CHUNK_BYTES);
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) {
+                                        float x_ = xacc[m0 + u];
+                                        x_ = __builtin_fmaf(t[u].x, rf.x, x_); x_ = __builtin_fmaf(t[u].y, rf.y, x_);
+                                        x_ = __builtin_fmaf(t[u].z, rf.z, x_); x_ = __builtin_fmaf(t[u].w, rf.w, x_);
+                                        xacc[m0 + u] = x_;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            // Every stage has landed (the last wait was vmcnt(0)) and was published by the barrier of the last
+            // iteration, which every wave reached only after its last channel stage: the Gram planes sit in ring
+            // slot BR-1 and the other slots are free for the X exchange buffer (slot j of every pixel at
+            // xb + j*256 + lane*4).
+            const int xb = win_lds0 + lane * 4;
+#pragma unroll
+            for (int m = 0; m < XPW; ++m) {
+                const int j = pgl + NPG * m;
+                if (j < NX) *(lds_fw)(size_t)(unsigned)(xb + j * 256) = xacc[m];
+            }
+            lds_barrier();
+            // combine: wave w takes planes ks + w, ks + w + 4, ...; Gram planes (N, H, V, D1) and (D2, -, -, -)
+            const int g4b = win_lds0 + (BR - 1) * BAND_STAGE_BYTES, g1b = g4b + BAND_CHUNK_BYTES;
+            int viol = 0;
+            for (int k = ks + pgl; k < a.D; k += NPG) {
+                float ix, iy;
+                plane_sample_pos_fast(xf, t2a, t2b, t2c, dcl[k], cx, cy, rcx, rcy, half_w, half_h, ix, iy);
+                const Footprint f = make_footprint(ix, iy, a.W, a.H);
+                float fw = ix - floorf(ix), fe = 1.0f - fw, fn = iy - floorf(iy), fs = 1.0f - fn;
+                int dx = f.x0 - bbx0, dy = f.y0 - bby0;
+                const bool any = f.mask != 0u && live;
+                if (!any) { fw = fw * 0.0f; fe = fe * 0.0f; fn = fn * 0.0f; fs = fs * 0.0f; dx = 0; dy = 0; }
+                if (dx < 0 || dx > NC - 2 || dy < 0 || dy > NR - 2) { viol = 1; dx = 0; dy = 0; }
+                const int slot = dy * NC + dx;
+                const int tex = ((bby0 + dy - gwy0) * gWC + (bbx0 + dx - gwx0)) * 16;
+                auto xat = [&](int j) { return *(lds_f)(size_t)(unsigned)(xb + j * 256); };
+                const float X00 = xat(slot), X01 = xat(slot + 1), X10 = xat(slot + NC), X11 = xat(slot + NC + 1);
+                const v4f G00 = *(lds_v4f)(size_t)(unsigned)(g4b + tex);
+                const v4f G01 = *(lds_v4f)(size_t)(unsigned)(g4b + tex + 16);
+                const v4f G10 = *(lds_v4f)(size_t)(unsigned)(g4b + tex + gWC * 16);
+                const v4f G11 = *(lds_v4f)(size_t)(unsigned)(g4b + tex + gWC * 16 + 16);
+                const float D2 = *(lds_f)(size_t)(unsigned)(g1b + tex);
+                // |sum_t w_t s_t|^2, separable in the x weights (e, w) and the y weights (s, n)
+                const float ee = fe * fe, ww = fw * fw, ew = fe * fw;
+                const float A = ee * G00.x + ww * G01.x + 2.0f * ew * G00.y;   // top row:    N00, N01, H00
+                const float B = ee * G10.x + ww * G11.x + 2.0f * ew * G10.y;   // bottom row: N10, N11, H10
+                const float Cq = ee * G00.z + ww * G01.z + ew * (G00.w + D2);  // cross rows: V00, V01, D1 + D2
+                const float Q = (fs * fs) * A + (fn * fn) * B + 2.0f * (fs * fn) * Cq;
+                const float XW = (fs * fe) * X00 + (fs * fw) * X01 + (fn * fe) * X10 + (fn * fw) * X11;
+                const float c = ((Q - 2.0f * XW) + rr) / a.sigma;
+                float* o = costs + (size_t)k * 64 + lane;
+                *o = (v == 0) ? (0.0f + c) : (*o + c);
+            }
+            if (wave_max_s(viol) != 0 && lane == 0) tile_flags[b * ntile + tile] = 1;  // the gather kernel redoes the tile
         }
     }
     __syncthreads();
@@ -402,28 +632,54 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
     }
 }
 
-// NCHW -> channel-group-planar [C/4][H][W] float4 (channels beyond C are zero): what the sweep kernel stages
-// with 16-byte LDS-DMA.  One thread per (pixel, channel group); reads are 256-byte and writes 1-KiB wave
-// transactions.
+// Pre-pass of every call.  NCHW -> channel-group-planar [C/4 + 2][H][W] float4: plane g < C/4 holds channels
+// 4g .. 4g+3 of every texel (channels beyond C are zero) -- what the sweep kernel stages with 16-byte LDS-DMA --
+// and the last two planes hold the Gram terms of the band mode for texel (x, y), with s(.) = 0 outside the image:
+//     plane C/4     : ( <s(x,y),s(x,y)>, <s(x,y),s(x+1,y)>, <s(x,y),s(x,y+1)>, <s(x,y),s(x+1,y+1)> )
+//     plane C/4 + 1 : ( <s(x+1,y),s(x,y+1)>, 0, 0, 0 )
+// One thread per texel, channels in order (sequential fma: deterministic); the neighbours' loads hit L1/L2.
 __global__ __launch_bounds__(256) void pack_c4_kernel(const float* __restrict__ src, long long bstride,
-                                                      long long vstride, int V, int C, int HW,
+                                                      long long vstride, int V, int C, int H, int W,
                                                       float4* __restrict__ out) {
+    const int HW = H * W;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= HW) return;
-    const int g = blockIdx.y, bv = blockIdx.z;
-    const float* s = src + (size_t)(bv / V) * bstride + (size_t)(bv % V) * vstride + (size_t)g * 4 * HW + pix;
-    const int c = g * 4;
-    float4 o;
-    o.x = s[0];
-    o.y = c + 1 < C ? s[HW] : 0.0f;
-    o.z = c + 2 < C ? s[2 * (size_t)HW] : 0.0f;
-    o.w = c + 3 < C ? s[3 * (size_t)HW] : 0.0f;
-    out[((size_t)bv * gridDim.y + g) * HW + pix] = o;
+    const int bv = blockIdx.y;
+    const int y = pix / W, x = pix - y * W;
+    const bool hr = x + 1 < W, hd = y + 1 < H;
+    const float* s = src + (size_t)(bv / V) * bstride + (size_t)(bv % V) * vstride + pix;
+    const int ngrp = (C + 3) / 4;
+    float4* o = out + (size_t)bv * (ngrp + 2) * HW + pix;
+    float n = 0.f, h = 0.f, vv = 0.f, d1 = 0.f, d2 = 0.f;
+    for (int g = 0; g < ngrp; ++g) {
+        float c4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = g * 4 + j;
+            float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
+            if (c < C) {  // uniform
+                const float* sc = s + (size_t)c * HW;
+                s00 = sc[0];
+                s01 = hr ? sc[1] : 0.f;
+                s10 = hd ? sc[W] : 0.f;
+                s11 = hr && hd ? sc[W + 1] : 0.f;
+            }
+            c4[j] = s00;
+            n = __builtin_fmaf(s00, s00, n);
+            h = __builtin_fmaf(s00, s01, h);
+            vv = __builtin_fmaf(s00, s10, vv);
+            d1 = __builtin_fmaf(s00, s11, d1);
+            d2 = __builtin_fmaf(s01, s10, d2);
+        }
+        o[(size_t)g * HW] = make_float4(c4[0], c4[1], c4[2], c4[3]);
+    }
+    o[(size_t)ngrp * HW] = make_float4(n, h, vv, d1);
+    o[(size_t)(ngrp + 1) * HW] = make_float4(d2, 0.f, 0.f, 0.f);
 }
 
 static size_t tiled_lds_bytes(int D) {
     return (size_t)(NBUF * NTEX_MAX + NBUF * 64) * sizeof(float4) + (size_t)(D + NPG) * 64 * sizeof(float) +
-           (size_t)D * sizeof(float);
+           (size_t)(D + 2 * (D / 16 + 1)) * sizeof(float);
 }
 
 // Largest D whose cost tile fits LDS next to the window (2 blocks per CU).
@@ -436,7 +692,7 @@ static size_t flag_bytes(int B, int H, int W) {
     return ((size_t)B * tiles * sizeof(int) + 255) & ~(size_t)255;
 }
 size_t sweep_tiled_workspace_bytes(int B, int V, int C, int H, int W) {
-    return flag_bytes(B, H, W) + (size_t)B * V * ((C + 3) / 4) * H * W * sizeof(float4);
+    return flag_bytes(B, H, W) + (size_t)B * V * ((C + 3) / 4 + 2) * H * W * sizeof(float4);
 }
 
 // Launches the tiled kernel, then the gather kernel on the tiles it flagged.
@@ -447,8 +703,8 @@ hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t s
     float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + flag_bytes(a.B, a.H, a.W));
     {
         const int HW = a.H * a.W;
-        dim3 pgrid((HW + 255) / 256, (a.C + 3) / 4, a.B * a.V);
-        hipLaunchKernelGGL(pack_c4_kernel, pgrid, dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V, a.C, HW, packed);
+        dim3 pgrid((HW + 255) / 256, a.B * a.V);
+        hipLaunchKernelGGL(pack_c4_kernel, pgrid, dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V, a.C, a.H, a.W, packed);
     }
     hipError_t e = hipMemsetAsync(flags, 0, (size_t)a.B * tiles * sizeof(int), stream);
     if (e != hipSuccess) return e;
