@@ -566,12 +566,16 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
             for (int k = ks + pgl; k < a.D; k += NPG) {
                 float ix, iy;
                 plane_sample_pos_fast(xf, t2a, t2b, t2c, dcl[k], cx, cy, rcx, rcy, half_w, half_h, ix, iy);
-                const Footprint f = make_footprint(ix, iy, a.W, a.H);
-                float fw = ix - floorf(ix), fe = 1.0f - fw, fn = iy - floorf(iy), fs = 1.0f - fn;
-                int dx = f.x0 - bbx0, dy = f.y0 - bby0;
-                const bool any = f.mask != 0u && live;
+                // footprint as in make_footprint(); "any tap inside the image" <=> x0 in [-1, W-1] and y0 in [-1, H-1]
+                const float xfl = floorf(ix), yfl = floorf(iy);
+                float fw = ix - xfl, fe = 1.0f - fw, fn = iy - yfl, fs = 1.0f - fn;
+                const int fx0 = (int)fminf(fmaxf(xfl, -2.0f), (float)(a.W + 1));
+                const int fy0 = (int)fminf(fmaxf(yfl, -2.0f), (float)(a.H + 1));
+                int dx = fx0 - bbx0, dy = fy0 - bby0;
+                const bool any = live && ix == ix && iy == iy && (unsigned)(fx0 + 1) < (unsigned)(a.W + 1) &&
+                                 (unsigned)(fy0 + 1) < (unsigned)(a.H + 1);
                 if (!any) { fw = fw * 0.0f; fe = fe * 0.0f; fn = fn * 0.0f; fs = fs * 0.0f; dx = 0; dy = 0; }
-                if (dx < 0 || dx > NC - 2 || dy < 0 || dy > NR - 2) { viol = 1; dx = 0; dy = 0; }
+                if ((unsigned)dx > (unsigned)(NC - 2) || (unsigned)dy > (unsigned)(NR - 2)) { viol = 1; dx = 0; dy = 0; }
                 const int slot = dy * NC + dx;
                 const int tex = ((bby0 + dy - gwy0) * gWC + (bbx0 + dx - gwx0)) * 16;
                 auto xat = [&](int j) { return *(lds_f)(size_t)(unsigned)(xb + j * 256); };
