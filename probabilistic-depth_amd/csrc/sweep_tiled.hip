@@ -1,41 +1,46 @@
 // LDS-tiled plane sweep: the fast path of pdepth_sweep_{cost,dpv}_f32.
 //
-// Same bit-faithful sample positions and bilinear weights as sweep_direct.hip, but the taps come from
-// LDS instead of global memory and the per-channel arithmetic is folded into five fma-class ops.
+// Same bit-faithful sample positions and bilinear weights as sweep_direct.hip, but the source comes from LDS
+// instead of global memory, and the planes of a tile are evaluated in one of two forms:
 //
-//   block   = 16x4 reference pixels x 4 plane groups = 256 threads.  Wave w of the block owns the
-//             same 64 pixels (lane = 16 wide x 4 tall) and plane group w: KP = 8 consecutive depth
-//             planes of the current "super group" of 4*KP = 32 planes.  The per-plane geometry of a
-//             thread (tap offset into the LDS window + 4 bilinear weights, 8 planes) lives in
-//             registers and is computed ONCE per (pixel, plane, view);
-//   source  = a pre-pass (pack_c4_kernel, HBM-rate) re-lays every source view from NCHW to channel-group-
-//             planar [C/4][H][W] float4 texels in the workspace, zero padded to a multiple of 4 channels;
-//   window  = bounding box of every tap the block touches in the current super group, staged four
-//             channels at a time into LDS as float4 texels [row][col] by LDS-DMA (buffer_load_dwordx4 ...
-//             lds: a wave-instruction moves 64 texels = 1 KiB, no registers, no ds_write), double
-//             buffered: chunk ch+1 is in flight while chunk ch is computed; one barrier per chunk.  The
-//             DMA is issued from inline asm with hand-counted s_waitcnt, because the compiler would
+//   DIRECT groups (near planes, which move the sample by texels per plane): per (pixel, plane, channel) four taps
+//   and five fma-class ops, diff = fma(s00,nw,-r) ... fma(s11,se,.), acc = fma(diff,diff,acc);
+//
+//   the BAND group (all planes from ks on, which move the sample by a fraction of a texel per plane; L2 only):
+//   the taps of all those planes of one pixel fall into a box of at most 64 source texels, and
+//       sum_c (sum_t w_t s_t[c] - r[c])^2 = w^T G w - 2 sum_t w_t X_t + |r|^2
+//   needs the channel loop only for X_t = <r, s_t>, ONE dot product per (pixel, box texel) instead of one
+//   interpolation per (pixel, plane); G (Gram terms of neighbouring source texels) comes from the pre-pass.
+//   On the benchmark poses 40..64 of the 64 planes are band planes and a pixel's box has ~30 texels (against
+//   160..256 taps): ~2x fewer VALU and LDS instructions per tile than direct evaluation of everything.
+//
+//   block   = 16x4 reference pixels x 4 waves = 256 threads; every wave holds the same 64 pixels (lane = pixel).
+//             Direct group: wave w owns KP = 8 (or 4, 2) consecutive planes of a group of 32 (16, 8); their
+//             geometry (LDS tap address + 4 weights) lives in registers, computed once per (pixel, plane, view).
+//             Band group: wave w accumulates box texels w, w+4, ... (X in registers), the waves exchange X
+//             through LDS, then wave w combines planes ks+w, ks+w+4, ... (geometry recomputed on the fly);
+//   source  = a pre-pass (pack_c4_kernel) re-lays every source view from NCHW to channel-group-planar
+//             [C/4 + 2][H][W] float4 texels in the workspace: C/4 planes of 4 channels (zero padded), then the
+//             two Gram planes;
+//   window  = bounding box of every texel the block touches in the current group, staged four channels at a
+//             time into LDS as float4 texels [row][col] by LDS-DMA (buffer_load_dwordx4 ... lds: a
+//             wave-instruction moves 64 texels = 1 KiB, no registers, no ds_write).  Direct groups: two 16 KB
+//             buffers, chunk ch+1 in flight while chunk ch is computed, one barrier per chunk.  Band group
+//             (small windows): the same 32 KB as a ring of 4 stages of two chunks each, three stages in flight.
+//             The DMA is issued from inline asm with hand-counted s_waitcnt, because the compiler would
 //             otherwise drain it in front of every ds_read.  Texels outside the image are fetched with an
-//             out-of-range buffer offset and arrive as zeros, which IS padding_mode='zeros' -- no per-tap
-//             masks in the inner loop.  The row pitch is a multiple of 16 texels;
-//   taps    = software pipelined over the wave's planes: the four ds_read_b128 of plane i+1 are in flight
-//             while the 20 fma of plane i execute; the window buffer is an immediate of the ds_read;
+//             out-of-range buffer offset and arrive as zeros, which IS padding_mode='zeros';
+//   taps    = (direct) software pipelined over the wave's planes: the four ds_read_b128 of plane i+1 are in
+//             flight while the 20 fma of plane i execute; the window buffer is an immediate of the ds_read;
 //   ref     = the tile's reference features of the chunk (wave w moves channel 4*ch+w by LDS-DMA from NCHW);
-//   sum     = five VALU ops per (pixel, plane, channel): the reference feature enters the bilinear fma
-//             chain as its initial addend (diff = fma(s00,nw,-r) ... fma(s11,se,.)) and the square is
-//             accumulated with one fma.  The reference rounds the interpolated value and the square
-//             separately (7 ops); the difference is ~1e-7 relative per term, two orders below the
-//             parity tolerance (the gather kernel of sweep_direct.hip keeps the reference's op order);
-//   costs   = cost[k][pixel] of the tile in LDS (D x 64 floats), accumulated over views in view
-//             order like homography.py:129; the fused epilogue (log_softmax over D + E[d]) runs on
-//             those with the 4 waves splitting the planes, so nothing but the requested outputs is
-//             ever written to HBM.
+//   costs   = cost[k][pixel] of the tile in LDS (D x 64 floats), accumulated over views in view order like
+//             homography.py:129; the fused epilogue (log_softmax over D + E[d]) runs on those with the 4 waves
+//             splitting the planes, so nothing but the requested outputs is ever written to HBM.
 //
-// Consecutive planes hit neighbouring texels, so a super group's window is only a few texels larger
-// than the tile and each source texel is staged from L2 a handful of times per chunk instead of being
-// gathered 4 x D times.  A block whose window does not fit (extreme poses) raises its tile flag and
-// leaves the tile to the gather kernel of sweep_direct.hip; a window that is merely too large is first
-// split into 2 or 4 parts of consecutive planes.  Both kernels agree to rounding (~1e-7 relative per term).
+// A block whose direct window does not fit (extreme poses) first splits the group into 2 or 4 parts of
+// consecutive planes, then raises its tile flag and leaves the tile to the gather kernel of sweep_direct.hip; so
+// does a band group whose box assumption is violated (never observed).  The three evaluations agree to rounding:
+// ~3e-7 (direct) and ~5e-7 (band) of the largest cost of the volume, i.e. an ulp or two of the fp32 cost.
 #include <hip/hip_runtime.h>
 
 #include "geometry.hpp"
@@ -646,7 +651,11 @@ __global__ __launch_bounds__(256) void pack_c4_kernel(const float* __restrict__ 
                                                       long long vstride, int V, int C, int H, int W,
                                                       float4* __restrict__ out) {
     const int HW = H * W;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
+    // XCD-aware block order (workgroups are dealt round-robin over the 8 XCDs): every XCD packs one contiguous band
+    // of rows, so the row below -- which another block of the same band loads as its own row -- hits that XCD's L2
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, qq = nb >> 3, rr = nb & 7;
+    const int blk = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+    const int pix = blk * 256 + threadIdx.x;
     if (pix >= HW) return;
     const int bv = blockIdx.y;
     const int y = pix / W, x = pix - y * W;

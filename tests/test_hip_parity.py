@@ -304,6 +304,22 @@ def test_fast_divide_chain_is_bit_identical_to_ieee(dev):
     assert total > 5_000_000
 
 
+@pytest.mark.parametrize("pose", ["mono", "stereo"])
+def test_band_mode_agrees_with_gather_to_an_ulp_of_the_cost(dev, pose):
+    """The tiled kernel evaluates far planes in correlation form (w^T G w - 2 w.X + |r|^2).  Its costs must agree
+    with the gather kernel (reference op order) to an ulp or two of the largest cost of the volume, whatever the
+    feature magnitude -- i.e. it adds no error beyond what re-ordering an fp32 sum adds anyway."""
+    for scale in (1.0, 4.0, 16.0):
+        b = synth.make_batch(5, 1, C=67, D=64, H=64, W=128, V=1, pose=pose, peaked=True)
+        d = to_dev(b, dev)
+        args = (d["ref"] * scale, d["src"] * scale, d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0)
+        ca = ops.sweep_cost(*args, algo="auto")
+        cd = ops.sweep_cost(*args, algo="direct")
+        rel = float((ca - cd).abs().max() / cd.abs().max())
+        assert rel < 2e-6, f"scale {scale}: tiled vs gather differ by {rel:.2e} of the largest cost"
+    assert _native.fallback_tiles(1, 64, 128) == 0
+
+
 def test_fuzz_tiled_against_gather(dev):
     """Random shapes / poses / intrinsics: the LDS-tiled kernel (with window splitting and per-tile fallback)
     must agree with the gather kernel, which evaluates every pixel independently in the reference's op order.
