@@ -649,8 +649,11 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
 // One thread per texel, channels in order (sequential fma: deterministic); the neighbours' loads hit L1/L2.
 __global__ __launch_bounds__(256) void pack_c4_kernel(const float* __restrict__ src, long long bstride,
                                                       long long vstride, int V, int C, int H, int W,
-                                                      float4* __restrict__ out) {
+                                                      float4* __restrict__ out, int* __restrict__ flags, int nflags) {
     const int HW = H * W;
+    // also clears the tile flags of this call (saves a memset launch)
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < nflags; i += gridDim.x * gridDim.y * 256)
+        flags[i] = 0;
     // XCD-aware block order (workgroups are dealt round-robin over the 8 XCDs): every XCD packs one contiguous band
     // of rows, so the row below -- which another block of the same band loads as its own row -- hits that XCD's L2
     const int nb = gridDim.x, xcd = blockIdx.x & 7, qq = nb >> 3, rr = nb & 7;
@@ -717,9 +720,10 @@ hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t s
     {
         const int HW = a.H * a.W;
         dim3 pgrid((HW + 255) / 256, a.B * a.V);
-        hipLaunchKernelGGL(pack_c4_kernel, pgrid, dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V, a.C, a.H, a.W, packed);
+        hipLaunchKernelGGL(pack_c4_kernel, pgrid, dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V, a.C, a.H, a.W, packed,
+                           flags, a.B * tiles);
     }
-    hipError_t e = hipMemsetAsync(flags, 0, (size_t)a.B * tiles * sizeof(int), stream);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t lds = tiled_lds_bytes(a.D);
     dim3 grid(tiles, a.B);
