@@ -134,6 +134,17 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 
 }  // namespace
 
+// A kernel argument that is used once or twice per tile and would otherwise occupy scalar registers for the whole
+// kernel (which already spills SGPRs into VGPR lanes): re-read it from the kernarg segment at the point of use.
+// `a` is the first kernel argument, so field offsets are offsets into the segment.
+template <typename T>
+__device__ __forceinline__ T cold_arg(size_t offset) {
+    typedef const char __attribute__((address_space(4))) * kptr;
+    typedef const volatile T __attribute__((address_space(4))) * vptr;
+    return *(vptr)((kptr)__builtin_amdgcn_kernarg_segment_ptr() + offset);
+}
+#define PDEPTH_COLD_ARG(type, field) cold_arg<type>(offsetof(SweepArgs, field))
+
 template <int METRIC>
 __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a, const float4* __restrict__ packed,
                                                               int* __restrict__ tile_flags, int tiles_x) {
@@ -207,8 +218,8 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
 
     for (int v = 0; v < a.V; ++v) {
         ViewXform xf;
-        make_view_xform(a.K + b * 9, a.R + ((size_t)b * a.V + v) * 9, a.t + ((size_t)b * a.V + v) * 3,
-                        a.blas_mode, xf);
+        make_view_xform(PDEPTH_COLD_ARG(const float*, K) + b * 9, PDEPTH_COLD_ARG(const float*, R) + ((size_t)b * a.V + v) * 9,
+                        PDEPTH_COLD_ARG(const float*, t) + ((size_t)b * a.V + v) * 3, a.blas_mode, xf);
         float t2a, t2b, t2c;
         ray_term2(xf, r0, r1, r2, t2a, t2b, t2c);
         // [C/4 + 2][H][W] float4 texels: the channel groups, then the two Gram planes of the band mode
@@ -608,10 +619,13 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
 
     // ---- epilogue from LDS: cost store, log-softmax over D, expectation ----------------------
     // wave w handles planes k = w, w+4, w+8, ... of the tile's 64 pixels
-    float* cout = (a.cost_out && live) ? a.cost_out + (size_t)b * a.D * HW + p : nullptr;
+    float* const cost_out = PDEPTH_COLD_ARG(float*, cost_out);
+    float* const logp_out = PDEPTH_COLD_ARG(float*, logp_out);
+    float* const depth_out = PDEPTH_COLD_ARG(float*, depth_out);
+    float* cout = (cost_out && live) ? cost_out + (size_t)b * a.D * HW + p : nullptr;
     if (cout)
         for (int k = pgl; k < a.D; k += NPG) cout[(size_t)k * HW] = costs[k * 64 + lane];
-    if (a.logp_out || a.depth_out) {
+    if (logp_out || depth_out) {
         float m = -INFINITY;
         for (int k = pgl; k < a.D; k += NPG) m = fmaxf(m, costs[k * 64 + lane]);
         red[pgl * 64 + lane] = m;
@@ -626,17 +640,17 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
         __syncthreads();
         const float ls = logf(s);
         float e = 0.0f;
-        float* o = (a.logp_out && live) ? a.logp_out + (size_t)b * a.D * HW + p : nullptr;
+        float* o = (logp_out && live) ? logp_out + (size_t)b * a.D * HW + p : nullptr;
         for (int k = pgl; k < a.D; k += NPG) {
             const float lp = (costs[k * 64 + lane] - m) - ls;
             if (o) o[(size_t)k * HW] = lp;
             e = e + dcl[k] * expf(lp);
         }
-        if (a.depth_out) {
+        if (depth_out) {
             red[pgl * 64 + lane] = e;
             __syncthreads();
             if (pgl == 0 && live)
-                a.depth_out[(size_t)b * HW + p] = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+                depth_out[(size_t)b * HW + p] = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
         }
     }
 }
