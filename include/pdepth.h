@@ -138,6 +138,14 @@ int pdepth_dpv_expect_f32(const float *dpv, const float *d_candi, int32_t B, int
                           int32_t H, int32_t W, int32_t bv_log, float *depth, void *stream);
 
 /*
+ * Mean and variance of the depth distribution: z = bv_log ? exp(dpv) : dpv, mean = sum_k d_k z_k,
+ * variance[b,y,x] = sum_k (d_k - mean)^2 z_k.  Replaces the per-item torch ops of the evaluation loop
+ * (trainer/default_trainer.py:333-336), batched over B.  mean may be NULL.
+ */
+int pdepth_dpv_moments_f32(const float *dpv, const float *d_candi, int32_t B, int32_t D,
+                           int32_t H, int32_t W, int32_t bv_log, float *mean, float *variance, void *stream);
+
+/*
  * Diagonal feature warp: out[b,v,i,y,x] = bilinear(src[b,v,i,:,:]) sampled with the
  * plane-i homography of view v.  Replaces warp_feature (warping/homography.py:137-168),
  * which warps all D x C planes and keeps [i,i]; requires C == D.

@@ -182,6 +182,19 @@ def dpv_to_depthmap(dpv, d_candi, BV_log=False):
     return torch.sum(d * z, dim=0).unsqueeze(0)
 
 
+def dpv_variance(dpv_log, d_candi):
+    """Mean and variance of the depth distribution of a [1,D,H,W] log-DPV -> ([H,W], [H,W]).
+
+    trainer/default_trainer.py:333-336 (evaluation loop, inline): z = exp(logDPV.squeeze(0)),
+    mean = sum(d * z, 0), variance = sum((d - mean)**2 * z, 0).  Restated op for op; the reference has no callable
+    for it, so this restatement is pinned by inspection only."""
+    z = torch.exp(dpv_log.squeeze(0))
+    d = torch.tensor(d_candi).unsqueeze(1).unsqueeze(1).float()
+    mean = torch.sum(d * z, dim=0)
+    variance = torch.sum(((d - mean) ** 2) * z, dim=0)
+    return mean, variance
+
+
 def sweep_dpv(feat_ref, feat_src, d_candi, R, t, K, rays, cx, cy, sigma, metric="L2"):
     """cost -> log-DPV -> depth for one item (the PackNet-style fusable chain).
 

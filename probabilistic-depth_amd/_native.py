@@ -25,6 +25,7 @@ EXPORTED_SYMBOLS = (
     "pdepth_sweep_cost_f32", "pdepth_sweep_dpv_f32", "pdepth_dpv_reduce_f32",
     "pdepth_dpv_expect_f32", "pdepth_warp_feature_f32", "pdepth_sample_coords_f32",
     "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32", "pdepth_inverse_warp_f32",
+    "pdepth_dpv_moments_f32",
 )
 
 
@@ -100,6 +101,8 @@ def load():
                                           c_void_p, c_void_p]
     lib.pdepth_dpv_expect_f32.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                           c_void_p, c_void_p]
+    lib.pdepth_dpv_moments_f32.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                           c_void_p, c_void_p, c_void_p]
     lib.pdepth_warp_feature_f32.argtypes = [POINTER(SweepDesc), POINTER(Camera), c_void_p, c_void_p, c_void_p,
                                             c_void_p]
     lib.pdepth_sample_coords_f32.argtypes = [POINTER(SweepDesc), POINTER(Camera), c_void_p, c_void_p, c_void_p,
@@ -110,7 +113,8 @@ def load():
     lib.pdepth_inverse_warp_f32.argtypes = [c_void_p] * 4 + [c_int32] * 4 + [c_void_p] * 3
     for fn in ("pdepth_sweep_cost_f32", "pdepth_sweep_dpv_f32", "pdepth_dpv_reduce_f32",
                "pdepth_dpv_expect_f32", "pdepth_warp_feature_f32", "pdepth_sample_coords_f32",
-               "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32", "pdepth_inverse_warp_f32"):
+               "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32", "pdepth_inverse_warp_f32",
+               "pdepth_dpv_moments_f32"):
         getattr(lib, fn).restype = c_int
     if lib.pdepth_abi_version() != 1:
         raise RuntimeError("libpdepth_hip.so ABI version mismatch")
@@ -257,6 +261,26 @@ def dpv_expect(dpv, d_candi, bv_log):
                                        depth.data_ptr(), _stream(dpv.device))
     _check(rc, lib)
     return depth
+
+
+def dpv_moments(dpv, d_candi, bv_log=True):
+    """dpv [B,D,H,W] -> (mean [B,H,W], variance [B,H,W]) of the depth distribution."""
+    lib = load()
+    _dev(dpv, "dpv")
+    if dpv.dim() != 4:
+        raise RuntimeError("dpv_moments: dpv must be [B,D,H,W]")
+    dpv = dpv.contiguous()
+    B, D, H, W = dpv.shape
+    d_candi = d_candi.contiguous()
+    if d_candi.numel() != D:
+        raise RuntimeError(f"dpv_moments: d_candi has {d_candi.numel()} entries, volume has D={D}")
+    mean = torch.empty((B, H, W), dtype=torch.float32, device=dpv.device)
+    var = torch.empty_like(mean)
+    with torch.cuda.device(dpv.device):
+        rc = lib.pdepth_dpv_moments_f32(_dev(dpv, "dpv"), _dev(d_candi, "d_candi"), B, D, H, W, int(bool(bv_log)),
+                                        mean.data_ptr(), var.data_ptr(), _stream(dpv.device))
+    _check(rc, lib)
+    return mean, var
 
 
 def warp_feature(src, K, R, t, rays, cxcy, d_candi, blas_mode=None):

@@ -139,6 +139,15 @@ int pdepth_dpv_expect_f32(const float* dpv, const float* d_candi, int32_t B, int
                                               (hipStream_t)stream), "pdepth_dpv_expect_f32");
 }
 
+int pdepth_dpv_moments_f32(const float* dpv, const float* d_candi, int32_t B, int32_t D, int32_t H,
+                           int32_t W, int32_t bv_log, float* mean, float* variance, void* stream) {
+    if (!dpv || !d_candi || !variance) return fail(PDEPTH_E_ARG, "pdepth_dpv_moments_f32: null pointer");
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0)
+        return fail(PDEPTH_E_ARG, "pdepth_dpv_moments_f32: non-positive dimension");
+    return launched(pdepth::launch_dpv_moments(dpv, d_candi, B, D, H, W, bv_log, mean, variance,
+                                               (hipStream_t)stream), "pdepth_dpv_moments_f32");
+}
+
 int pdepth_warp_feature_f32(const pdepth_sweep_desc* desc, const pdepth_camera* cam, const float* src,
                             const float* d_candi, float* out, void* stream) {
     if (int rc = check_desc(desc, cam, "pdepth_warp_feature_f32")) return rc;

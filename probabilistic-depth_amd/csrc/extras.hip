@@ -54,6 +54,38 @@ __global__ __launch_bounds__(256) void dpv_fuse_kernel(const float* __restrict__
     }
 }
 
+// Mean and variance of the depth distribution per pixel (trainer/default_trainer.py:333-336):
+//   z = exp(logDPV), mean = sum_k d_k z_k, variance = sum_k (d_k - mean)^2 z_k.
+// Two sweeps over the column like the reference (the second one re-reads from L2).
+__global__ __launch_bounds__(256) void dpv_moments_kernel(const float* __restrict__ dpv, const float* __restrict__ dc,
+                                                          int D, int HW, int bv_log, float* __restrict__ mean,
+                                                          float* __restrict__ var) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const int b = blockIdx.y;
+    const float* x = dpv + (size_t)b * D * HW + pix;
+    float m = 0.0f;
+    for (int k = 0; k < D; ++k) {
+        const float z = bv_log ? expf(x[(size_t)k * HW]) : x[(size_t)k * HW];
+        m += dc[k] * z;
+    }
+    float s = 0.0f;
+    for (int k = 0; k < D; ++k) {
+        const float z = bv_log ? expf(x[(size_t)k * HW]) : x[(size_t)k * HW];
+        const float e = dc[k] - m;
+        s += (e * e) * z;
+    }
+    if (mean) mean[(size_t)b * HW + pix] = m;
+    var[(size_t)b * HW + pix] = s;
+}
+
+hipError_t launch_dpv_moments(const float* dpv, const float* d_candi, int B, int D, int H, int W, int bv_log,
+                              float* mean, float* var, hipStream_t stream) {
+    dim3 grid((H * W + 255) / 256, B);
+    hipLaunchKernelGGL(dpv_moments_kernel, grid, dim3(256), 0, stream, dpv, d_candi, D, H * W, bv_log, mean, var);
+    return hipGetLastError();
+}
+
 hipError_t launch_dpv_fuse(const float* logp, const float* dmaps, const float* masks, const float* d_candi,
                            int B, int D, int H, int W, float var, float eps, float* fused, float* logfused,
                            hipStream_t stream) {

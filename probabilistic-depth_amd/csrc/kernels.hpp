@@ -50,6 +50,8 @@ hipError_t launch_warp_feature(const SweepArgs& a, float* out, hipStream_t strea
 hipError_t launch_sample_coords(const SweepArgs& a, float* ix, float* iy, hipStream_t stream);
 
 // extras.hip
+hipError_t launch_dpv_moments(const float* dpv, const float* d_candi, int B, int D, int H, int W, int bv_log,
+                              float* mean, float* var, hipStream_t stream);
 hipError_t launch_dpv_fuse(const float* logp, const float* dmaps, const float* masks, const float* d_candi,
                            int B, int D, int H, int W, float var, float eps, float* fused, float* logfused,
                            hipStream_t stream);

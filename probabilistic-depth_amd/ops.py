@@ -71,6 +71,11 @@ def dpv_expect(dpv, d_candi, BV_log=False):
     return _native.dpv_expect(dpv, d_candi_tensor(d_candi, dpv.device), BV_log)
 
 
+def dpv_moments(dpv, d_candi, BV_log=True):
+    """(mean, variance) [B,H,W] of the depth distribution of a (log-)DPV (trainer/default_trainer.py:333-336)."""
+    return _native.dpv_moments(dpv, d_candi_tensor(d_candi, dpv.device), BV_log)
+
+
 def warp_feature(src, K, R, t, rays, cxcy, d_candi, blas=None):
     """[B,V,D,H,W] diagonal warp (warping/homography.py:137-168, batched)."""
     return _native.warp_feature(src, K, R, t, rays, cxcy, d_candi_tensor(d_candi, src.device),

@@ -90,3 +90,44 @@ def test_hip_inverse_warp():
         iw.inverse_warp(img, dep, torch.from_numpy(g["pose44"]).to(dev), K, padding_mode="border")
     with pytest.raises(AssertionError, match="wrong size for depth"):
         iw.inverse_warp(img, dep[:, None], torch.from_numpy(g["pose44"]).to(dev), K)
+
+
+def test_oracle_dpv_variance_properties():
+    """The variance restatement (trainer/default_trainer.py:333-336) has no reference callable to pin it; check it
+    against a float64 evaluation of the same formula and against the two limiting cases."""
+    rng = np.random.default_rng(3)
+    d = np.linspace(5.0, 40.0, 16)
+    logits = torch.from_numpy(rng.normal(size=(1, 16, 5, 7)).astype(np.float32) * 3)
+    logp = torch.log_softmax(logits, dim=1)
+    mean, var = O.dpv_variance(logp, d)
+    z = np.exp(logp[0].numpy().astype(np.float64))
+    m64 = (d[:, None, None] * z).sum(0)
+    v64 = (((d[:, None, None] - m64) ** 2) * z).sum(0)
+    np.testing.assert_allclose(mean.numpy(), m64, rtol=1e-5)
+    np.testing.assert_allclose(var.numpy(), v64, rtol=1e-4, atol=1e-4)
+    onehot = torch.full((1, 16, 2, 2), -1e4)
+    onehot[0, 5] = 0.0
+    m1, v1 = O.dpv_variance(onehot, d)
+    assert np.allclose(m1.numpy(), d[5]) and np.allclose(v1.numpy(), 0.0, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_dpv_moments():
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(4)
+    for (B, D, H, W) in ((2, 64, 33, 47), (1, 16, 8, 8), (3, 7, 5, 130)):
+        d = np.sort(rng.uniform(3.0, 60.0, size=D))
+        logits = torch.from_numpy(rng.normal(size=(B, D, H, W)).astype(np.float32) * 4)
+        logp = torch.log_softmax(logits, dim=1)
+        mean, var = ops.dpv_moments(logp.to(dev), d, BV_log=True)
+        for b in range(B):
+            om, ov = O.dpv_variance(logp[b:b + 1], d)
+            assert float((mean[b].cpu() - om).abs().max()) < 1e-4
+            assert float(((var[b].cpu() - ov).abs() / (1.0 + ov.abs())).max()) < 1e-4
+        # linear-space input gives the same moments
+        m2, v2 = ops.dpv_moments(torch.exp(logp).to(dev), d, BV_log=False)
+        assert float((m2 - mean).abs().max()) < 1e-4 and float(((v2 - var).abs() / (1.0 + var.abs())).max()) < 1e-4
+        # the mean is dpv_to_depthmap
+        assert float((ops.dpv_expect(logp.to(dev), d, BV_log=True) - mean).abs().max()) < 1e-4
+    with pytest.raises(RuntimeError):
+        ops.dpv_moments(torch.zeros(1, 4, 2, 2, device=dev), np.ones(5))
