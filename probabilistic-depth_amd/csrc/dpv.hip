@@ -128,6 +128,44 @@ __global__ __launch_bounds__(256) void dpv_reduce_scalar_kernel(const float* x,
     if (depth) depth[(size_t)b * HW + pix] = e;
 }
 
+// Expectation with the wave layout of dpv_reduce_vec4_kernel: lane = (plane group g, pixel quad q), all loads of a
+// lane issued up front (RPL 16-byte non-temporal loads in flight per lane), partial sums combined by xor-shuffles.
+template <bool BV_LOG, int RPL>
+__global__ __launch_bounds__(256) void dpv_expect_vec4_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ dc, int D, int HW,
+                                                              float* __restrict__ depth) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int g = lane >> 4;
+    const int quads = HW >> 2;
+    const int q = wave * 16 + (lane & 15);
+    const bool live = q < quads;
+    const int b = blockIdx.y;
+    const float* xb = x + (size_t)b * D * HW + (size_t)(live ? q : 0) * 4;
+    float4 v[RPL];
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        const int k = g + 4 * i;
+        v[i] = (k < D && live) ? load_nt(xb + (size_t)k * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        const int k = g + 4 * i;
+        if (k < D) {
+            const float dk = dc[k];
+            e.x += dk * (BV_LOG ? expf(v[i].x) : v[i].x); e.y += dk * (BV_LOG ? expf(v[i].y) : v[i].y);
+            e.z += dk * (BV_LOG ? expf(v[i].z) : v[i].z); e.w += dk * (BV_LOG ? expf(v[i].w) : v[i].w);
+        }
+    }
+#pragma unroll
+    for (int s = 16; s <= 32; s <<= 1) {
+        const float4 o = shfl_xor4(e, s);
+        e.x += o.x; e.y += o.y; e.z += o.z; e.w += o.w;
+    }
+    if (live && g == 0) *reinterpret_cast<float4*>(depth + (size_t)b * HW + (size_t)q * 4) = e;
+}
+
 template <bool BV_LOG, int VEC>
 __global__ __launch_bounds__(256) void dpv_expect_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ dc, int D,
@@ -183,7 +221,14 @@ hipError_t launch_dpv_expect(const float* dpv, const float* d_candi, int B, int 
                              int bv_log, float* depth, hipStream_t stream) {
     const int HW = H * W;
     const bool vec = (HW % 4 == 0) && aligned16(dpv) && aligned16(depth);
-    if (vec) {
+    if (vec && D <= 128) {
+        dim3 grid((HW / 4 + 63) / 64, B);
+#define PDEPTH_EXPECT(RPL)                                                                                              \
+    if (bv_log) hipLaunchKernelGGL((dpv_expect_vec4_kernel<true, RPL>), grid, dim3(256), 0, stream, dpv, d_candi, D, HW, depth); \
+    else hipLaunchKernelGGL((dpv_expect_vec4_kernel<false, RPL>), grid, dim3(256), 0, stream, dpv, d_candi, D, HW, depth);
+        if (D <= 32) { PDEPTH_EXPECT(8) } else if (D <= 64) { PDEPTH_EXPECT(16) } else { PDEPTH_EXPECT(32) }
+#undef PDEPTH_EXPECT
+    } else if (vec) {
         dim3 grid((HW / 4 + 255) / 256, B);
         if (bv_log) hipLaunchKernelGGL((dpv_expect_kernel<true, 4>), grid, dim3(256), 0, stream, dpv, d_candi, D, HW, depth);
         else hipLaunchKernelGGL((dpv_expect_kernel<false, 4>), grid, dim3(256), 0, stream, dpv, d_candi, D, HW, depth);
