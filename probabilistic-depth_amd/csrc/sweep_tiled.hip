@@ -14,6 +14,10 @@
 //   On the benchmark poses 40..64 of the 64 planes are band planes and a pixel's box has ~30 texels (against
 //   160..256 taps): ~2x fewer VALU and LDS instructions per tile than direct evaluation of everything.
 //
+//   grid    = persistent: as many blocks as the chip holds at once (3 per CU), each pulling (batch item, tile)
+//             work items from a per-XCD queue counter in the workspace, so the per-block setup (depth candidates
+//             to LDS, suffix min/max) and the launch cost are paid once per block instead of once per tile (-3.5 %);
+//             when the grid covers all items anyway (small problems) block i just takes item i, no atomics;
 //   block   = 16x4 reference pixels x 4 waves = 256 threads; every wave holds the same 64 pixels (lane = pixel).
 //             Direct group: wave w owns KP = 8 (or 4, 2) consecutive planes of a group of 32 (16, 8); their
 //             geometry (LDS tap address + 4 weights) lives in registers, computed once per (pixel, plane, view).
@@ -147,7 +151,8 @@ __device__ __forceinline__ T cold_arg(size_t offset) {
 
 template <int METRIC>
 __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a, const float4* __restrict__ packed,
-                                                              int* __restrict__ tile_flags, int tiles_x) {
+                                                              int* __restrict__ tile_flags, int* __restrict__ queue,
+                                                              int tiles_x, int ntile) {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
     float4* win = lds4;                                   // [NBUF][NTEX_MAX]
     float* reft = reinterpret_cast<float*>(lds4 + NBUF * NTEX_MAX);  // [NBUF][4 channels][64 pixels]
@@ -157,42 +162,26 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
     float* dlo = dcl + a.D;                               // [D/16 + 1] min of d_candi[16 j .. D)
     float* dhi = dlo + (a.D / 16 + 1);                    // [D/16 + 1] max of d_candi[16 j .. D)
     __shared__ int s_bbox[2][NPG][4];  // per-wave bounding boxes of window_of(), double buffered by call parity
+    __shared__ int s_item[2];          // work item of this block: current / prefetched next
     int bbox_parity = 0;
 
     const int tid = threadIdx.x;
     const int pgl = __builtin_amdgcn_readfirstlane(tid >> 6);  // plane group of this wave (wave-uniform)
     const int lane = tid & 63;       // pixel of the tile
     const int lx = lane & 15, ly = lane >> 4;
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so blocks i and i+8
-    // share an L2.  Give every XCD one contiguous band of tiles: neighbouring tiles stage overlapping
-    // source windows, which then hit that XCD's L2 instead of going out to the Infinity Cache.
-    // (bijective for any tile count; affects speed only)
-    const int ntile = gridDim.x;
+    // Persistent blocks: the grid is sized to fill the chip once and every block pulls (tile, batch item) work
+    // items from a queue, so the per-block setup below is paid once per block and not once per tile.  XCD-aware:
+    // workgroups are dealt round-robin over the 8 XCDs, so blocks i and i+8 share an L2.  Every XCD owns one
+    // contiguous band of tiles (its own queue counter): neighbouring tiles stage overlapping source windows,
+    // which then hit that XCD's L2 instead of going out to the Infinity Cache.
     const int xcd = blockIdx.x & 7, qq = ntile >> 3, rr = ntile & 7;
-    int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-    if (rr == 0 && qq % tiles_x == 0) {
-        // the band is a whole number of tile rows: walk it column by column, so that the blocks in flight
-        // on one XCD share a narrow strip of source columns (working set ~1 MB instead of the full image
-        // width) -- measured HBM reads 485 MB -> see profiles/ (algorithmic 281 MB)
-        const int band_rows = qq / tiles_x, i = blockIdx.x >> 3;
-        tile = (xcd * band_rows + i % band_rows) * tiles_x + i / band_rows;
-    }
-    const int b = blockIdx.y;
-    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
-    const int x = tx0 + lx, y = ty0 + ly;
-    const bool live = x < a.W && y < a.H;
+    const int band_first = xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq;
+    const int band_tiles = qq + (xcd < rr ? 1 : 0);
+    const int nitems = band_tiles * a.B;
+    const bool colmajor = rr == 0 && qq % tiles_x == 0;  // the band is a whole number of tile rows
     const int HW = a.H * a.W;
-    const int p = live ? y * a.W + x : (min(y, a.H - 1) * a.W + min(x, a.W - 1));
-
-    const float cx = a.cxcy[b * 2 + 0], cy = a.cxcy[b * 2 + 1];
-    const float half_w = (float)a.W / 2.0f, half_h = (float)a.H / 2.0f;
-    const float rcx = refined_rcp(cx), rcy = refined_rcp(cy);
-    const float r0 = a.rays[((size_t)b * 3 + 0) * HW + p];
-    const float r1 = a.rays[((size_t)b * 3 + 1) * HW + p];
-    const float r2 = a.rays[((size_t)b * 3 + 2) * HW + p];
-    const float* refb = a.ref + (size_t)b * a.ref_bstride;
-    const v4i ref_rsrc = make_rsrc(refb, a.C * HW * 4);
     const int nchunk = (a.C + 3) / 4;
+    const float half_w = (float)a.W / 2.0f, half_h = (float)a.H / 2.0f;
     for (int k = tid; k < a.D; k += 256) dcl[k] = a.d_candi[k];
     __syncthreads();
     {   // suffix min / max of the depth candidates per 16 planes: one wave, 16 lanes per segment
@@ -215,6 +204,41 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
         __syncthreads();
     }
     const int win_lds0 = (int)lds_addr_of(win);
+    // work item -> batch item, tile, this lane's pixel
+    auto map_item = [&](int it, int& b_, int& tile_, bool& live_, int& p_) {
+        b_ = it / band_tiles;
+        const int ti = it - b_ * band_tiles;
+        tile_ = band_first + ti;
+        if (colmajor) {
+            // walk the band column by column, so that the blocks in flight on one XCD share a narrow strip of
+            // source columns (working set ~1 MB instead of the full image width)
+            const int band_rows = qq / tiles_x;
+            tile_ = (xcd * band_rows + ti % band_rows) * tiles_x + ti / band_rows;
+        }
+        const int x = (tile_ % tiles_x) * TW + lx, y = (tile_ / tiles_x) * TH + ly;
+        live_ = x < a.W && y < a.H;
+        p_ = live_ ? y * a.W + x : (min(y, a.H - 1) * a.W + min(x, a.W - 1));
+    };
+    // (when the grid already covers every item -- small problems -- block i simply takes item i of its XCD:
+    //  no atomics on the critical path of a launch that is latency bound anyway)
+    const bool queued = (int)gridDim.x < 8 * ((ntile + 7) / 8) * a.B;  // else: one block per item of every XCD band
+    if (queued) {
+        if (tid == 0) s_item[0] = atomicAdd(&queue[xcd], 1);
+        __syncthreads();
+    }
+    int item = queued ? s_item[0] : (int)(blockIdx.x >> 3), item_par = 0;
+    while (item < nitems) {
+    if (tid == 0) s_item[item_par ^ 1] = queued ? atomicAdd(&queue[xcd], 1) : nitems;  // next item; published by any later barrier
+    int b, tile, p; bool live;
+    map_item(item, b, tile, live, p);
+
+    const float cx = a.cxcy[b * 2 + 0], cy = a.cxcy[b * 2 + 1];
+    const float rcx = refined_rcp(cx), rcy = refined_rcp(cy);
+    const float r0 = a.rays[((size_t)b * 3 + 0) * HW + p];
+    const float r1 = a.rays[((size_t)b * 3 + 1) * HW + p];
+    const float r2 = a.rays[((size_t)b * 3 + 2) * HW + p];
+    const float* refb = a.ref + (size_t)b * a.ref_bstride;
+    const v4i ref_rsrc = make_rsrc(refb, a.C * HW * 4);
 
     for (int v = 0; v < a.V; ++v) {
         ViewXform xf;
@@ -351,7 +375,7 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
                 if (fits) break;
                 if (nsplit == 4) {  // block-uniform: leave the tile to the gather kernel
                     if (tid == 0) tile_flags[b * ntile + tile] = 1;
-                    return;
+                    goto tile_done;
                 }
                 nsplit *= 2;
             }
@@ -616,7 +640,7 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
         }
     }
     __syncthreads();
-
+    {
     // ---- epilogue from LDS: cost store, log-softmax over D, expectation ----------------------
     // wave w handles planes k = w, w+4, w+8, ... of the tile's 64 pixels
     float* const cost_out = PDEPTH_COLD_ARG(float*, cost_out);
@@ -653,6 +677,12 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
                 depth_out[(size_t)b * HW + p] = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
         }
     }
+    }
+tile_done:
+    __syncthreads();  // the tile's LDS state is dead, s_item of the next round is visible
+    item_par ^= 1;
+    item = s_item[item_par];
+    }  // work items
 }
 
 // Pre-pass of every call.  NCHW -> channel-group-planar [C/4 + 2][H][W] float4: plane g < C/4 holds channels
@@ -717,10 +747,12 @@ static size_t tiled_lds_bytes(int D) {
 // Largest D whose cost tile fits LDS next to the window buffers (2 blocks per CU).
 int sweep_tiled_max_planes() { return 160; }
 
-static size_t flag_bytes(int B, int H, int W) {
+// workspace head: one flag per (batch item, tile), then the 8 work-queue counters (one per XCD)
+static size_t flag_only_bytes(int B, int H, int W) {
     const size_t tiles = (size_t)((W + TW - 1) / TW) * ((H + TH - 1) / TH);
     return ((size_t)B * tiles * sizeof(int) + 255) & ~(size_t)255;
 }
+static size_t flag_bytes(int B, int H, int W) { return flag_only_bytes(B, H, W) + 256; }
 size_t sweep_tiled_workspace_bytes(int B, int V, int C, int H, int W) {
     return flag_bytes(B, H, W) + (size_t)B * V * ((C + 3) / 4 + 2) * H * W * sizeof(float4);
 }
@@ -735,20 +767,33 @@ hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t s
         const int HW = a.H * a.W;
         dim3 pgrid((HW + 255) / 256, a.B * a.V);
         hipLaunchKernelGGL(pack_c4_kernel, pgrid, dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V, a.C, a.H, a.W, packed,
-                           flags, a.B * tiles);
+                           flags, (int)(flag_bytes(a.B, a.H, a.W) / sizeof(int)));
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t lds = tiled_lds_bytes(a.D);
-    dim3 grid(tiles, a.B);
+    int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + flag_only_bytes(a.B, a.H, a.W));
+    // persistent grid: as many blocks as the device holds at once (3 per CU at D <= 64), a multiple of 8
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+            n_cu = 256;
+    }
+    const int per_cu = (int)((160 * 1024) / (lds + 64));
+    int nblk = n_cu * (per_cu < 1 ? 1 : per_cu > 3 ? 3 : per_cu);
+    nblk = (nblk + 7) & ~7;
+    const long long full = 8ll * ((tiles + 7) / 8) * a.B;  // one block per item of the largest XCD band, times 8
+    if (full <= nblk) nblk = (int)full;
+    dim3 grid(nblk);
     if (a.metric == 0) {
         auto kern = sweep_tiled_kernel<0>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, packed, flags, tiles_x);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, packed, flags, queue, tiles_x, tiles);
     } else {
         auto kern = sweep_tiled_kernel<1>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, packed, flags, tiles_x);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, packed, flags, queue, tiles_x, tiles);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
