@@ -356,3 +356,30 @@ def test_fuzz_tiled_against_gather(dev):
         if fin.any():
             assert np.abs(da.cpu().numpy() - dd.cpu().numpy())[fin].max() < 2e-3 * max(1.0, float(np.max(b["d_candi"])) / 40.0)
     print(f"fuzz: worst relative cost difference tiled vs gather {worst:.2e}")
+
+
+def test_fuzz_large_tiled_against_gather(dev):
+    """Larger random shapes (up to 260x520, D up to 130, mono / stereo / wide-baseline poses, unsorted depth
+    candidates): every path of the tiled kernel -- direct groups with and without window splits, band groups of all
+    sizes, per-tile fallback -- against the gather kernel, to an ulp or two of the largest cost."""
+    rng = np.random.default_rng(99)
+    worst, fallback = 0.0, 0
+    for case in range(40):
+        H, W = int(rng.integers(40, 260)), int(rng.integers(60, 520))
+        C, D, V = int(rng.integers(1, 70)), int(rng.integers(8, 130)), int(rng.integers(1, 3))
+        b = synth.make_batch(300 + case, 1, C=C, D=D, H=H, W=W, V=V, pose=("mono", "stereo", "wide")[case % 3],
+                             cx_off=float(rng.uniform(-2, 2)), cy_off=float(rng.uniform(-1, 1)))
+        if case % 5 == 4:
+            b["d_candi"] = rng.uniform(2.0, 50.0, size=D)
+        d = to_dev(b, dev)
+        args = (d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 7.5)
+        ca = ops.sweep_cost(*args, algo="auto").cpu().numpy()
+        fallback += _native.fallback_tiles(1, H, W)
+        cd = ops.sweep_cost(*args, algo="direct").cpu().numpy()
+        assert np.array_equal(np.isnan(ca), np.isnan(cd)), f"case {case}: NaN pattern differs"
+        err = float(np.nanmax(np.abs(ca - cd))) / max(1.0, float(np.nanmax(np.abs(cd))))
+        worst = max(worst, err)
+        assert err < 2e-6, f"case {case} ({H}x{W}, C={C}, D={D}, V={V}): tiled vs gather differ by {err:.3e} (relative)"
+    assert fallback > 0  # the wide-baseline cases must have exercised the per-tile fallback as well
+    print(f"large fuzz: worst relative difference {worst:.2e}, {fallback} tiles through the gather kernel")
+
