@@ -650,18 +650,24 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
     if (cout)
         for (int k = pgl; k < a.D; k += NPG) cout[(size_t)k * HW] = costs[k * 64 + lane];
     if (logp_out || depth_out) {
-        float m = -INFINITY;
-        for (int k = pgl; k < a.D; k += NPG) m = fmaxf(m, costs[k * 64 + lane]);
-        red[pgl * 64 + lane] = m;
+        // Each wave reduces its planes locally (max, then sum of exp relative to its own max); ONE exchange of
+        // (max, sum) per wave through the idle reference buffers, combined by rescaling -- one barrier instead of
+        // two exchange rounds with two barriers each.
+        float mw = -INFINITY;
+        for (int k = pgl; k < a.D; k += NPG) mw = fmaxf(mw, costs[k * 64 + lane]);
+        float sw = 0.0f;
+        for (int k = pgl; k < a.D; k += NPG) sw = sw + expf(costs[k * 64 + lane] - mw);
+        float* redm = reft;        // [NPG][64]
+        float* reds = reft + 256;  // [NPG][64]
+        redm[pgl * 64 + lane] = mw;
+        reds[pgl * 64 + lane] = sw;
         __syncthreads();
-        m = fmaxf(fmaxf(red[lane], red[64 + lane]), fmaxf(red[128 + lane], red[192 + lane]));
-        __syncthreads();
-        float s = 0.0f;
-        for (int k = pgl; k < a.D; k += NPG) s = s + expf(costs[k * 64 + lane] - m);
-        red[pgl * 64 + lane] = s;
-        __syncthreads();
-        s = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
-        __syncthreads();
+        const float m0 = redm[lane], m1 = redm[64 + lane], m2 = redm[128 + lane], m3 = redm[192 + lane];
+        const float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        // (a wave without planes -- D < 4 -- has max -inf and sum 0: exp(-inf - m) = 0, no NaN as long as m is finite;
+        //  if every cost is -inf or NaN the result is NaN like the reference's)
+        const float s = (reds[lane] * expf(m0 - m) + reds[64 + lane] * expf(m1 - m)) +
+                        (reds[128 + lane] * expf(m2 - m) + reds[192 + lane] * expf(m3 - m));
         const float ls = logf(s);
         float e = 0.0f;
         float* o = (logp_out && live) ? logp_out + (size_t)b * a.D * HW + p : nullptr;
