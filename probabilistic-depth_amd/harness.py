@@ -43,3 +43,4 @@ def eval_trajectory(model, frames):
         prev = r["prev_output"]
         results.append(r)
     return results
+

@@ -22,12 +22,27 @@ def _metric(feat_dist):
     return METRICS[feat_dist]
 
 
+_D_CANDI_CACHE = {}
+
+
 def d_candi_tensor(d_candi, device):
-    """float64 numpy / list / tensor -> fp32 device tensor (homography.py:115 cast)."""
+    """float64 numpy / list / tensor -> fp32 device tensor (homography.py:115 cast).
+
+    Host arrays are uploaded once per (values, device) and cached: the candidates are a constant of a run, and a
+    pageable host-to-device copy per op would synchronise the stream (and cannot be captured in a HIP graph)."""
     if isinstance(d_candi, torch.Tensor):
         return d_candi.to(device=device, dtype=torch.float32)
     import numpy as np
-    return torch.from_numpy(np.asarray(d_candi).astype(np.float32)).to(device)
+    arr = np.ascontiguousarray(np.asarray(d_candi), dtype=np.float32)
+    dev = torch.device(device)
+    key = (arr.tobytes(), dev.type, dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else -1))
+    t = _D_CANDI_CACHE.get(key)
+    if t is None:
+        if len(_D_CANDI_CACHE) > 64:
+            _D_CANDI_CACHE.clear()
+        t = torch.from_numpy(arr.copy()).to(dev)
+        _D_CANDI_CACHE[key] = t
+    return t
 
 
 def sweep_cost(ref, src, K, R, t, rays, cxcy, d_candi, sigma, feat_dist="L2", algo="auto", blas=None):

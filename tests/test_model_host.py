@@ -121,3 +121,4 @@ def test_upsample_mode_fuses_sparse_depth():
     want_fused, want_log = O.dpv_fuse(bv_cur.cpu(), inp["dmaps"], inp["masks"], inp["d_candi"], 0.3)
     np.testing.assert_allclose(fused_log.cpu().numpy(), want_log.numpy(), rtol=1e-5, atol=3e-5)
     assert out["output_refined"][0].shape == (2, 64, 256, 256)
+
