@@ -190,6 +190,16 @@ int pdepth_correlation_forward_f32(const float *input1, const float *input2, int
                                    void *stream);
 
 /*
+ * Backward of the same operator: replaces correlation_backward_cuda (correlation_cuda.cc:89-167; kernels
+ * correlation_cuda_kernel.cu:116-300).  grad_output [B,(2r+1)^2,H,W] -> grad_input1, grad_input2 [B,C,H,W]
+ * (either may be NULL).  Same supported configurations as the forward.
+ */
+int pdepth_correlation_backward_f32(const float *input1, const float *input2, const float *grad_output, int32_t B,
+                                    int32_t C, int32_t H, int32_t W, int32_t pad_size, int32_t kernel_size,
+                                    int32_t max_displacement, int32_t stride1, int32_t stride2,
+                                    int32_t corr_multiply, float *grad_input1, float *grad_input2, void *stream);
+
+/*
  * Depth-map driven inverse warp (forward only): replaces the sampling part of inverse_warp
  * (utils/inverse_warp.py:174-210 with pixel2cam :26-40 and cam2pixel :43-69), used by the training losses
  * (losses/loss_blocks.py:116,151).  The host supplies Kinv = intrinsics.inverse() [B,3,3] and

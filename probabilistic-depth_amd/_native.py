@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "pdepth_sweep_cost_f32", "pdepth_sweep_dpv_f32", "pdepth_dpv_reduce_f32",
     "pdepth_dpv_expect_f32", "pdepth_warp_feature_f32", "pdepth_sample_coords_f32",
     "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32", "pdepth_inverse_warp_f32",
-    "pdepth_dpv_moments_f32",
+    "pdepth_dpv_moments_f32", "pdepth_correlation_backward_f32",
 )
 
 
@@ -110,11 +110,12 @@ def load():
     lib.pdepth_dpv_fuse_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                         c_float, c_float, c_void_p, c_void_p, c_void_p]
     lib.pdepth_correlation_forward_f32.argtypes = [c_void_p, c_void_p] + [c_int32] * 10 + [c_void_p, c_void_p]
+    lib.pdepth_correlation_backward_f32.argtypes = [c_void_p] * 3 + [c_int32] * 10 + [c_void_p] * 3
     lib.pdepth_inverse_warp_f32.argtypes = [c_void_p] * 4 + [c_int32] * 4 + [c_void_p] * 3
     for fn in ("pdepth_sweep_cost_f32", "pdepth_sweep_dpv_f32", "pdepth_dpv_reduce_f32",
                "pdepth_dpv_expect_f32", "pdepth_warp_feature_f32", "pdepth_sample_coords_f32",
                "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32", "pdepth_inverse_warp_f32",
-               "pdepth_dpv_moments_f32"):
+               "pdepth_dpv_moments_f32", "pdepth_correlation_backward_f32"):
         getattr(lib, fn).restype = c_int
     if lib.pdepth_abi_version() != 1:
         raise RuntimeError("libpdepth_hip.so ABI version mismatch")
@@ -363,6 +364,27 @@ def correlation_forward(x1, x2, pad_size, kernel_size, max_displacement, stride1
                                                 out.data_ptr(), _stream(x1.device))
     _check(rc, lib)
     return out
+
+
+def correlation_backward(x1, x2, grad_out, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply=1,
+                         want1=True, want2=True):
+    """x1, x2 [B,C,H,W], grad_out [B,(2r+1)^2,H,W] -> (grad_x1 | None, grad_x2 | None)."""
+    lib = load()
+    _dev(x1, "input1"), _dev(x2, "input2"), _dev(grad_out, "grad_output")
+    x1, x2, grad_out = x1.contiguous(), x2.contiguous(), grad_out.contiguous()
+    B, C, H, W = x1.shape
+    nd = 2 * (max_displacement // max(stride2, 1)) + 1
+    if x2.shape != x1.shape or tuple(grad_out.shape) != (B, nd * nd, H, W):
+        raise RuntimeError("correlation_backward: shape mismatch")
+    g1 = torch.empty_like(x1) if want1 else None
+    g2 = torch.empty_like(x2) if want2 else None
+    with torch.cuda.device(x1.device):
+        rc = lib.pdepth_correlation_backward_f32(
+            x1.data_ptr(), x2.data_ptr(), grad_out.data_ptr(), B, C, H, W, int(pad_size), int(kernel_size),
+            int(max_displacement), int(stride1), int(stride2), int(corr_multiply),
+            g1.data_ptr() if want1 else None, g2.data_ptr() if want2 else None, _stream(x1.device))
+    _check(rc, lib)
+    return g1, g2
 
 
 def inverse_warp(img, depth, Kinv, proj):

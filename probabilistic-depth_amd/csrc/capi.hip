@@ -196,6 +196,23 @@ int pdepth_correlation_forward_f32(const float* input1, const float* input2, int
                                                        output, (hipStream_t)stream), "pdepth_correlation_forward_f32");
 }
 
+int pdepth_correlation_backward_f32(const float* input1, const float* input2, const float* grad_output, int32_t B,
+                                    int32_t C, int32_t H, int32_t W, int32_t pad_size, int32_t kernel_size,
+                                    int32_t max_displacement, int32_t stride1, int32_t stride2, int32_t corr_multiply,
+                                    float* grad_input1, float* grad_input2, void* stream) {
+    (void)corr_multiply;
+    if (!input1 || !input2 || !grad_output || (!grad_input1 && !grad_input2))
+        return fail(PDEPTH_E_ARG, "pdepth_correlation_backward_f32: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(PDEPTH_E_ARG, "pdepth_correlation_backward_f32: non-positive dimension");
+    if (kernel_size != 1 || stride1 != 1 || stride2 < 1 || pad_size != max_displacement || max_displacement < 1 ||
+        max_displacement % stride2 != 0 || max_displacement / stride2 > pdepth::correlation_max_radius())
+        return fail(PDEPTH_E_ARG, "pdepth_correlation_backward_f32: unsupported configuration (pad %d, kernel %d, "
+                    "max_displacement %d, stride1 %d, stride2 %d)", pad_size, kernel_size, max_displacement, stride1, stride2);
+    return launched(pdepth::launch_correlation_backward(input1, input2, grad_output, B, C, H, W, max_displacement / stride2,
+                                                        stride2, grad_input1, grad_input2, (hipStream_t)stream),
+                    "pdepth_correlation_backward_f32");
+}
+
 int pdepth_inverse_warp_f32(const float* img, const float* depth, const float* Kinv, const float* proj, int32_t B,
                             int32_t C, int32_t H, int32_t W, float* out, uint8_t* valid, void* stream) {
     if (!img || !depth || !Kinv || !proj || !out) return fail(PDEPTH_E_ARG, "pdepth_inverse_warp_f32: null pointer");

@@ -169,6 +169,49 @@ hipError_t launch_correlation_forward(const float* x1, const float* x2, int B, i
 
 int correlation_max_radius() { return RMAX; }
 
+// Backward of the correlation: with out[b,d,y,x] = (1/C) sum_c x1[b,c,y,x] * x2[b,c,y+dy,x+dx] (zero padded),
+//   grad_x1[b,c,y,x] = (1/C) sum_d go[b,d,y,x]       * x2[b,c,y+dy,x+dx]
+//   grad_x2[b,c,y,x] = (1/C) sum_d go[b,d,y-dy,x-dx] * x1[b,c,y-dy,x-dx]
+// (correlation_cuda_kernel.cu:116-300 computes the same two sums over its padded NHWC repacks).  One thread
+// per (pixel, channel); the (2r+1)^2 gradient values of a pixel are re-read per channel from L1/L2.
+__global__ __launch_bounds__(256) void correlation_bwd_kernel(const float* __restrict__ x1,
+                                                              const float* __restrict__ x2,
+                                                              const float* __restrict__ go, int C, int H, int W,
+                                                              int r, int s2, float* __restrict__ g1,
+                                                              float* __restrict__ g2) {
+    const int HW = H * W;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int y = pix / W, x = pix - y * W;
+    const int nd = 2 * r + 1;
+    const float* a1 = x1 + ((size_t)b * C + c) * HW;
+    const float* a2 = x2 + ((size_t)b * C + c) * HW;
+    const float* gb = go + (size_t)b * nd * nd * HW;
+    float s1 = 0.0f, s2acc = 0.0f;
+    for (int i = 0; i < nd; ++i) {
+        const int dy = (i - r) * s2;
+        for (int j = 0; j < nd; ++j) {
+            const int dx = (j - r) * s2;
+            const float* gd = gb + (size_t)(i * nd + j) * HW;
+            const int yp = y + dy, xp = x + dx;  // x2 position paired with (y, x)
+            if (yp >= 0 && yp < H && xp >= 0 && xp < W) s1 = __builtin_fmaf(gd[pix], a2[yp * W + xp], s1);
+            const int ym = y - dy, xm = x - dx;  // x1 position whose pair is (y, x)
+            if (ym >= 0 && ym < H && xm >= 0 && xm < W) s2acc = __builtin_fmaf(gd[ym * W + xm], a1[ym * W + xm], s2acc);
+        }
+    }
+    const float inv = 1.0f / (float)C;
+    if (g1) g1[((size_t)b * C + c) * HW + pix] = s1 * inv;
+    if (g2) g2[((size_t)b * C + c) * HW + pix] = s2acc * inv;
+}
+
+hipError_t launch_correlation_backward(const float* x1, const float* x2, const float* go, int B, int C, int H, int W,
+                                       int radius, int stride2, float* g1, float* g2, hipStream_t stream) {
+    dim3 grid((H * W + 255) / 256, C, B);
+    hipLaunchKernelGGL(correlation_bwd_kernel, grid, dim3(256), 0, stream, x1, x2, go, C, H, W, radius, stride2, g1, g2);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // inverse_warp forward (utils/inverse_warp.py:174-210): depth-map driven warp used by the training losses
 // (losses/loss_blocks.py:116,151).  pixel2cam (:26-40), cam2pixel (:43-69, Z clamped at 1e-3, coordinates

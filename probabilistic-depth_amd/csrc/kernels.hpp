@@ -58,6 +58,8 @@ hipError_t launch_dpv_fuse(const float* logp, const float* dmaps, const float* m
 hipError_t launch_correlation_forward(const float* x1, const float* x2, int B, int C, int H, int W, int radius,
                                       int stride2, float* out, hipStream_t stream);
 int correlation_max_radius();
+hipError_t launch_correlation_backward(const float* x1, const float* x2, const float* go, int B, int C, int H, int W,
+                                       int radius, int stride2, float* g1, float* g2, hipStream_t stream);
 hipError_t launch_inverse_warp(const float* img, const float* depth, const float* Kinv, const float* proj, int B,
                                int C, int H, int W, float* out, unsigned char* valid, hipStream_t stream);
 

@@ -1,10 +1,10 @@
-"""Drop-in for the reference's correlation module (forward only).
+"""Drop-in for the reference's correlation module (forward and backward).
 
 Same constructor arguments as models/correlation_package/correlation.py:47-61 (`Correlation(pad_size,
 kernel_size, max_displacement, stride1, stride2, corr_multiply)`) and as models/correlation_native.py:6-23
-(`Correlation(max_displacement)`); the forward runs the HIP kernel behind pdepth_correlation_forward_f32.
-The backward of the reference (correlation_cuda_kernel.cu:116-300) is not provided: the op is dead code
-w.r.t. get_model and this package is eval-only; a tensor that requires grad raises.
+(`Correlation(max_displacement)`); the forward runs the HIP kernel behind pdepth_correlation_forward_f32, the
+backward (reference: correlation_cuda_kernel.cu:116-300) the one behind pdepth_correlation_backward_f32 through a
+torch.autograd.Function, like models/correlation_package/correlation.py:6-44.
 """
 import torch.nn as nn
 
@@ -23,7 +23,5 @@ class Correlation(nn.Module):
         self.output_dim = 2 * (max_displacement // stride2) + 1
 
     def forward(self, input1, input2):
-        if input1.requires_grad or input2.requires_grad:
-            raise RuntimeError("Correlation: backward is not implemented in the HIP path (forward/eval only)")
         return ops.correlation(input1, input2, self.pad_size, self.kernel_size, self.max_displacement, self.stride1,
                                self.stride2, self.corr_multiply)

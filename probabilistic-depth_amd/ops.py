@@ -117,6 +117,25 @@ def dpv_fuse(logp, dmaps, masks, d_candi, var=0.3, eps=None, want_fused=True, wa
                             want_fused, want_log)
 
 
+class _CorrelationFn(torch.autograd.Function):
+    """Autograd binding like models/correlation_package/correlation.py:6-44 (CorrelationFunction)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply):
+        ctx.save_for_backward(x1, x2)
+        ctx.cfg = (pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply)
+        return _native.correlation_forward(x1, x2, *ctx.cfg)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x1, x2 = ctx.saved_tensors
+        g1, g2 = _native.correlation_backward(x1, x2, grad_out, *ctx.cfg, want1=ctx.needs_input_grad[0],
+                                              want2=ctx.needs_input_grad[1])
+        return g1, g2, None, None, None, None, None, None
+
+
 def correlation(x1, x2, pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1, corr_multiply=1):
-    """Forward of the reference's native correlation op (models/correlation_package/correlation.py:47-61)."""
+    """The reference's native correlation op, forward and backward (models/correlation_package/correlation.py:6-61)."""
+    if x1.requires_grad or x2.requires_grad:
+        return _CorrelationFn.apply(x1, x2, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply)
     return _native.correlation_forward(x1, x2, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply)

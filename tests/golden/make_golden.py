@@ -79,7 +79,12 @@ def main():
     # the HIP kernels are asked for the same mode when they are checked against these fixtures.
     meta = dict(torch=torch.__version__, cpu_capability=torch.backends.cpu.get_cpu_capability(),
                 cpu_vendor=cpu_vendor(), blas_mode=np.int32(pdepth_amd._native.host_blas_mode()))
-    save = lambda name, **kw: np.savez_compressed(os.path.join(HERE, name), **kw, **{"meta_" + k: v for k, v in meta.items()})
+    only = os.environ.get("PDEPTH_GOLDEN_ONLY")  # e.g. "g12": rewrite just that fixture, leave the others untouched
+
+    def save(name, **kw):
+        if only and not name.startswith(only):
+            return
+        np.savez_compressed(os.path.join(HERE, name), **kw, **{"meta_" + k: v for k, v in meta.items()})
 
     # ---- G1/G2/G3: tiny sweeps (16x24, C=7, D=8, V=2), off-centre principal point -------
     h, w, C, D, V = 16, 24, 7, 8, 2
@@ -216,6 +221,16 @@ def main():
     save("g11_inverse_warp.npz", img=img11.numpy(), depth=dep11.numpy(), K=K11.numpy(), pose44=pose44.numpy(),
          pose6=pose6.numpy(), out44=o44.numpy(), valid44=v44.numpy(), out6e=o6e.numpy(), valid6e=v6e.numpy(),
          out6q=o6q.numpy(), valid6q=v6q.numpy())
+
+    # ---- G12: correlation backward: autograd through the reference's pure-PyTorch twin -------------
+    g12 = torch.Generator().manual_seed(1212)
+    x1 = torch.randn(2, 20, 11, 14, generator=g12).requires_grad_(True)
+    x2 = torch.randn(2, 20, 11, 14, generator=g12).requires_grad_(True)
+    go = torch.randn(2, 81, 11, 14, generator=g12)
+    out12 = corr_native.Correlation(max_displacement=4)(x1, x2)
+    out12.backward(go)
+    save("g12_correlation_backward.npz", x1=x1.detach().numpy(), x2=x2.detach().numpy(), grad_out=go.numpy(),
+         grad_x1=x1.grad.numpy(), grad_x2=x2.grad.numpy())
 
     print("golden fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):

@@ -1,4 +1,4 @@
-"""DPV Bayesian fusion (rank 2) and the correlation op forward (rank 3)."""
+"""DPV Bayesian fusion (rank 2), the correlation op forward + backward (rank 3), rank-4 pieces."""
 import numpy as np
 import pytest
 import torch
@@ -48,8 +48,6 @@ def test_hip_correlation_forward():
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
     with pytest.raises(RuntimeError, match="unsupported configuration"):
         ops.correlation(x1.to(dev), x2.to(dev), kernel_size=3)
-    with pytest.raises(RuntimeError, match="backward is not implemented"):
-        Correlation()(x1.to(dev).requires_grad_(), x2.to(dev))
 
 
 @pytest.mark.gpu
@@ -131,3 +129,37 @@ def test_hip_dpv_moments():
         assert float((ops.dpv_expect(logp.to(dev), d, BV_log=True) - mean).abs().max()) < 1e-4
     with pytest.raises(RuntimeError):
         ops.dpv_moments(torch.zeros(1, 4, 2, 2, device=dev), np.ones(5))
+
+
+def test_oracle_correlation_backward_matches_reference_fixture():
+    """Autograd through the oracle's restatement vs autograd through the reference's correlation_native (fixture g12)."""
+    g = golden("g12_correlation_backward.npz")
+    x1 = torch.from_numpy(g["x1"]).requires_grad_(True)
+    x2 = torch.from_numpy(g["x2"]).requires_grad_(True)
+    O.correlation(x1, x2, 4).backward(torch.from_numpy(g["grad_out"]))
+    np.testing.assert_allclose(x1.grad.numpy(), g["grad_x1"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(x2.grad.numpy(), g["grad_x2"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_hip_correlation_backward():
+    dev = torch.device("cuda")
+    g = golden("g12_correlation_backward.npz")
+    x1 = torch.from_numpy(g["x1"]).to(dev).requires_grad_(True)
+    x2 = torch.from_numpy(g["x2"]).to(dev).requires_grad_(True)
+    out = Correlation(pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1)(x1, x2)
+    out.backward(torch.from_numpy(g["grad_out"]).to(dev))
+    np.testing.assert_allclose(x1.grad.cpu().numpy(), g["grad_x1"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(x2.grad.cpu().numpy(), g["grad_x2"], rtol=1e-5, atol=1e-6)
+    # only one input needs a gradient; a stride-2 displacement grid against the oracle's autograd
+    rng = np.random.default_rng(5)
+    a = torch.from_numpy(rng.normal(size=(1, 6, 9, 13)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(size=(1, 6, 9, 13)).astype(np.float32))
+    go = torch.from_numpy(rng.normal(size=(1, 25, 9, 13)).astype(np.float32))
+    ad = a.to(dev).requires_grad_(True)
+    ops.correlation(ad, b.to(dev), 4, 1, 4, 1, 2).backward(go.to(dev))
+    ac = a.clone().requires_grad_(True)
+    full = O.correlation(ac, b, 4)  # 81 channels; stride 2 keeps displacements -4, -2, 0, 2, 4
+    idx = [i * 9 + j for i in range(0, 9, 2) for j in range(0, 9, 2)]
+    full[:, idx].backward(go)
+    np.testing.assert_allclose(ad.grad.cpu().numpy(), ac.grad.numpy(), rtol=1e-5, atol=1e-6)
