@@ -19,8 +19,10 @@
 //             to LDS, suffix min/max) and the launch cost are paid once per block instead of once per tile (-3.5 %);
 //             when the grid covers all items anyway (small problems) block i just takes item i, no atomics;
 //   block   = 16x4 reference pixels x 4 waves = 256 threads; every wave holds the same 64 pixels (lane = pixel).
-//             Direct group: wave w owns KP = 8 (or 4, 2) consecutive planes of a group of 32 (16, 8); their
+//             Direct group: wave w owns KP = 4 (or 2, 1) consecutive planes of a group of 16 (8, 4); their
 //             geometry (LDS tap address + 4 weights) lives in registers, computed once per (pixel, plane, view).
+//             (8 planes per wave and groups of 32 were measured: +28 VGPRs, and slower on every configuration
+//             once the band mode had taken the far planes.)
 //             Band group: wave w accumulates box texels w, w+4, ... (X in registers), the waves exchange X
 //             through LDS, then wave w combines planes ks+w, ks+w+4, ... (geometry recomputed on the fly);
 //   source  = a pre-pass (pack_c4_kernel) re-lays every source view from NCHW to channel-group-planar
@@ -30,7 +32,7 @@
 //             time into LDS as float4 texels [row][col] by LDS-DMA (buffer_load_dwordx4 ... lds: a
 //             wave-instruction moves 64 texels = 1 KiB, no registers, no ds_write).  Direct groups: two 16 KB
 //             buffers, chunk ch+1 in flight while chunk ch is computed, one barrier per chunk.  Band group
-//             (small windows): the same 32 KB as a ring of 4 stages of two chunks each, three stages in flight.
+//             (small windows): the same 32 KB as a ring of 3 stages of two chunks each, two stages in flight.
 //             The DMA is issued from inline asm with hand-counted s_waitcnt, because the compiler would
 //             otherwise drain it in front of every ds_read.  Texels outside the image are fetched with an
 //             out-of-range buffer offset and arrive as zeros, which IS padding_mode='zeros';
@@ -56,7 +58,7 @@ namespace {
 
 constexpr int TW = 16, TH = 4;    // tile (pixels); one wave covers it
 constexpr int NPG = 4;            // plane groups per block (= waves)
-constexpr int KP = 8;             // planes per group
+constexpr int KP = 4;             // planes per group
 constexpr int SG = NPG * KP;      // planes per super group
 constexpr int NBUF = 2;           // LDS window buffers: chunk ch+1 is in flight (LDS-DMA) while chunk ch is computed
 #ifndef PDEPTH_NTEX   // experiment knobs (tools/variants.sh): window texels per buffer, blocks per CU
@@ -70,14 +72,14 @@ constexpr int BUF_BYTES = NTEX_MAX * 16;   // one window buffer of the direct gr
 // Band mode (see "band group" in the kernel).  Its windows are small, so the 32 KB of the two direct-mode window
 // buffers (plus nothing else) are re-cut into a ring of BR stages of two channel groups each:
 //     [BR stages][2 chunks][BAND_TEX texels * 16 B]   window ring   (24 KB)
-//     [2 * BR chunks][4 channels][64 pixels] floats   reference ring (8 KB)
+//     [2 * BR chunks][4 channels][64 pixels] floats   reference ring (6 KB)
 // and, once the channel loop is done, the first 16 KB hold the X exchange buffer (NX_MAX slots of 256 B) while the
 // last stage -- the two Gram planes -- stays in ring slot BR-1.
-constexpr int BR = 4;                       // ring depth in stages (BR-1 stages in flight)
-constexpr int BAND_TEX = 192;               // window texels of a band group
+constexpr int BR = 3;                       // ring depth in stages (BR-1 stages in flight)
+constexpr int BAND_TEX = 256;               // window texels of a band group
 constexpr int BAND_CHUNK_BYTES = BAND_TEX * 16;
 constexpr int BAND_STAGE_BYTES = 2 * BAND_CHUNK_BYTES;
-constexpr int BAND_REF_OFF = BR * BAND_STAGE_BYTES;   // 24576
+constexpr int BAND_REF_OFF = BR * BAND_STAGE_BYTES;   // 24576 (one DMA instruction per wave and chunk covers 256 texels)
 constexpr int NX_MAX = 64;                  // box texels per pixel: X exchange buffer = 16 KB
 constexpr int XPW = NX_MAX / NPG;           // X accumulators per wave
 static_assert(BAND_REF_OFF + 2 * BR * 1024 <= 2 * BUF_BYTES, "band ring must fit the direct-mode window buffers");
@@ -293,16 +295,16 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
 
         for (int k0 = 0; k0 < kend; k0 += SG) {
             // ---- geometry of this thread's KP planes (registers) ----------------------------
-            // Plane assignment inside the 32-plane super group: the 8 planes of a wave are split into
-            // nsplit parts of per = 8/nsplit planes; part q of wave w holds planes
+            // Plane assignment inside the 16-plane group: the KP = 4 planes of a wave are split into nsplit
+            // parts of per = 4/nsplit planes; part q of wave w holds planes
             //     k0 + q*(4*per) + w*per + [0, per),
             // so the planes staged together (one part of all 4 waves) are 4*per CONSECUTIVE planes and
-            // their common window shrinks with nsplit (nsplit = 1 is simply planes 8w .. 8w+7).
+            // their common window shrinks with nsplit (nsplit = 1 is simply planes 4w .. 4w+3).
             int off[KP];  // packed (y0, x0) until the plane's part is staged, then its window texel index
             int kpl[KP];  // depth plane of slot i
             float wnw[KP], wne[KP], wsw[KP], wse[KP];
             auto geometry = [&](int nsplit_) {
-                const int lper = nsplit_ == 1 ? 3 : nsplit_ == 2 ? 2 : 1;  // log2(planes per part and wave)
+                const int lper = nsplit_ == 1 ? 2 : nsplit_ == 2 ? 1 : 0;  // log2(planes per part and wave)
 #pragma unroll
                 for (int i = 0; i < KP; ++i) {
                     kpl[i] = k0 + ((i >> lper) << (lper + 2)) + (pgl << lper) + (i & ((1 << lper) - 1));
@@ -364,8 +366,8 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
             };
             // Smallest split into 1, 2 or 4 parts whose windows all fit LDS; the geometry is only redone
             // when the coarser split failed (large disparities per plane, e.g. 512x1024 with D=128).
-            // (a group of only 16 planes starts at nsplit = 2: part 0 is then exactly planes k0 .. k0+15)
-            int nsplit = kend - k0 <= 16 ? 2 : 1;
+            // (a group of only 8 planes starts at nsplit = 2: part 0 is then exactly planes k0 .. k0+7)
+            int nsplit = kend - k0 <= 8 ? 2 : 1;
             for (;;) {
                 geometry(nsplit);
                 const int per = KP / nsplit;
@@ -473,12 +475,12 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
     {                                                                                               \
         const float* rp = reft + CUR * 256 + lane;                                                  \
         const float4 rf = make_float4(rp[0], rp[64], rp[128], rp[192]);                             \
-        if (per == 8) PDEPTH_COMPUTE(8, 0)                                                          \
-        else if (per == 4) { if (part == 0) PDEPTH_COMPUTE(4, 0) else PDEPTH_COMPUTE(4, 4) }        \
-        else if (part == 0) PDEPTH_COMPUTE(2, 0)                                                    \
-        else if (part == 1) PDEPTH_COMPUTE(2, 2)                                                    \
-        else if (part == 2) PDEPTH_COMPUTE(2, 4)                                                    \
-        else PDEPTH_COMPUTE(2, 6)                                                                   \
+        if (per == 4) PDEPTH_COMPUTE(4, 0)                                                          \
+        else if (per == 2) { if (part == 0) PDEPTH_COMPUTE(2, 0) else PDEPTH_COMPUTE(2, 2) }        \
+        else if (part == 0) PDEPTH_COMPUTE(1, 0)                                                    \
+        else if (part == 1) PDEPTH_COMPUTE(1, 1)                                                    \
+        else if (part == 2) PDEPTH_COMPUTE(1, 2)                                                    \
+        else PDEPTH_COMPUTE(1, 3)                                                                   \
     }
                     if (ch & 1) {
                         constexpr int CUR = 1;
