@@ -73,17 +73,27 @@ constexpr int BUF_BYTES = NTEX_MAX * 16;   // one window buffer of the direct gr
 // buffers (plus nothing else) are re-cut into a ring of BR stages of two channel groups each:
 //     [BR stages][2 chunks][BAND_TEX texels * 16 B]   window ring   (24 KB)
 //     [2 * BR chunks][4 channels][64 pixels] floats   reference ring (6 KB)
-// and, once the channel loop is done, the first 16 KB hold the X exchange buffer (NX_MAX slots of 256 B) while the
-// last stage -- the two Gram planes -- stays in ring slot BR-1.
-constexpr int BR = 3;                       // ring depth in stages (BR-1 stages in flight)
-constexpr int BAND_TEX = 256;               // window texels of a band group
+// and, once the channel loop is done, the last stage -- the two Gram planes -- sits in ring slot 0 and everything
+// behind it (the other slots and the reference ring) holds the X exchange buffer (NX_MAX slots of 256 B).
+#ifndef PDEPTH_BR
+#define PDEPTH_BR 3
+#endif
+#ifndef PDEPTH_BAND_TEX
+#define PDEPTH_BAND_TEX 256
+#endif
+#ifndef PDEPTH_NX
+#define PDEPTH_NX 64
+#endif
+constexpr int BR = PDEPTH_BR;               // ring depth in stages (BR-1 stages in flight)
+constexpr int BAND_TEX = PDEPTH_BAND_TEX;    // window texels of a band group
 constexpr int BAND_CHUNK_BYTES = BAND_TEX * 16;
 constexpr int BAND_STAGE_BYTES = 2 * BAND_CHUNK_BYTES;
 constexpr int BAND_REF_OFF = BR * BAND_STAGE_BYTES;   // 24576 (one DMA instruction per wave and chunk covers 256 texels)
-constexpr int NX_MAX = 64;                  // box texels per pixel: X exchange buffer = 16 KB
+constexpr int NX_MAX = PDEPTH_NX;            // box texels per pixel: X exchange buffer = NX_MAX * 256 B
 constexpr int XPW = NX_MAX / NPG;           // X accumulators per wave
 static_assert(BAND_REF_OFF + 2 * BR * 1024 <= 2 * BUF_BYTES, "band ring must fit the direct-mode window buffers");
-static_assert(NX_MAX * 256 <= (BR - 1) * BAND_STAGE_BYTES, "X exchange buffer must not reach the last ring slot");
+// after the channel loop: [Gram stage = ring slot 0][X exchange buffer over the other slots and the reference ring]
+static_assert(NX_MAX * 256 <= (BR - 1) * BAND_STAGE_BYTES + 2 * BR * 1024, "X exchange buffer does not fit");
 constexpr int SLOTS = (PDEPTH_NTEX + 255) / 256;          // sub-blocks of a window (256 texels each = one DMA pass of the block)
 
 // Wave-wide min / max with a scalar result, for fully active waves: four DPP steps make every row of 16 lanes
@@ -523,7 +533,7 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
             const int ro = p * 4;
             // Stage st = packed planes 2 st and 2 st + 1, except the last stage = the two Gram planes.
             const int gstage = (nchunk + 1) / 2, nstage = gstage + 1;
-            const int shift = (BR - 1) - (nstage - 1) % BR;  // the last stage lands in ring slot BR-1
+            const int shift = (BR - (nstage - 1) % BR) % BR;  // the last stage lands in ring slot 0
             auto stage = [&](int st) {
                 const int q = (st + shift) % BR;
 #pragma unroll
@@ -593,9 +603,9 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
             }
             // Every stage has landed (the last wait was vmcnt(0)) and was published by the barrier of the last
             // iteration, which every wave reached only after its last channel stage: the Gram planes sit in ring
-            // slot BR-1 and the other slots are free for the X exchange buffer (slot j of every pixel at
+            // slot 0 and everything behind it is free for the X exchange buffer (slot j of every pixel at
             // xb + j*256 + lane*4).
-            const int xb = win_lds0 + lane * 4;
+            const int xb = win_lds0 + BAND_STAGE_BYTES + lane * 4;
 #pragma unroll
             for (int m = 0; m < XPW; ++m) {
                 const int j = pgl + NPG * m;
@@ -603,7 +613,7 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
             }
             lds_barrier();
             // combine: wave w takes planes ks + w, ks + w + 4, ...; Gram planes (N, H, V, D1) and (D2, -, -, -)
-            const int g4b = win_lds0 + (BR - 1) * BAND_STAGE_BYTES, g1b = g4b + BAND_CHUNK_BYTES;
+            const int g4b = win_lds0, g1b = g4b + BAND_CHUNK_BYTES;
             int viol = 0;
             for (int k = ks + pgl; k < a.D; k += NPG) {
                 float ix, iy;
