@@ -118,7 +118,8 @@ int pdepth_sweep_dpv_f32(const pdepth_sweep_desc *desc, const pdepth_camera *cam
 /* Bytes of scratch the two sweep entry points need for `desc` (0 for ALGO_DIRECT); the workspace
  * must be 256-byte aligned.  ALGO_AUTO without it returns PDEPTH_E_WORKSPACE.  For ALGO_AUTO it holds
  * one flag per 16x4 tile, 8 work-queue counters and a channel-group-planar copy of the source views
- * plus their Gram planes (B*V*(ceil(C/4)+2)*H*W*16 bytes, written by a pre-pass of every call) -- size it once per shape and reuse it. */
+ * plus their Gram planes (B*V*(ceil(C/4)+2)*H*W*16 bytes, written by a pre-pass of every call) -- size it once per shape and reuse it.  A call
+ * rewrites all of it: do not share one workspace between calls that may run concurrently (different streams). */
 size_t pdepth_sweep_workspace_bytes(const pdepth_sweep_desc *desc);
 
 /*
