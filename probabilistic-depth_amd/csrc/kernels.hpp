@@ -37,7 +37,10 @@ int sweep_direct_max_planes(int C);
 // sweep_tiled.hip
 size_t sweep_tiled_workspace_bytes(int B, int V, int C, int H, int W);
 int sweep_tiled_max_planes();
-hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t stream);
+hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t stream);      // picks a variant
+hipError_t launch_sweep_tiled_n1(const SweepArgs& a, void* workspace, hipStream_t stream);   // one 16x4 tile per block
+hipError_t launch_sweep_tiled_n2(const SweepArgs& a, void* workspace, hipStream_t stream);   // two tiles per block
+hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t stream);          // pre-pass of both
 
 // dpv.hip
 hipError_t launch_dpv_reduce(const float* logits, const float* d_candi, int B, int D, int H,

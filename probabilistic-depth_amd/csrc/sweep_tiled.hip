@@ -18,7 +18,10 @@
 //             work items from a per-XCD queue counter in the workspace, so the per-block setup (depth candidates
 //             to LDS, suffix min/max) and the launch cost are paid once per block instead of once per tile (-3.5 %);
 //             when the grid covers all items anyway (small problems) block i just takes item i, no atomics;
-//   block   = 16x4 reference pixels x 4 waves = 256 threads; every wave holds the same 64 pixels (lane = pixel).
+//   block   = NSUB tiles of 16x4 reference pixels, side by side, x 4 waves each; the 4 waves of a tile hold the same
+//             64 pixels (lane = pixel).  NSUB = 1: 256 threads, 3 blocks per CU.  NSUB = 2: 512 threads, 2 blocks
+//             per CU (16 instead of 12 waves); the two tiles share band decision, window search, staged windows
+//             and barriers, and keep their own geometry, X, costs and epilogue.
 //             Direct group: wave w owns KP = 4 (or 2, 1) consecutive planes of a group of 16 (8, 4); their
 //             geometry (LDS tap address + 4 weights) lives in registers, computed once per (pixel, plane, view).
 //             (8 planes per wave and groups of 32 were measured: +28 VGPRs, and slower on every configuration
@@ -56,16 +59,22 @@ namespace pdepth {
 
 namespace {
 
-constexpr int TW = 16, TH = 4;    // tile (pixels); one wave covers it
-constexpr int NPG = 4;            // plane groups per block (= waves)
+#ifndef PDEPTH_NSUB
+#define PDEPTH_NSUB 1
+#endif
+constexpr int TW = 16, TH = 4;    // sub-tile (pixels); one wave covers it
+constexpr int NSUB = PDEPTH_NSUB; // sub-tiles per block, side by side: they share decision, windows, staging, barriers
+constexpr int NPG = 4;            // plane groups (= waves) per sub-tile
+constexpr int NW = NPG * NSUB;    // waves per block
+constexpr int NT = 64 * NW;       // threads per block
 constexpr int KP = 4;             // planes per group
 constexpr int SG = NPG * KP;      // planes per super group
 constexpr int NBUF = 2;           // LDS window buffers: chunk ch+1 is in flight (LDS-DMA) while chunk ch is computed
 #ifndef PDEPTH_NTEX   // experiment knobs (tools/variants.sh): window texels per buffer, blocks per CU
-#define PDEPTH_NTEX 1024
+#define PDEPTH_NTEX (PDEPTH_NSUB == 1 ? 1024 : 1216)
 #endif
-#ifndef PDEPTH_OCC
-#define PDEPTH_OCC 3
+#ifndef PDEPTH_OCC   // waves per SIMD the register allocation must allow (second argument of __launch_bounds__)
+#define PDEPTH_OCC (PDEPTH_NSUB == 1 ? 3 : 4)
 #endif
 constexpr int NTEX_MAX = PDEPTH_NTEX;    // window texels per buffer (LDS: NTEX_MAX*NBUF*16 B = 32 KB)
 constexpr int BUF_BYTES = NTEX_MAX * 16;   // one window buffer of the direct groups
@@ -76,25 +85,27 @@ constexpr int BUF_BYTES = NTEX_MAX * 16;   // one window buffer of the direct gr
 // and, once the channel loop is done, the last stage -- the two Gram planes -- sits in ring slot 0 and everything
 // behind it (the other slots and the reference ring) holds the X exchange buffer (NX_MAX slots of 256 B).
 #ifndef PDEPTH_BR
-#define PDEPTH_BR 3
+#define PDEPTH_BR (PDEPTH_NSUB == 1 ? 3 : 2)
 #endif
 #ifndef PDEPTH_BAND_TEX
-#define PDEPTH_BAND_TEX 256
+#define PDEPTH_BAND_TEX (PDEPTH_NSUB == 1 ? 256 : 448)
 #endif
 #ifndef PDEPTH_NX
-#define PDEPTH_NX 64
+#define PDEPTH_NX (PDEPTH_NSUB == 1 ? 64 : 48)
 #endif
 constexpr int BR = PDEPTH_BR;               // ring depth in stages (BR-1 stages in flight)
 constexpr int BAND_TEX = PDEPTH_BAND_TEX;    // window texels of a band group
 constexpr int BAND_CHUNK_BYTES = BAND_TEX * 16;
 constexpr int BAND_STAGE_BYTES = 2 * BAND_CHUNK_BYTES;
 constexpr int BAND_REF_OFF = BR * BAND_STAGE_BYTES;   // 24576 (one DMA instruction per wave and chunk covers 256 texels)
+constexpr int BAND_REF_CHUNK = 1024 * NSUB;           // reference features of one chunk: [NSUB][4 channels][64 pixels]
 constexpr int NX_MAX = PDEPTH_NX;            // box texels per pixel: X exchange buffer = NX_MAX * 256 B
-constexpr int XPW = NX_MAX / NPG;           // X accumulators per wave
-static_assert(BAND_REF_OFF + 2 * BR * 1024 <= 2 * BUF_BYTES, "band ring must fit the direct-mode window buffers");
+constexpr int XPW = (NX_MAX + NPG - 1) / NPG;  // X accumulators per wave
+static_assert(BAND_REF_OFF + 2 * BR * BAND_REF_CHUNK <= 2 * BUF_BYTES, "band ring must fit the direct-mode window buffers");
 // after the channel loop: [Gram stage = ring slot 0][X exchange buffer over the other slots and the reference ring]
-static_assert(NX_MAX * 256 <= (BR - 1) * BAND_STAGE_BYTES + 2 * BR * 1024, "X exchange buffer does not fit");
-constexpr int SLOTS = (PDEPTH_NTEX + 255) / 256;          // sub-blocks of a window (256 texels each = one DMA pass of the block)
+static_assert(BAND_STAGE_BYTES + NSUB * NX_MAX * 256 <= 2 * BUF_BYTES, "X exchange buffer does not fit");
+static_assert(BAND_TEX <= NT, "one window DMA instruction per wave and chunk");
+constexpr int SLOTS = (NTEX_MAX + NT - 1) / NT;          // sub-blocks of a window (256 texels each = one DMA pass of the block)
 
 // Wave-wide min / max with a scalar result, for fully active waves: four DPP steps make every row of 16 lanes
 // uniform (xor 1, xor 2, mirror within 8, mirror within 16), the four rows are combined on the scalar unit.
@@ -161,24 +172,37 @@ __device__ __forceinline__ T cold_arg(size_t offset) {
 }
 #define PDEPTH_COLD_ARG(type, field) cold_arg<type>(offsetof(SweepArgs, field))
 
+// The file is compiled twice (Makefile): PDEPTH_NSUB = 1 (one 16x4 tile per block; also defines the shared
+// pre-pass and workspace helpers) and PDEPTH_NSUB = 2 (two tiles side by side per block).  Each variant keeps its
+// kernel in its own namespace; launch_sweep_tiled() (first variant) picks one per call.
+#define PDEPTH_CAT_(a, b) a##b
+#define PDEPTH_CAT(a, b) PDEPTH_CAT_(a, b)
+#define PDEPTH_VARIANT PDEPTH_CAT(tiled_n, PDEPTH_NSUB)
+namespace PDEPTH_VARIANT {
+
 template <int METRIC>
-__global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a, const float4* __restrict__ packed,
+__global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a, const float4* __restrict__ packed,
                                                               int* __restrict__ tile_flags, int* __restrict__ queue,
                                                               int tiles_x, int ntile) {
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
     float4* win = lds4;                                   // [NBUF][NTEX_MAX]
-    float* reft = reinterpret_cast<float*>(lds4 + NBUF * NTEX_MAX);  // [NBUF][4 channels][64 pixels]
-    float* costs = reft + NBUF * 256;                     // [D][64]
-    float* red = costs + (size_t)a.D * 64;                // [NPG][64]
-    float* dcl = red + NPG * 64;                          // [D] depth candidates (read wave-uniformly, per plane)
+    float* reft = reinterpret_cast<float*>(lds4 + NBUF * NTEX_MAX);  // [NBUF][NSUB][4 channels][64 pixels]
+    float* costs_all = reft + NBUF * NSUB * 256;          // [NSUB][D][64]
+    float* red_all = costs_all + (size_t)NSUB * a.D * 64; // [NSUB][NPG][64]
+    float* dcl = red_all + NW * 64;                       // [D] depth candidates (read wave-uniformly, per plane)
     float* dlo = dcl + a.D;                               // [D/16 + 1] min of d_candi[16 j .. D)
     float* dhi = dlo + (a.D / 16 + 1);                    // [D/16 + 1] max of d_candi[16 j .. D)
-    __shared__ int s_bbox[2][NPG][4];  // per-wave bounding boxes of window_of(), double buffered by call parity
+    __shared__ int s_bbox[2][NW][4];   // per-wave bounding boxes of window_of(), double buffered by call parity
+    __shared__ int s_dec[2][NW][8];    // per-wave band-decision values (NSUB > 1: the sub-tiles see different pixels)
     __shared__ int s_item[2];          // work item of this block: current / prefetched next
-    int bbox_parity = 0;
+    int bbox_parity = 0, dec_parity = 0;
 
     const int tid = threadIdx.x;
-    const int pgl = __builtin_amdgcn_readfirstlane(tid >> 6);  // plane group of this wave (wave-uniform)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform
+    const int sub = wave / NPG;      // sub-tile of this wave
+    const int pgl = wave % NPG;      // plane group of this wave within its sub-tile
+    float* costs = costs_all + (size_t)sub * a.D * 64;    // [D][64] of this sub-tile
+    float* red = red_all + sub * NPG * 64;                // [NPG][64] of this sub-tile
     const int lane = tid & 63;       // pixel of the tile
     const int lx = lane & 15, ly = lane >> 4;
     // Persistent blocks: the grid is sized to fill the chip once and every block pulls (tile, batch item) work
@@ -194,7 +218,7 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
     const int HW = a.H * a.W;
     const int nchunk = (a.C + 3) / 4;
     const float half_w = (float)a.W / 2.0f, half_h = (float)a.H / 2.0f;
-    for (int k = tid; k < a.D; k += 256) dcl[k] = a.d_candi[k];
+    for (int k = tid; k < a.D; k += NT) dcl[k] = a.d_candi[k];
     __syncthreads();
     {   // suffix min / max of the depth candidates per 16 planes: one wave, 16 lanes per segment
         const int nseg = a.D / 16 + 1;
@@ -204,13 +228,13 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
                 float lo = (seg < nseg && k < a.D) ? dcl[k] : INFINITY, hi = (seg < nseg && k < a.D) ? dcl[k] : -INFINITY;
 #pragma unroll
                 for (int sh = 8; sh >= 1; sh >>= 1) { lo = fminf(lo, __shfl_xor(lo, sh)); hi = fmaxf(hi, __shfl_xor(hi, sh)); }
-                if ((tid & 15) == 0 && seg < nseg) { red[seg] = lo; red[64 + seg] = hi; }  // (red: free scratch here)
+                if ((tid & 15) == 0 && seg < nseg) { red_all[seg] = lo; red_all[64 + seg] = hi; }  // (free scratch here)
             }
         }
         __syncthreads();
         if (tid < nseg) {
             float lo = INFINITY, hi = -INFINITY;
-            for (int j = tid; j < nseg; ++j) { lo = fminf(lo, red[j]); hi = fmaxf(hi, red[64 + j]); }
+            for (int j = tid; j < nseg; ++j) { lo = fminf(lo, red_all[j]); hi = fmaxf(hi, red_all[64 + j]); }
             dlo[tid] = lo; dhi[tid] = hi;
         }
         __syncthreads();
@@ -227,7 +251,7 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
             const int band_rows = qq / tiles_x;
             tile_ = (xcd * band_rows + ti % band_rows) * tiles_x + ti / band_rows;
         }
-        const int x = (tile_ % tiles_x) * TW + lx, y = (tile_ / tiles_x) * TH + ly;
+        const int x = (tile_ % tiles_x) * (TW * NSUB) + sub * TW + lx, y = (tile_ / tiles_x) * TH + ly;
         live_ = x < a.W && y < a.H;
         p_ = live_ ? y * a.W + x : (min(y, a.H - 1) * a.W + min(x, a.W - 1));
     };
@@ -243,6 +267,12 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
     if (tid == 0) s_item[item_par ^ 1] = queued ? atomicAdd(&queue[xcd], 1) : nitems;  // next item; published by any later barrier
     int b, tile, p; bool live;
     map_item(item, b, tile, live, p);
+    // the gather kernel's flags are per 16x4 tile: this wave's sub-tile (if it lies in the image at all)
+    auto flag_subtile = [&]() {
+        const int tiles16_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+        const int tx16 = (tile % tiles_x) * NSUB + sub, ty = tile / tiles_x;
+        if (tx16 < tiles16_x) tile_flags[b * tiles16_x * tiles_y + ty * tiles16_x + tx16] = 1;
+    };
 
     const float cx = a.cxcy[b * 2 + 0], cy = a.cxcy[b * 2 + 1];
     const float rcx = refined_rcp(cx), rcy = refined_rcp(cy);
@@ -289,11 +319,37 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
                 const bool ok = denl * denh > 0.0f && big < 1.0e6f;  // false for NaN as well
                 const int x0 = (int)floorf(fminf(ixl, ixh) - 1e-3f), x1 = (int)floorf(fmaxf(ixl, ixh) + 1e-3f) + 1;
                 const int y0 = (int)floorf(fminf(iyl, iyh) - 1e-3f), y1 = (int)floorf(fmaxf(iyl, iyh) + 1e-3f) + 1;
-                if (__builtin_amdgcn_ballot_w64(ok) != ~0ull) continue;  // some pixel crosses the pole / leaves the range
-                const int nc = wave_max_s(x1 - x0 + 1), nr = wave_max_s(y1 - y0 + 1);
-                if (nc * nr > NX_MAX) continue;
-                const int wx0_ = wave_min_s(x0), wy0_ = wave_min_s(y0);
-                const int wc_ = wave_max_s(x0) + nc - wx0_, wr_ = wave_max_s(y0) + nr - wy0_;
+                int nc, nr, wx0_, wy0_, wc_, wr_;
+                if (NSUB == 1) {  // every wave sees the same 64 pixels: no exchange needed
+                    if (__builtin_amdgcn_ballot_w64(ok) != ~0ull) continue;  // some pixel crosses the pole / leaves the range
+                    nc = wave_max_s(x1 - x0 + 1); nr = wave_max_s(y1 - y0 + 1);
+                    if (nc * nr > NX_MAX) continue;
+                    wx0_ = wave_min_s(x0); wy0_ = wave_min_s(y0);
+                    wc_ = wave_max_s(x0) + nc - wx0_; wr_ = wave_max_s(y0) + nr - wy0_;
+                } else {          // combine the sub-tiles through LDS (one barrier per trial, double buffered)
+                    int (*sd)[8] = s_dec[dec_parity];
+                    dec_parity ^= 1;
+                    const int okw = __builtin_amdgcn_ballot_w64(ok) == ~0ull ? 1 : 0;
+                    const int v1 = wave_max_s(ok ? x1 - x0 + 1 : 0), v2 = wave_max_s(ok ? y1 - y0 + 1 : 0);
+                    const int v3 = wave_min_s(ok ? x0 : 0), v4 = wave_min_s(ok ? y0 : 0);
+                    const int v5 = wave_max_s(ok ? x0 : 0), v6 = wave_max_s(ok ? y0 : 0);
+                    if (lane == 0) {
+                        sd[wave][0] = okw; sd[wave][1] = v1; sd[wave][2] = v2; sd[wave][3] = v3; sd[wave][4] = v4;
+                        sd[wave][5] = v5; sd[wave][6] = v6;
+                    }
+                    __syncthreads();
+                    int allok = 1, xmax = INT_MIN, ymax = INT_MIN;
+                    nc = 0; nr = 0; wx0_ = INT_MAX; wy0_ = INT_MAX;
+#pragma unroll
+                    for (int w2 = 0; w2 < NW; w2 += NPG) {  // one representative wave per sub-tile
+                        allok &= sd[w2][0];
+                        nc = max(nc, sd[w2][1]); nr = max(nr, sd[w2][2]);
+                        wx0_ = min(wx0_, sd[w2][3]); wy0_ = min(wy0_, sd[w2][4]);
+                        xmax = max(xmax, sd[w2][5]); ymax = max(ymax, sd[w2][6]);
+                    }
+                    if (!allok || nc * nr > NX_MAX) continue;
+                    wc_ = xmax + nc - wx0_; wr_ = ymax + nr - wy0_;
+                }
                 if (wc_ * wr_ <= BAND_TEX) {
                     ks = kc; bbx0 = x0; bby0 = y0; NC = nc; NR = nr;
                     gwx0 = wx0_; gwy0 = wy0_; gWC = wc_; gWR = wr_;
@@ -362,12 +418,14 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
                 // passed the barrier of the previous call since
                 int (*sb)[4] = s_bbox[bbox_parity];
                 bbox_parity ^= 1;
-                if (lane == 0) { sb[pgl][0] = bx0; sb[pgl][1] = by0; sb[pgl][2] = bx1; sb[pgl][3] = by1; }
+                if (lane == 0) { sb[wave][0] = bx0; sb[wave][1] = by0; sb[wave][2] = bx1; sb[wave][3] = by1; }
                 __syncthreads();
-                wx0 = min(min(sb[0][0], sb[1][0]), min(sb[2][0], sb[3][0]));
-                wy0 = min(min(sb[0][1], sb[1][1]), min(sb[2][1], sb[3][1]));
-                wx1 = max(max(sb[0][2], sb[1][2]), max(sb[2][2], sb[3][2]));
-                wy1 = max(max(sb[0][3], sb[1][3]), max(sb[2][3], sb[3][3]));
+                wx0 = INT_MAX; wy0 = INT_MAX; wx1 = INT_MIN; wy1 = INT_MIN;
+#pragma unroll
+                for (int w2 = 0; w2 < NW; ++w2) {
+                    wx0 = min(wx0, sb[w2][0]); wy0 = min(wy0, sb[w2][1]);
+                    wx1 = max(wx1, sb[w2][2]); wy1 = max(wy1, sb[w2][3]);
+                }
                 empty = wx0 > wx1;  // every sample of these planes is fully out of bounds
                 if (empty) { wx0 = 0; wx1 = 0; wy0 = 0; wy1 = 0; }
                 WC = ((wx1 - wx0 + 2) + 15) & ~15;  // +1 east tap, pitch multiple of 16
@@ -385,8 +443,8 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
                 for (int part = 0; part < nsplit && fits && k0 + part * NPG * per < kend; ++part)
                     fits = window_of(part * per, per);
                 if (fits) break;
-                if (nsplit == 4) {  // block-uniform: leave the tile to the gather kernel
-                    if (tid == 0) tile_flags[b * ntile + tile] = 1;
+                if (nsplit == 4) {  // block-uniform: leave the tile (all its sub-tiles) to the gather kernel
+                    if (lane == 0 && pgl == 0) flag_subtile();
                     goto tile_done;
                 }
                 nsplit *= 2;
@@ -414,7 +472,7 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
             int so[SLOTS];
 #pragma unroll
             for (int sl = 0; sl < SLOTS; ++sl) {
-                const int tl = sl * 256 + tid;
+                const int tl = sl * NT + tid;
                 // floor(tl / WC): (tl + 0.5) / WC is at least 0.5 / WC away from an integer, far more than the
                 // rounding error of the product for tl < 4096
                 const int row = (int)(((float)tl + 0.5f) * __builtin_amdgcn_rcpf((float)WC)), col = tl - row * WC;
@@ -424,16 +482,16 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
             }
             // reference features: wave w moves channel 4*ch + w of the tile's 64 pixels
             const int ro = p * 4;
-            const unsigned win_lds = lds_addr_of(win + pgl * 64), ref_lds = lds_addr_of(reft + pgl * 64);
+            const unsigned win_lds = lds_addr_of(win + wave * 64), ref_lds = lds_addr_of(reft + (sub * NPG + pgl) * 64);
             auto stage = [&](int bufi, int ch) {
                 const int soff = ch * HW * 16;
 #pragma unroll
                 for (int sl = 0; sl < SLOTS; ++sl)
-                    if (sl * 256 + pgl * 64 < WC * WR)  // wave-uniform: this wave's 64 texels are part of the window
-                        dma_b128(src_rsrc, win_lds + (bufi * NTEX_MAX + sl * 256) * 16, so[sl], soff);
+                    if (sl * NT + wave * 64 < WC * WR)  // wave-uniform: this wave's 64 texels are part of the window
+                        dma_b128(src_rsrc, win_lds + (bufi * NTEX_MAX + sl * NT) * 16, so[sl], soff);
                 const int c = ch * 4 + pgl;
                 // channels beyond C: out of range => zeros (the packed source is zero padded as well)
-                dma_b32(ref_rsrc, ref_lds + bufi * 1024, c < a.C ? ro : 0x7fffffff, c < a.C ? c * HW * 4 : 0);
+                dma_b32(ref_rsrc, ref_lds + bufi * (NSUB * 1024), c < a.C ? ro : 0x7fffffff, c < a.C ? c * HW * 4 : 0);
             };
             // Iteration ch: wait until this wave's DMA of chunk ch has landed, barrier (=> every wave's part of
             // chunk ch is in LDS and every wave is done reading chunk ch-1), re-fill the buffer of chunk ch-1
@@ -483,7 +541,7 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
                     // (plane slots of a part and the buffer are compile-time constants in every instantiation)
 #define PDEPTH_CHUNK(CUR)                                                                           \
     {                                                                                               \
-        const float* rp = reft + CUR * 256 + lane;                                                  \
+        const float* rp = reft + CUR * (NSUB * 256) + sub * 256 + lane;                             \
         const float4 rf = make_float4(rp[0], rp[64], rp[128], rp[192]);                             \
         if (per == 4) PDEPTH_COMPUTE(4, 0)                                                          \
         else if (per == 2) { if (part == 0) PDEPTH_COMPUTE(2, 0) else PDEPTH_COMPUTE(2, 2) }        \
@@ -529,7 +587,7 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
             const int tgx = gwx0 + tcol, tgy = gwy0 + trow;
             const bool tin = tid < WCW && tgx >= 0 && tgx < a.W && tgy >= 0 && tgy < a.H;
             const int so = tin ? (tgy * a.W + tgx) * 16 : 0x7fffffff;
-            const bool has_win = pgl * 64 < WCW;  // wave-uniform
+            const bool has_win = wave * 64 < WCW;  // wave-uniform
             const int ro = p * 4;
             // Stage st = packed planes 2 st and 2 st + 1, except the last stage = the two Gram planes.
             const int gstage = (nchunk + 1) / 2, nstage = gstage + 1;
@@ -541,11 +599,11 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
                     const int pl = st == gstage ? nchunk + hlf : 2 * st + hlf;  // packed plane
                     const bool feat = st < gstage && pl < nchunk;              // a channel group (else Gram / nothing)
                     if (has_win)
-                        dma_b128(src_rsrc, win_lds0 + q * BAND_STAGE_BYTES + hlf * BAND_CHUNK_BYTES + pgl * 1024,
+                        dma_b128(src_rsrc, win_lds0 + q * BAND_STAGE_BYTES + hlf * BAND_CHUNK_BYTES + wave * 1024,
                                  (feat || st == gstage) ? so : 0x7fffffff, pl * HW * 16);
                     const int c = pl * 4 + pgl;
                     const bool rok = feat && c < a.C;
-                    dma_b32(ref_rsrc, win_lds0 + BAND_REF_OFF + ((2 * st + hlf) % (2 * BR)) * 1024 + pgl * 256,
+                    dma_b32(ref_rsrc, win_lds0 + BAND_REF_OFF + ((2 * st + hlf) % (2 * BR)) * BAND_REF_CHUNK + sub * 1024 + pgl * 256,
                             rok ? ro : 0x7fffffff, rok ? c * HW * 4 : 0);
                 }
             };
@@ -573,11 +631,12 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
                 if (st + BR - 1 < nstage) stage(st + BR - 1);  // into the slot of stage st-1
                 if (st < gstage) {
                     const int qoff = ((st + shift) % BR) * BAND_STAGE_BYTES;
-                    const float* rp0 = reinterpret_cast<const float*>(win) + BAND_REF_OFF / 4 + ((2 * st) % (2 * BR)) * 256 + lane;
+                    const float* rp0 = reinterpret_cast<const float*>(win) + BAND_REF_OFF / 4 +
+                                       ((2 * st) % (2 * BR)) * (BAND_REF_CHUNK / 4) + sub * 256 + lane;
 #pragma unroll
                     for (int hlf = 0; hlf < 2; ++hlf) {
                         if (2 * st + hlf < nchunk) {  // uniform
-                            const float* rp = rp0 + hlf * 256;
+                            const float* rp = rp0 + hlf * (BAND_REF_CHUNK / 4);
                             const float4 rf = make_float4(rp[0], rp[64], rp[128], rp[192]);
                             rr = __builtin_fmaf(rf.x, rf.x, rr); rr = __builtin_fmaf(rf.y, rf.y, rr);
                             rr = __builtin_fmaf(rf.z, rf.z, rr); rr = __builtin_fmaf(rf.w, rf.w, rr);
@@ -605,7 +664,7 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
             // iteration, which every wave reached only after its last channel stage: the Gram planes sit in ring
             // slot 0 and everything behind it is free for the X exchange buffer (slot j of every pixel at
             // xb + j*256 + lane*4).
-            const int xb = win_lds0 + BAND_STAGE_BYTES + lane * 4;
+            const int xb = win_lds0 + BAND_STAGE_BYTES + sub * (NX_MAX * 256) + lane * 4;
 #pragma unroll
             for (int m = 0; m < XPW; ++m) {
                 const int j = pgl + NPG * m;
@@ -648,7 +707,7 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
                 float* o = costs + (size_t)k * 64 + lane;
                 *o = (v == 0) ? (0.0f + c) : (*o + c);
             }
-            if (wave_max_s(viol) != 0 && lane == 0) tile_flags[b * ntile + tile] = 1;  // the gather kernel redoes the tile
+            if (wave_max_s(viol) != 0 && lane == 0) flag_subtile();  // the gather kernel redoes the sub-tile
         }
     }
     __syncthreads();
@@ -669,8 +728,8 @@ __global__ __launch_bounds__(256, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs 
         for (int k = pgl; k < a.D; k += NPG) mw = fmaxf(mw, costs[k * 64 + lane]);
         float sw = 0.0f;
         for (int k = pgl; k < a.D; k += NPG) sw = sw + expf(costs[k * 64 + lane] - mw);
-        float* redm = reft;        // [NPG][64]
-        float* reds = reft + 256;  // [NPG][64]
+        float* redm = reft + sub * 512;        // [NPG][64] of this sub-tile
+        float* reds = reft + sub * 512 + 256;  // [NPG][64]
         redm[pgl * 64 + lane] = mw;
         reds[pgl * 64 + lane] = sw;
         __syncthreads();
@@ -703,6 +762,9 @@ tile_done:
     }  // work items
 }
 
+}  // namespace PDEPTH_VARIANT
+
+#if PDEPTH_NSUB == 1
 // Pre-pass of every call.  NCHW -> channel-group-planar [C/4 + 2][H][W] float4: plane g < C/4 holds channels
 // 4g .. 4g+3 of every texel (channels beyond C are zero) -- what the sweep kernel stages with 16-byte LDS-DMA --
 // and the last two planes hold the Gram terms of the band mode for texel (x, y), with s(.) = 0 outside the image:
@@ -755,15 +817,19 @@ __global__ __launch_bounds__(256) void pack_c4_kernel(const float* __restrict__ 
     o[(size_t)(ngrp + 1) * HW] = make_float4(d2, 0.f, 0.f, 0.f);
 }
 
+#endif  // PDEPTH_NSUB == 1 (pre-pass kernel)
+
 static size_t tiled_lds_bytes(int D) {
-    return (size_t)(NBUF * NTEX_MAX + NBUF * 64) * sizeof(float4) + (size_t)(D + NPG) * 64 * sizeof(float) +
+    return (size_t)(NBUF * NTEX_MAX + NBUF * NSUB * 64) * sizeof(float4) + (size_t)NSUB * (D + NPG) * 64 * sizeof(float) +
            (size_t)(D + 2 * (D / 16 + 1)) * sizeof(float);
 }
 
 // Largest D whose cost tile fits LDS next to the window (2 blocks per CU).
 
+#if PDEPTH_NSUB == 1
 // Largest D whose cost tile fits LDS next to the window buffers (2 blocks per CU).
 int sweep_tiled_max_planes() { return 160; }
+#endif
 
 // workspace head: one flag per (batch item, tile), then the 8 work-queue counters (one per XCD)
 static size_t flag_only_bytes(int B, int H, int W) {
@@ -771,23 +837,42 @@ static size_t flag_only_bytes(int B, int H, int W) {
     return ((size_t)B * tiles * sizeof(int) + 255) & ~(size_t)255;
 }
 static size_t flag_bytes(int B, int H, int W) { return flag_only_bytes(B, H, W) + 256; }
+#if PDEPTH_NSUB == 1
 size_t sweep_tiled_workspace_bytes(int B, int V, int C, int H, int W) {
     return flag_bytes(B, H, W) + (size_t)B * V * ((C + 3) / 4 + 2) * H * W * sizeof(float4);
 }
 
-// Launches the tiled kernel, then the gather kernel on the tiles it flagged.
+// pre-pass of a call: packed source + Gram planes, tile flags and queue counters cleared
+hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t stream) {
+    int* flags = reinterpret_cast<int*>(workspace);
+    float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + flag_bytes(a.B, a.H, a.W));
+    const int HW = a.H * a.W;
+    dim3 pgrid((HW + 255) / 256, a.B * a.V);
+    hipLaunchKernelGGL(pack_c4_kernel, pgrid, dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V, a.C, a.H, a.W, packed,
+                       flags, (int)(flag_bytes(a.B, a.H, a.W) / sizeof(int)));
+    return hipGetLastError();
+}
+
+// Two tiles per block pay off when two such blocks fit a CU (the cost tiles of both sub-tiles live in LDS: D <= 64)
+// and the image is large enough for the wider windows not to dominate; measured on the BASELINE configurations.
 hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t stream) {
-    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    bool two = a.D <= 64 && (long long)a.H * a.W >= 96 * 1024 && a.W >= 128;
+    if (const char* f = getenv("PDEPTH_TILED_VARIANT")) {  // tests: force a variant ("1" / "2"), any shape
+        if (f[0] == '1') two = false;
+        if (f[0] == '2') two = true;
+    }
+    return two ? launch_sweep_tiled_n2(a, workspace, stream) : launch_sweep_tiled_n1(a, workspace, stream);
+}
+#endif
+
+// Launches the pre-pass, this variant's tiled kernel, then the gather kernel on the tiles it flagged.
+hipError_t PDEPTH_CAT(launch_sweep_tiled_n, PDEPTH_NSUB)(const SweepArgs& a, void* workspace, hipStream_t stream) {
+    const int tiles16_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;  // the gather kernel's (and the flags') tiles
+    const int tiles_x = (a.W + TW * NSUB - 1) / (TW * NSUB);                  // this kernel's work items per row
     const int tiles = tiles_x * tiles_y;
     int* flags = reinterpret_cast<int*>(workspace);
     float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + flag_bytes(a.B, a.H, a.W));
-    {
-        const int HW = a.H * a.W;
-        dim3 pgrid((HW + 255) / 256, a.B * a.V);
-        hipLaunchKernelGGL(pack_c4_kernel, pgrid, dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V, a.C, a.H, a.W, packed,
-                           flags, (int)(flag_bytes(a.B, a.H, a.W) / sizeof(int)));
-    }
-    hipError_t e = hipGetLastError();
+    hipError_t e = launch_pack_c4(a, workspace, stream);
     if (e != hipSuccess) return e;
     const size_t lds = tiled_lds_bytes(a.D);
     int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + flag_only_bytes(a.B, a.H, a.W));
@@ -798,24 +883,25 @@ hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t s
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
             n_cu = 256;
     }
-    const int per_cu = (int)((160 * 1024) / (lds + 64));
-    int nblk = n_cu * (per_cu < 1 ? 1 : per_cu > 3 ? 3 : per_cu);
+    const int per_cu = (int)((160 * 1024) / (lds + 640));
+    constexpr int max_per_cu = PDEPTH_OCC * 4 / NW;  // blocks per CU the register budget allows
+    int nblk = n_cu * (per_cu < 1 ? 1 : per_cu > max_per_cu ? max_per_cu : per_cu);
     nblk = (nblk + 7) & ~7;
     const long long full = 8ll * ((tiles + 7) / 8) * a.B;  // one block per item of the largest XCD band, times 8
     if (full <= nblk) nblk = (int)full;
     dim3 grid(nblk);
     if (a.metric == 0) {
-        auto kern = sweep_tiled_kernel<0>;
+        auto kern = PDEPTH_VARIANT::sweep_tiled_kernel<0>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, packed, flags, queue, tiles_x, tiles);
+        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles);
     } else {
-        auto kern = sweep_tiled_kernel<1>;
+        auto kern = PDEPTH_VARIANT::sweep_tiled_kernel<1>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, packed, flags, queue, tiles_x, tiles);
+        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_sweep_direct_flagged(a, flags, tiles_x, tiles, stream);
+    return launch_sweep_direct_flagged(a, flags, tiles16_x, tiles16_x * tiles_y, stream);
 }
 
 }  // namespace pdepth

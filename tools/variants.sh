@@ -1,5 +1,6 @@
 #!/bin/bash
 # time bench.py with each probabilistic-depth_amd/libvariant_*.so swapped in (experiments only)
+# (link a variant from csrc/: capi.o sweep_direct.o <sweep_tiled variant>.o sweep_tiled_n2.o dpv.o warp.o extras.o)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 cp probabilistic-depth_amd/libpdepth_hip.so /tmp/full.so
 for f in probabilistic-depth_amd/libvariant_*.so; do
