@@ -892,11 +892,13 @@ hipError_t PDEPTH_CAT(launch_sweep_tiled_n, PDEPTH_NSUB)(const SweepArgs& a, voi
     dim3 grid(nblk);
     if (a.metric == 0) {
         auto kern = PDEPTH_VARIANT::sweep_tiled_kernel<0>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static size_t lds_set0 = 64 * 1024;  // (the attribute is per kernel and sticky: raise it only when needed)
+        if (lds > lds_set0) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set0 = lds; }
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles);
     } else {
         auto kern = PDEPTH_VARIANT::sweep_tiled_kernel<1>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static size_t lds_set1 = 64 * 1024;
+        if (lds > lds_set1) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set1 = lds; }
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles);
     }
     e = hipGetLastError();
