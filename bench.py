@@ -128,7 +128,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "fused sweep+DPV = pack_c4_kernel (source re-layout pre-pass) + sweep_tiled_kernel", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         # secondary figure of SURVEY 8(d): flops of the direct formulation, 11*D*h*w*V*C per volume,
+                         # against the dense fp32 vector peak (157.3 TFLOP/s); the band mode executes fewer
+                         "algorithmic_tflops": 11.0 * cfg["D"] * cfg["H"] * cfg["W"] * cfg["V"] * cfg["C"] * (hi - lo)
+                                               / (kern_ms * 1e-3) / 1e12,
+                         "fp32_valu_peak_tflops": 157.3},
             "per_rank_kernel_ms": [float(x) for x in allm[:, 1]],
             "gather_fallback_tiles": pdepth_amd._native.fallback_tiles(hi - lo, cfg["H"], cfg["W"]),
         }
