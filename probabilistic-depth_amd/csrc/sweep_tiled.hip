@@ -309,7 +309,9 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
         int NC = 0, NR = 0;       // block-uniform box size
         int gwx0 = 0, gwy0 = 0, gWC = 0, gWR = 0;  // staged window of the band group
         if (METRIC == 0) {
-            for (int kc = 0; kc < a.D; kc += 16) {
+            int t_x0 = 0, t_y0 = 0, t_nc = 0, t_nr = 0, t_wx0 = 0, t_wy0 = 0, t_wc = 0, t_wr = 0;
+            // one candidate: does the band group [kc, D) fit?  (block-uniform result; contains a barrier for NSUB > 1)
+            auto trial = [&](int kc) -> bool {
                 const float dl = dlo[kc >> 4], dh = dhi[kc >> 4];
                 float ixl, iyl, ixh, iyh;
                 plane_sample_pos_fast(xf, t2a, t2b, t2c, dl, cx, cy, rcx, rcy, half_w, half_h, ixl, iyl);
@@ -321,9 +323,9 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
                 const int y0 = (int)floorf(fminf(iyl, iyh) - 1e-3f), y1 = (int)floorf(fmaxf(iyl, iyh) + 1e-3f) + 1;
                 int nc, nr, wx0_, wy0_, wc_, wr_;
                 if (NSUB == 1) {  // every wave sees the same 64 pixels: no exchange needed
-                    if (__builtin_amdgcn_ballot_w64(ok) != ~0ull) continue;  // some pixel crosses the pole / leaves the range
+                    if (__builtin_amdgcn_ballot_w64(ok) != ~0ull) return false;  // some pixel crosses the pole / leaves the range
                     nc = wave_max_s(x1 - x0 + 1); nr = wave_max_s(y1 - y0 + 1);
-                    if (nc * nr > NX_MAX) continue;
+                    if (nc * nr > NX_MAX) return false;
                     wx0_ = wave_min_s(x0); wy0_ = wave_min_s(y0);
                     wc_ = wave_max_s(x0) + nc - wx0_; wr_ = wave_max_s(y0) + nr - wy0_;
                 } else {          // combine the sub-tiles through LDS (one barrier per trial, double buffered)
@@ -347,14 +349,26 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
                         wx0_ = min(wx0_, sd[w2][3]); wy0_ = min(wy0_, sd[w2][4]);
                         xmax = max(xmax, sd[w2][5]); ymax = max(ymax, sd[w2][6]);
                     }
-                    if (!allok || nc * nr > NX_MAX) continue;
+                    if (!allok || nc * nr > NX_MAX) return false;
                     wc_ = xmax + nc - wx0_; wr_ = ymax + nr - wy0_;
                 }
-                if (wc_ * wr_ <= BAND_TEX) {
-                    ks = kc; bbx0 = x0; bby0 = y0; NC = nc; NR = nr;
-                    gwx0 = wx0_; gwy0 = wy0_; gWC = wc_; gWR = wr_;
-                    break;
-                }
+                if (wc_ * wr_ > BAND_TEX) return false;
+                t_x0 = x0; t_y0 = y0; t_nc = nc; t_nr = nr; t_wx0 = wx0_; t_wy0 = wy0_; t_wc = wc_; t_wr = wr_;
+                return true;
+            };
+            auto commit = [&](int kc) {
+                ks = kc; bbx0 = t_x0; bby0 = t_y0; NC = t_nc; NR = t_nr;
+                gwx0 = t_wx0; gwy0 = t_wy0; gWC = t_wc; gWR = t_wr;
+            };
+            // Candidates in the order of their likelihood: [16, D) first (the usual answer); [0, D) only if the box of
+            // [16, D) leaves room (it contains it); later starts only if [16, D) does not fit.
+            const int k1 = a.D > 16 ? 16 : 0;
+            if (trial(k1)) {
+                commit(k1);
+                if (k1 != 0 && NC * NR * 2 <= NX_MAX && trial(0)) commit(0);
+            } else {
+                for (int kc = k1 + 16; kc < a.D; kc += 16)
+                    if (trial(kc)) { commit(kc); break; }
             }
         }
         const int kend = ks;  // planes [0, kend) are evaluated directly
