@@ -218,6 +218,14 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     const int HW = a.H * a.W;
     const int nchunk = (a.C + 3) / 4;
     const float half_w = (float)a.W / 2.0f, half_h = (float)a.H / 2.0f;
+    // cost / sigma with the divide chain of geometry.hpp (bit-identical to the IEEE divide for finite operands in
+    // range); non-finite costs take the real divide so that inf / NaN come out exactly as before
+    const float sigma = a.sigma, rsigma = refined_rcp(a.sigma);
+    auto div_sigma = [&](float v) {
+        float q = div_core(v, sigma, rsigma);
+        if (!(fabsf(v) < 1.0e30f)) q = v / sigma;
+        return q;
+    };
     for (int k = tid; k < a.D; k += NT) dcl[k] = a.d_candi[k];
     __syncthreads();
     {   // suffix min / max of the depth candidates per 16 planes: one wave, 16 lanes per segment
@@ -584,7 +592,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
             for (int i = 0; i < KP; ++i) {
                 if (kpl[i] < kend) {
                     float* o = costs + (size_t)kpl[i] * 64 + lane;  // owned by this thread only
-                    const float c = acc[i] / a.sigma;
+                    const float c = div_sigma(acc[i]);
                     *o = (v == 0) ? (0.0f + c) : (*o + c);
                 }
             }
@@ -717,7 +725,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
                 const float Cq = ee * G00.z + ww * G01.z + ew * (G00.w + D2);  // cross rows: V00, V01, D1 + D2
                 const float Q = (fs * fs) * A + (fn * fn) * B + 2.0f * (fs * fn) * Cq;
                 const float XW = (fs * fe) * X00 + (fs * fw) * X01 + (fn * fe) * X10 + (fn * fw) * X11;
-                const float c = ((Q - 2.0f * XW) + rr) / a.sigma;
+                const float c = div_sigma((Q - 2.0f * XW) + rr);
                 float* o = costs + (size_t)k * 64 + lane;
                 *o = (v == 0) ? (0.0f + c) : (*o + c);
             }
