@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/pdepth.h"
 #include "kernels.hpp"
@@ -50,6 +51,16 @@ pdepth::SweepArgs make_args(const pdepth_sweep_desc* d, const pdepth_camera* cam
     return a;
 }
 
+// Test / A-B hook, read once per process: PDEPTH_SWEEP_IMPL=tiled keeps ALGO_AUTO on the round-1 tiled kernel.
+enum { IMPL_DEFAULT = 0, IMPL_TILED = 1 };
+int sweep_impl() {
+    static const int impl = [] {
+        const char* f = getenv("PDEPTH_SWEEP_IMPL");
+        return (f && f[0] == 't') ? IMPL_TILED : IMPL_DEFAULT;
+    }();
+    return impl;
+}
+
 int launched(hipError_t e, const char* who) {
     if (e != hipSuccess) return fail(PDEPTH_E_LAUNCH, "%s: %s", who, hipGetErrorString(e));
     return PDEPTH_OK;
@@ -79,7 +90,8 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
     pdepth::SweepArgs a = make_args(d, cam, ref, src, d_candi);
     a.cost_out = cost; a.logp_out = logp; a.depth_out = depth;
     // the tiled kernel addresses one view through a 32-bit buffer descriptor (C*H*W*4 bytes < 2^31)
-    if (d->algo == PDEPTH_ALGO_AUTO && d->D <= pdepth::sweep_tiled_max_planes() &&
+    // (the tiled kernels also pack a footprint as two 16-bit coordinates)
+    if (d->algo == PDEPTH_ALGO_AUTO && d->D <= pdepth::sweep_tiled_max_planes() && d->W <= 32767 && d->H <= 32767 &&
         (long long)((d->C + 3) / 4 + 2) * d->H * d->W * 16 < (1ll << 31)) {
         const size_t need = tiled_ws_bytes(d);
         if (!workspace || workspace_bytes < need)
@@ -87,6 +99,9 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
                         "query pdepth_sweep_workspace_bytes()", who, need, workspace_bytes);
         if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0)
             return fail(PDEPTH_E_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
+        // L2: the cell-list kernel (sweep_cells.hip); L1 has no correlation form and stays with the tiled kernel
+        if (d->metric == PDEPTH_METRIC_L2 && d->D <= pdepth::sweep_cells_max_planes() && sweep_impl() != IMPL_TILED)
+            return launched(pdepth::launch_sweep_cells(a, workspace, (hipStream_t)stream), who);
         return launched(pdepth::launch_sweep_tiled(a, workspace, (hipStream_t)stream), who);
     }
     return launched(pdepth::launch_sweep_direct(a, (hipStream_t)stream), who);

@@ -42,6 +42,10 @@ hipError_t launch_sweep_tiled_n1(const SweepArgs& a, void* workspace, hipStream_
 hipError_t launch_sweep_tiled_n2(const SweepArgs& a, void* workspace, hipStream_t stream);   // two tiles per block
 hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t stream);          // pre-pass of both
 
+// sweep_cells.hip (L2 only; same workspace as the tiled kernel)
+int sweep_cells_max_planes();
+hipError_t launch_sweep_cells(const SweepArgs& a, void* workspace, hipStream_t stream);
+
 // dpv.hip
 hipError_t launch_dpv_reduce(const float* logits, const float* d_candi, int B, int D, int H,
                              int W, float* logp, float* depth, hipStream_t stream);
