@@ -84,11 +84,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    # experiments only (tools/variants_cells.sh): PDEPTH_LIB points at a library built with other kernel knobs
+    path = os.environ.get("PDEPTH_LIB") or LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: build the HIP extension first "
+            f"{path} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C probabilistic-depth_amd/csrc)")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     lib.pdepth_abi_version.restype = c_int
     lib.pdepth_last_error.restype = c_char_p
     lib.pdepth_sweep_workspace_bytes.restype = c_size_t

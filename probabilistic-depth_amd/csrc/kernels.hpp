@@ -31,7 +31,7 @@ struct SweepArgs {
 // sweep_direct.hip
 hipError_t launch_sweep_direct(const SweepArgs& a, hipStream_t stream);
 hipError_t launch_sweep_direct_flagged(const SweepArgs& a, const int* tile_flags, int tiles_x, int tiles,
-                                       hipStream_t stream);
+                                       hipStream_t stream, int flag_value = 1);  // runs the tiles whose flag == flag_value
 int sweep_direct_max_planes(int C);
 
 // sweep_tiled.hip
@@ -45,6 +45,10 @@ hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t strea
 // sweep_cells.hip (L2 only; same workspace as the tiled kernel)
 int sweep_cells_max_planes();
 hipError_t launch_sweep_cells(const SweepArgs& a, void* workspace, hipStream_t stream);
+
+// sweep_cells_fast.hip: straight-line instantiation (D = 64 or 128), flags the tiles it leaves to the generic kernel
+hipError_t launch_sweep_cells_fast(const SweepArgs& a, const float4* packed, int* flags, int* queue, int tiles_x, int tiles,
+                                   int n_cu, hipStream_t stream);
 
 // dpv.hip
 hipError_t launch_dpv_reduce(const float* logits, const float* d_candi, int B, int D, int H,

@@ -39,6 +39,7 @@
 // path); the correlation form agrees with direct evaluation to an ulp or two of the cost (tests/test_hip_parity.py).
 #include <hip/hip_runtime.h>
 
+#include "cells_common.hpp"
 #include "geometry.hpp"
 #include "kernels.hpp"
 
@@ -51,95 +52,58 @@ constexpr int NW = 4;           // waves per block
 constexpr int NT = 64 * NW;
 constexpr int NS = 32;          // cell slots per pixel and pass
 constexpr int JS = 16;          // plane steps per lane and window: a window is 4 * JS = 64 planes
-constexpr int WT = 1024;        // window texels per ring buffer
-constexpr int SLOTS = WT / NT;  // DMA instructions per wave, chunk and buffer (64 texels each)
+// Build knobs (tools/variants_cells.sh): blocks per CU the register allocation must allow, window texels per ring
+// buffer, ring depth.  Default: 3 blocks per CU, 53.6 KB of LDS per block.
+#ifndef CELLS_OCC
+#define CELLS_OCC 2
+#endif
+#ifndef CELLS_WT
+#define CELLS_WT (CELLS_OCC >= 3 ? 704 : 1024)
+#endif
+#ifndef CELLS_KEEP_POS
+#define CELLS_KEEP_POS 0
+#endif
+#ifndef CELLS_SETS   // register sets of 4 cells in the channel loop: SETS - 1 groups of reads in flight
+#define CELLS_SETS 2
+#endif
+#ifndef CELLS_NBUF
+#define CELLS_NBUF 3
+#endif
+constexpr int WT = CELLS_WT;     // window texels per ring buffer (multiple of 64)
+constexpr int SETS = CELLS_SETS;
+constexpr int NBUF = CELLS_NBUF; // window ring: chunks ch+1 .. ch+NBUF-1 are in flight while chunk ch is computed
+constexpr int SLOTS = (WT + NT - 1) / NT;  // DMA instructions per wave, chunk and buffer (64 texels each)
 constexpr int BUF_BYTES = WT * 16;
-constexpr int RING_BYTES = 2 * BUF_BYTES;        // two window buffers; aliased by the X dumps [NW][NS][16 px][4]
+constexpr int RING_BYTES = NBUF * BUF_BYTES;     // window buffers; aliased by the X dumps [NW][NS][16 px][4]
 constexpr int DUMP_WAVE_BYTES = NS * 256;
+constexpr int CLIST_WAVE_BYTES = 16 * NS * 4;    // cell lists [16 px][NS] of a wave
 constexpr int GRAMA_OFF = RING_BYTES;            // [WT] float4 (N, H, V, D1)
 constexpr int GRAMB_OFF = GRAMA_OFF + WT * 16;   // [WT] float   D2
-constexpr int DTAB_OFF = GRAMB_OFF + WT * 4;     // [D] depth candidates
+constexpr int REF_OFF = GRAMB_OFF + WT * 4;      // [NBUF][NW][64] reference features of the chunks in flight
+constexpr int DTAB_OFF = REF_OFF + NBUF * NW * 256;  // [D] depth candidates
+static_assert(NS == 32, "the channel loop is written out for 8 groups of 4 cells");
+static_assert(WT % 64 == 0 && SLOTS <= 4, "whole DMA instructions, at most 5 per stage (wait_but)");
 static_assert(NW * DUMP_WAVE_BYTES <= RING_BYTES, "X dumps must fit the window ring");
-static_assert(NW * 16 * NS * 4 <= BUF_BYTES, "cell lists must fit ring buffer 1");
-static_assert(DTAB_OFF + 1024 <= 65536, "packed 16-bit LDS addresses");
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(3))) v4f* lds_v4f;
-typedef const __attribute__((address_space(3))) v4i* lds_v4i;
-typedef const __attribute__((address_space(3))) float* lds_f;
-typedef __attribute__((address_space(3))) float* lds_fw;
-typedef __attribute__((address_space(3))) int* lds_iw;
-
-// ---- DPP helpers ---------------------------------------------------------------------------------------
-#define CELLS_DPP_I(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xf, 0xf, false)
-#define CELLS_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (v)), __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, false))
-constexpr int QP_XOR1 = 0xB1, QP_XOR2 = 0x4E;  // quad_perm [1,0,3,2], [2,3,0,1]
-constexpr int QP_SHR1 = 0x90, QP_SHR2 = 0x44;  // quad_perm [0,0,1,2], [0,1,0,1]
-constexpr int QP_B0 = 0x00, QP_B1 = 0x55, QP_B2 = 0xAA, QP_B3 = 0xFF;  // broadcast lane c of the quad
-
-// Wave-wide min / max with a scalar result (all 64 lanes active): four DPP steps, rows combined on the scalar unit.
-#define CELLS_STEP(OP, ctrl) v = OP(v, __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false))
-__device__ __forceinline__ int wave_min_s(int v) {
-    CELLS_STEP(min, 0xB1); CELLS_STEP(min, 0x4E); CELLS_STEP(min, 0x141); CELLS_STEP(min, 0x140);
-    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-__device__ __forceinline__ int wave_max_s(int v) {
-    CELLS_STEP(max, 0xB1); CELLS_STEP(max, 0x4E); CELLS_STEP(max, 0x141); CELLS_STEP(max, 0x140);
-    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-#undef CELLS_STEP
-
-// ---- LDS-DMA and hand-counted waits (the compiler must not know these loads write LDS; see sweep_tiled.hip) ----
-__device__ __forceinline__ void dma_b128(v4i rsrc, unsigned lds_addr, int voff, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
-}
-__device__ __forceinline__ void dma_b32(v4i rsrc, unsigned lds_addr, int voff, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
-}
-// Everything this wave has issued to vector memory has completed: its LDS-DMA of the chunk, and (known to the
-// compiler, which adds its own wait in front of the first use) the reference feature loaded beside it.
-__device__ __forceinline__ void wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ v4i make_rsrc(const void* base, int bytes) {
-    const unsigned long long p = reinterpret_cast<unsigned long long>(base);
-    v4i r;
-    r.x = (int)(unsigned)p; r.y = (int)(unsigned)(p >> 32) & 0xffff; r.z = bytes; r.w = 0x00020000;
-    return r;
-}
-__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
-    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
-}
-
-// Values the optimiser must re-derive where they are used: without this it hoists dozens of per-plane invariants
-// (addresses, masks, products of kernel arguments) to the top of the kernel and spills them.
-__device__ __forceinline__ int opaque_v(int x) { asm volatile("" : "+v"(x)); return x; }
-__device__ __forceinline__ int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
-
-// A kernel argument used once or twice per tile: re-read from the kernarg segment at the point of use instead of
-// occupying scalar registers for the whole kernel (`a` is the first kernel argument).
-template <typename T>
-__device__ __forceinline__ T cold_arg(size_t offset) {
-    typedef const char __attribute__((address_space(4))) * kptr;
-    typedef const volatile T __attribute__((address_space(4))) * vptr;
-    return *(vptr)((kptr)__builtin_amdgcn_kernarg_segment_ptr() + offset);
-}
-#define CELLS_ARG(type, field) cold_arg<type>(offsetof(SweepArgs, field))
+static_assert(NW * CLIST_WAVE_BYTES <= BUF_BYTES, "cell lists must fit the last ring buffer");
+static_assert(RING_BYTES + 1024 <= 65536, "packed 16-bit LDS addresses of the window taps");
+static_assert(CELLS_OCC * (DTAB_OFF + 512 + 320) <= 160 * 1024, "LDS of CELLS_OCC blocks per CU");
+static_assert(NBUF == 2 || NBUF == 3, "ring depth");
 
 constexpr int KEY_NONE = INT_MIN;  // cell key of a plane without any tap inside the image
 
 }  // namespace
 
 // NWIN = number of 64-plane windows (1: D <= 64, 2: D <= 128); the costs of a lane live in NWIN * 16 registers.
-template <int NWIN>
-__global__ __launch_bounds__(NT, 3) void sweep_cells_kernel(SweepArgs a, const float4* __restrict__ packed,
+// MV = more than one source view: the costs then stay live across the channel loops of the later views (V = 1 has
+// its own instantiation so that they never are).
+// FAST = the straight-line instantiation: D = 64 NWIN exactly and one pass per window and view; a tile that needs
+// more (cell slots, window texels) is flagged 1 and redone by the generic instantiation, which runs on flagged tiles
+// only (only_flagged) and flags what it cannot do either with 2, for the gather kernel.  Straight-line matters: with
+// the uniform guards of the generic code between the steps, hipcc drains lgkmcnt at every join and nothing overlaps.
+template <int NWIN, bool MV, bool FAST>
+__global__ __launch_bounds__(NT, CELLS_OCC) void sweep_cells_kernel(SweepArgs a, const float4* __restrict__ packed,
                                                             int* __restrict__ tile_flags, int* __restrict__ queue,
-                                                            int tiles_x, int ntile) {
+                                                            int tiles_x, int ntile, int only_flagged) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ int s_ex[2][NW][8];  // per-wave values of a block-wide reduction, double buffered by parity
     __shared__ int s_item[2];       // work item of this block: current / next
@@ -153,9 +117,10 @@ __global__ __launch_bounds__(NT, 3) void sweep_cells_kernel(SweepArgs a, const f
     const unsigned lds0 = lds_addr_of(lds_raw);
     float* dtab = reinterpret_cast<float*>(lds_raw + DTAB_OFF);
     const unsigned dump0 = lds0 + wave * DUMP_WAVE_BYTES;  // this wave's X dump (inside the ring)
-    // this wave's cell lists [16 pixels][NS]: in ring buffer 1, which is dead between the block-wide exchange of a
-    // pass (every wave is past its previous plane loop) and the barrier of chunk 0 (after which chunk 1 is staged into it)
-    const unsigned clist0 = lds0 + BUF_BYTES + wave * (16 * NS * 4);
+    // this wave's cell lists [16 pixels][NS]: in the last ring buffer, which is dead between the block-wide exchange
+    // of a pass (every wave is past its previous plane loop) and the barrier of chunk 0 (after which chunk NBUF-1 is
+    // staged into it)
+    const unsigned clist0 = lds0 + (NBUF - 1) * BUF_BYTES + wave * CLIST_WAVE_BYTES;
 
     const int HW = a.H * a.W;
     const int nchunk = (a.C + 3) / 4;
@@ -181,7 +146,12 @@ __global__ __launch_bounds__(NT, 3) void sweep_cells_kernel(SweepArgs a, const f
         __syncthreads();
     }
     int item = queued ? s_item[0] : (int)(blockIdx.x >> 3), item_par = 0;
+#ifdef CELLS_STAMPS
+    unsigned long long stamp_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#endif
     while (item < nitems) {
+        CELLS_STAMP(9)
         if (tid == 0) s_item[item_par ^ 1] = queued ? atomicAdd(&queue[xcd], 1) : nitems;
         const int b = item / band_tiles;
         int tile;
@@ -193,6 +163,13 @@ __global__ __launch_bounds__(NT, 3) void sweep_cells_kernel(SweepArgs a, const f
                 tile = (xcd * band_rows + ti % band_rows) * tiles_x + ti / band_rows;
             }
         }
+        int* const my_flag = tile_flags + (b * ntile + tile);
+        if (!FAST && only_flagged && *my_flag != 1) {  // block-uniform: this tile was done by the fast instantiation
+            __syncthreads();
+            item_par ^= 1;
+            item = s_item[item_par];
+            continue;
+        }
         const int px = (tile % tiles_x) * TW + q, py = (tile / tiles_x) * TH + wave;
         const bool live = px < a.W && py < a.H;
         const int p = min(py, a.H - 1) * a.W + min(px, a.W - 1);
@@ -203,12 +180,13 @@ __global__ __launch_bounds__(NT, 3) void sweep_cells_kernel(SweepArgs a, const f
         const float* rays_ = CELLS_ARG(const float*, rays) + (size_t)b * 3 * HW + p;
         const float r0 = rays_[0], r1 = rays_[HW], r2 = rays_[2 * (size_t)HW];
 
-        float cost[NWIN * JS];  // cost of plane 64 m + 4 j + g at [m * JS + j]
-#pragma unroll
-        for (int i = 0; i < NWIN * JS; ++i) cost[i] = 0.0f;
+        CELLS_STAMP(0)  // tile start: work item, camera, rays
+        // cost of plane 64 m + 4 j + g at [m * JS + j]; first written by the plane loops of view 0 (every plane belongs
+        // to exactly one pass), so for V = 1 no cost register is live across a channel loop
+        float cost[NWIN * JS];
         bool bail = false;  // block-uniform: the tile goes to the gather kernel
 
-        for (int v = 0; v < a.V && !bail; ++v) {
+        for (int v = 0; v < (MV ? a.V : 1) && !bail; ++v) {
             ViewXform xf;
             make_view_xform(CELLS_ARG(const float*, K) + b * 9, CELLS_ARG(const float*, R) + ((size_t)b * a.V + v) * 9,
                             CELLS_ARG(const float*, t) + ((size_t)b * a.V + v) * 3, CELLS_ARG(int, blas_mode), xf);
@@ -216,17 +194,18 @@ __global__ __launch_bounds__(NT, 3) void sweep_cells_kernel(SweepArgs a, const f
             ray_term2(xf, r0, r1, r2, t2a, t2b, t2c);
             const float4* srcv = packed + ((size_t)b * a.V + v) * (nchunk + 2) * HW;
             const v4i src_rsrc = make_rsrc(srcv, (nchunk + 2) * HW * 16);
-            const __amdgpu_buffer_rsrc_t ref_buf = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(CELLS_ARG(const float*, ref) + (size_t)b * CELLS_ARG(long long, ref_bstride)), (short)0, a.C * HW * 4, 0x00020000);
+            const v4i ref_rsrc = make_rsrc(CELLS_ARG(const float*, ref) + (size_t)b * CELLS_ARG(long long, ref_bstride), a.C * HW * 4);
 
 #pragma unroll
             for (int m = 0; m < NWIN; ++m) {
                 const int kw = m * 4 * JS;       // first plane of the window
                 if (kw >= a.D || bail) break;    // uniform
-                const int nstep = min(JS, (a.D - kw + 3) >> 2);  // plane steps of this window
+                const int nstep = FAST ? JS : min(JS, (a.D - kw + 3) >> 2);  // plane steps of this window
 
                 // ---- positions of this lane's planes of the window -----------------------------------
+#if CELLS_KEEP_POS
                 float fx[JS], fy[JS];  // fractional sample position inside the cell
+#endif
                 int ki[JS];            // cell key (y0 << 16 | x0 & 0xffff) or KEY_NONE; later the packed plane info
                 const int gk = opaque_v(kw + g);
 #pragma unroll
@@ -235,35 +214,39 @@ __global__ __launch_bounds__(NT, 3) void sweep_cells_kernel(SweepArgs a, const f
                     float ix, iy;
                     plane_sample_pos_fast(xf, t2a, t2b, t2c, dtab[min(k, a.D - 1)], cx, cy, rcx, rcy, half_w, half_h, ix, iy);
                     const float xfl = floorf(ix), yfl = floorf(iy);
+#if CELLS_KEEP_POS
                     fx[j] = ix - xfl;
                     fy[j] = iy - yfl;
+#endif
                     const int x0 = (int)fminf(fmaxf(xfl, -2.0f), (float)(a.W + 1));
                     const int y0 = (int)fminf(fmaxf(yfl, -2.0f), (float)(a.H + 1));
                     const bool any = live & (k < a.D) & (ix == ix) & (iy == iy) & ((unsigned)(x0 + 1) < (unsigned)(a.W + 1)) &
                                      ((unsigned)(y0 + 1) < (unsigned)(a.H + 1));
                     ki[j] = any ? ((y0 << 16) | (x0 & 0xffff)) : KEY_NONE;
-                    if (j & 1) __builtin_amdgcn_sched_barrier(0);  // two divide chains at a time (register pressure)
+                    if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four divide chains at a time
                 }
 
+                CELLS_STAMP(1)  // positions
                 int jlo = 0;
                 while (jlo < nstep) {  // passes of this window (block-uniform)
                     // ---- scan: cell slot of every plane from step jlo on, bounding box, cut point ----
                     int slot[JS];
                     unsigned newmask = 0;   // bit j: the plane of step j opens a new cell
                     int run = 0, jok = jlo, carry = KEY_NONE;
+                    const int mge1 = opaque_v(g >= 1 ? -1 : 0), mge2 = opaque_v(g >= 2 ? -1 : 0);  // lane masks as values
                     int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN;
 #pragma unroll
                     for (int j = 0; j < JS; ++j) {
                         slot[j] = 0;
-                        if (j >= jlo && j < nstep) {  // uniform
+                        if (FAST || (j >= jlo && j < nstep)) {  // uniform
                             const int key = ki[j];
                             const int left = CELLS_DPP_I(key, QP_SHR1);
-                            const int prev = g == 0 ? carry : left;
-                            const int isn = (key != KEY_NONE && key != prev) ? 1 : 0;
+                            const int prev = (left & mge1) | (carry & ~mge1);
+                            const int isn = ((key != KEY_NONE) & (key != prev)) ? 1 : 0;
                             int s1 = CELLS_DPP_I(isn, QP_SHR1);
-                            s1 = isn + (g >= 1 ? s1 : 0);
+                            s1 = isn + (s1 & mge1);
                             int s2 = CELLS_DPP_I(s1, QP_SHR2);
-                            s2 = s1 + (g >= 2 ? s2 : 0);
+                            s2 = s1 + (s2 & mge2);
                             slot[j] = max(run + s2 - 1, 0);
                             run += CELLS_DPP_I(s2, QP_B3);
                             carry = CELLS_DPP_I(key, QP_B3);
@@ -290,7 +273,7 @@ __global__ __launch_bounds__(NT, 3) void sweep_cells_kernel(SweepArgs a, const f
                         bx0 = INT_MAX; by0 = INT_MAX; bx1 = INT_MIN; by1 = INT_MIN;
 #pragma unroll
                         for (int j = 0; j < JS; ++j) {
-                            if (j >= jlo && j < jhi_ && ki[j] != KEY_NONE) {
+                            if ((FAST || (j >= jlo && j < jhi_)) && ki[j] != KEY_NONE) {
                                 const int y0 = ki[j] >> 16, x0 = (int)(short)(ki[j] & 0xffff);
                                 bx0 = min(bx0, x0); bx1 = max(bx1, x0);
                                 by0 = min(by0, y0); by1 = max(by1, y0);
@@ -319,13 +302,15 @@ __global__ __launch_bounds__(NT, 3) void sweep_cells_kernel(SweepArgs a, const f
                         jhi = jlo + (jhi - jlo) / 2;
                         recompute = true;
                     }
+                    if (FAST && jhi < JS) bail = true;  // more than one pass: leave the tile to the generic instantiation
                     if (bail) break;
+                    CELLS_STAMP(2)  // scan + exchange
 
                     // ---- cell list -> this lane's corner addresses; plane info -------------------------
                     int nc = 0;
 #pragma unroll
                     for (int j = 0; j < JS; ++j) {
-                        if (j >= jlo && j < jhi) {  // uniform
+                        if (FAST || (j >= jlo && j < jhi)) {  // uniform
                             const int key = ki[j];
                             const bool any = key != KEY_NONE;
                             const int y0 = key >> 16, x0 = (int)(short)(key & 0xffff);
@@ -370,19 +355,24 @@ __global__ __launch_bounds__(NT, 3) void sweep_cells_kernel(SweepArgs a, const f
                     }
                     const int wtex = pitch * WR;
                     const unsigned my_lds = lds0 + wave * 1024;  // this wave's 64 texels of every 256-texel slot
+                    const unsigned my_ref = lds0 + REF_OFF + wave * 256;
+                    const int ro = p * 4;
+                    int nd = 0;  // window DMA instructions of this wave per chunk (wave-uniform)
+#pragma unroll
+                    for (int sl = 0; sl < SLOTS; ++sl) nd += (sl * NT + wave * 64 < wtex) ? 1 : 0;
+                    // One stage = the wave's share of the window of chunk ch + its 64 reference features
+                    // (lane (q, g) <- channel 4 ch + g of pixel q; channels beyond C read as 0 like the packed source).
                     auto stage = [&](int bufi, int ch) {
 #pragma unroll
                         for (int sl = 0; sl < SLOTS; ++sl)
                             if (sl * NT + wave * 64 < wtex)  // wave-uniform
+#ifdef CELLS_ABL_NO_DMA   // ablation build: every chunk re-reads plane 0 (L2 resident), results are wrong
+                                dma_b128(src_rsrc, my_lds + bufi * BUF_BYTES + sl * NT * 16, so[sl], 0);
+#else
                                 dma_b128(src_rsrc, my_lds + bufi * BUF_BYTES + sl * NT * 16, so[sl], ch * HW * 16);
-                    };
-                    const int ro = p * 4;
-                    // reference feature (channel 4 ch + g) of the chunk in flight: a load the compiler tracks (an asm
-                    // load's destination register may be copied before the data has landed)
-                    float rnx;
-                    auto fetch_ref = [&](int ch) {
-                        const int c = ch * 4 + g;  // beyond C: 0, like the packed source
-                        rnx = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ref_buf, c < a.C ? ro + c * HW * 4 : 0x7fffffff, 0, 0));
+#endif
+                        const int c = ch * 4 + g;
+                        dma_b32(ref_rsrc, my_ref + bufi * (NW * 256), c < a.C ? ro + c * HW * 4 : 0x7fffffff, 0);
                     };
                     // Every wave is past its previous plane loop (the exchange barrier above): ring and Gram window are free.
                     {   // Gram planes of the window: plane nchunk as float4, .x of plane nchunk + 1 as floats
@@ -394,52 +384,124 @@ __global__ __launch_bounds__(NT, 3) void sweep_cells_kernel(SweepArgs a, const f
                             }
                         }
                     }
-                    fetch_ref(0);
-                    stage(0, 0);
+#pragma unroll
+                    for (int st = 0; st < NBUF - 1; ++st)
+                        if (st < nchunk) stage(st, st);
 
+                    CELLS_STAMP(3)  // cell list, addresses, staging offsets, first DMA
                     float X[NS];
 #pragma unroll
                     for (int i = 0; i < NS; ++i) X[i] = 0.0f;
                     float rr = 0.0f;
 
                     // ---- channel loop ---------------------------------------------------------------------
-#define CELLS_CELL(i_, BUF)                                                                               \
+                    // Groups of 4 cells, two register sets: the reads of group n + 1 are in flight while the 16 fma of
+                    // group n execute (left to itself the compiler issues read, wait, 4 fma per cell).
+#define CELLS_AD(i_) (((i_) & 1) ? (pk_[((i_) >> 1) & 1] >> 16) : (pk_[((i_) >> 1) & 1] & 0xffffu))
+#define CELLS_LOAD4(T, G4, BUF)                                                                           \
     {                                                                                                     \
-        const unsigned ad = ((i_) & 1) ? ((unsigned)addrp[(i_) >> 1] >> 16) : ((unsigned)addrp[(i_) >> 1] & 0xffffu); \
-        const v4f t = *(lds_v4f)(size_t)(ad + (BUF) * BUF_BYTES);                                         \
-        float x_ = X[i_];                                                                                 \
-        x_ = __builtin_fmaf(t.x, rb0, x_); x_ = __builtin_fmaf(t.y, rb1, x_);                             \
-        x_ = __builtin_fmaf(t.z, rb2, x_); x_ = __builtin_fmaf(t.w, rb3, x_);                             \
-        X[i_] = x_;                                                                                       \
+        const unsigned pk_[2] = {(unsigned)opaque_v(addrp[2 * (G4)]), (unsigned)opaque_v(addrp[2 * (G4) + 1])}; \
+        T[0] = *(lds_v4f)(size_t)(CELLS_AD(0) + (BUF) * BUF_BYTES);                                       \
+        T[1] = *(lds_v4f)(size_t)(CELLS_AD(1) + (BUF) * BUF_BYTES);                                       \
+        T[2] = *(lds_v4f)(size_t)(CELLS_AD(2) + (BUF) * BUF_BYTES);                                       \
+        T[3] = *(lds_v4f)(size_t)(CELLS_AD(3) + (BUF) * BUF_BYTES);                                       \
     }
-#define CELLS_CHUNK(BUF)                                                                                  \
-    {                                                                                                     \
+#define CELLS_FMA4(T, G4)                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                       \
+        float x_ = X[4 * (G4) + u];                                                                       \
+        x_ = __builtin_fmaf(T[u].x, rb0, x_); x_ = __builtin_fmaf(T[u].y, rb1, x_);                       \
+        x_ = __builtin_fmaf(T[u].z, rb2, x_); x_ = __builtin_fmaf(T[u].w, rb3, x_);                       \
+        X[4 * (G4) + u] = x_;                                                                             \
+    }
+    // step G4: reads of group G4 + SETS - 1 into the set that the fma of group G4 - 1 released, then the fma of group G4
+#define CELLS_STEP(G4, BUF)                                                                               \
+    if (4 * (G4) < wave_nc) {                                                                             \
+        if (4 * ((G4) + SETS - 1) < wave_nc && (G4) + SETS - 1 < NS / 4)                                  \
+            CELLS_LOAD4(ts[((G4) + SETS - 1) % SETS], ((G4) + SETS - 1 < NS / 4 ? (G4) + SETS - 1 : 0), BUF) \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        CELLS_FMA4(ts[(G4) % SETS], G4)                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    }
+#ifdef CELLS_ABL_NO_X   // ablation build: only the first group of 4 cells is accumulated, results are wrong
+#define CELLS_ABL_REST(BUF)
+#else
+#define CELLS_ABL_REST(BUF)                                                                               \
+        CELLS_STEP(1, BUF) CELLS_STEP(2, BUF) CELLS_STEP(3, BUF) CELLS_STEP(4, BUF) CELLS_STEP(5, BUF)    \
+        CELLS_STEP(6, BUF) CELLS_STEP(7, BUF)
+#endif
+#define CELLS_CHUNK_HEAD(BUF)                                                                             \
+        const float rc = *(lds_f)(size_t)(my_ref + (BUF) * (NW * 256) + lane * 4);                        \
+        v4f ts[SETS][4];                                                                                  \
+        CELLS_LOAD4(ts[0], 0, BUF)
+#define CELLS_CHUNK_R(BUF)                                                                                \
         const float rb0 = CELLS_DPP_F(rc, QP_B0), rb1 = CELLS_DPP_F(rc, QP_B1);                           \
         const float rb2 = CELLS_DPP_F(rc, QP_B2), rb3 = CELLS_DPP_F(rc, QP_B3);                           \
-        rr = __builtin_fmaf(rc, rc, rr);                                                                  \
-        _Pragma("unroll") for (int i8 = 0; i8 < NS; i8 += 8) {                                            \
-            if (i8 < wave_nc) {                                                                           \
-                _Pragma("unroll") for (int u = 0; u < 8; ++u) CELLS_CELL(i8 + u, BUF)                     \
-            }                                                                                             \
-        }                                                                                                 \
+        rr = __builtin_fmaf(rc, rc, rr);
+    // generic: every step guarded by the wave's cell count
+#define CELLS_CHUNK_GENERIC(BUF)                                                                          \
+    {                                                                                                     \
+        CELLS_CHUNK_HEAD(BUF)                                                                             \
+        if (SETS > 2 && 4 < wave_nc) CELLS_LOAD4(ts[1 % SETS], 1, BUF)                                    \
+        if (SETS > 3 && 8 < wave_nc) CELLS_LOAD4(ts[2 % SETS], 2, BUF)                                    \
+        CELLS_CHUNK_R(BUF)                                                                                \
+        CELLS_STEP(0, BUF) CELLS_ABL_REST(BUF)                                                            \
     }
-                    for (int ch = 0; ch < nchunk; ch += 2) {
-                        float rc;
-                        wait_all();
-                        rc = rnx;
-                        lds_barrier();  // chunk ch is in LDS for every wave, everybody is done with chunk ch - 1
-                        if (ch + 1 < nchunk) { fetch_ref(ch + 1); stage(1, ch + 1); }
-                        CELLS_CHUNK(0)
-                        if (ch + 1 < nchunk) {
-                            wait_all();
-                            rc = rnx;
-                            lds_barrier();
-                            if (ch + 2 < nchunk) { fetch_ref(ch + 2); stage(0, ch + 2); }
-                            CELLS_CHUNK(1)
-                        }
+    // straight line for NG4 groups of 4 cells (slots beyond the wave's cell count point at window texel 0)
+#define CELLS_SSTEP(G4, NG4, BUF)                                                                         \
+    if ((G4) < (NG4)) {                                                                                   \
+        if ((G4) + SETS - 1 < (NG4)) CELLS_LOAD4(ts[((G4) + SETS - 1) % SETS], ((G4) + SETS - 1 < NS / 4 ? (G4) + SETS - 1 : 0), BUF) \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        CELLS_FMA4(ts[(G4) % SETS], G4)                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    }
+#define CELLS_CHUNK_STRAIGHT(NG4, BUF)                                                                    \
+    {                                                                                                     \
+        CELLS_CHUNK_HEAD(BUF)                                                                             \
+        if (SETS > 2 && 1 < (NG4)) CELLS_LOAD4(ts[1 % SETS], 1, BUF)                                      \
+        if (SETS > 3 && 2 < (NG4)) CELLS_LOAD4(ts[2 % SETS], 2, BUF)                                      \
+        CELLS_CHUNK_R(BUF)                                                                                \
+        CELLS_SSTEP(0, NG4, BUF) CELLS_SSTEP(1, NG4, BUF) CELLS_SSTEP(2, NG4, BUF) CELLS_SSTEP(3, NG4, BUF) \
+        CELLS_SSTEP(4, NG4, BUF) CELLS_SSTEP(5, NG4, BUF) CELLS_SSTEP(6, NG4, BUF) CELLS_SSTEP(7, NG4, BUF) \
+    }
+#define CELLS_CHUNK(BUF)                                                                                  \
+    if (!FAST) CELLS_CHUNK_GENERIC(BUF)                                                                   \
+    else if (wave_nc <= 8) CELLS_CHUNK_STRAIGHT(2, BUF)                                                   \
+    else if (wave_nc <= 16) CELLS_CHUNK_STRAIGHT(4, BUF)                                                  \
+    else if (wave_nc <= 24) CELLS_CHUNK_STRAIGHT(6, BUF)                                                  \
+    else CELLS_CHUNK_STRAIGHT(8, BUF)
+                    // Iteration ch: wait until this wave's stage ch has landed (younger stages stay in flight), barrier
+                    // (=> chunk ch is in LDS for every wave, and everybody is done with chunk ch - 1), refill the buffer
+                    // of chunk ch - 1 with chunk ch + NBUF - 1, compute chunk ch.  One copy of the compute code per
+                    // buffer, so that the buffer base is an immediate of the ds_read.
+#define CELLS_ITER(U)                                                                                     \
+    if (ch0 + (U) < nchunk) {                                                                             \
+        const int ch = ch0 + (U);                                                                         \
+        wait_but(min(NBUF - 2, nchunk - 1 - ch) * (nd + 1));                                              \
+        CELLS_STAMP(10)                                                                                   \
+        lds_barrier();                                                                                    \
+        CELLS_STAMP(11)                                                                                   \
+        if (ch + NBUF - 1 < nchunk) stage(((U) + NBUF - 1) % NBUF, ch + NBUF - 1);                        \
+        CELLS_STAMP(12)                                                                                   \
+        CELLS_CHUNK(U)                                                                                    \
+        CELLS_STAMP(4)                                                                                    \
+    }
+                    for (int ch0 = 0; ch0 < nchunk; ch0 += NBUF) {
+                        CELLS_ITER(0)
+                        CELLS_ITER(1)
+                        if (NBUF > 2) { CELLS_ITER(NBUF > 2 ? 2 : 0) }
                     }
+#undef CELLS_ITER
 #undef CELLS_CHUNK
-#undef CELLS_CELL
+#undef CELLS_CHUNK_STRAIGHT
+#undef CELLS_SSTEP
+#undef CELLS_CHUNK_GENERIC
+#undef CELLS_CHUNK_R
+#undef CELLS_CHUNK_HEAD
+#undef CELLS_STEP
+#undef CELLS_FMA4
+#undef CELLS_LOAD4
+#undef CELLS_AD
+                    CELLS_STAMP(4)  // channel loop
                     // |r|^2 of the pixel: the quad's four channel residues
                     rr = rr + CELLS_DPP_F(rr, QP_XOR1);
                     rr = rr + CELLS_DPP_F(rr, QP_XOR2);
@@ -449,45 +511,70 @@ __global__ __launch_bounds__(NT, 3) void sweep_cells_kernel(SweepArgs a, const f
                         if (i < wave_nc) *(lds_fw)(size_t)(dump0 + i * 256 + lane * 4) = X[i];
                     lds_wait();
 
+                    CELLS_STAMP(5)  // barrier + dump
                     // ---- plane loop: planes kw + 4 j + g of the steps of this pass --------------------------
                     const unsigned gA = lds0 + GRAMA_OFF, gB = lds0 + GRAMB_OFF;
+                    const int gk2 = opaque_v(kw + g);
+                    // LDS operands of one plane: X of the 4 corners, Gram terms of the cell
+                    struct PlaneOps { v4f Xc, G00, G01, G10; float N11, D2; };
+                    auto fetch = [&](int info) {
+                        const int tex = info & 0x7ff;
+                        const unsigned xa = dump0 + (((unsigned)info >> 11) & 0xfffffu);
+                        PlaneOps o;
+                        o.Xc = *(lds_v4f)(size_t)xa;
+                        o.G00 = *(lds_v4f)(size_t)(gA + tex * 16);
+                        o.G01 = *(lds_v4f)(size_t)(gA + tex * 16 + 16);
+                        o.G10 = *(lds_v4f)(size_t)(gA + (tex + pitch) * 16);
+                        o.N11 = *(lds_f)(size_t)(gA + (tex + pitch) * 16 + 16);
+                        o.D2 = *(lds_f)(size_t)(gB + tex * 4);
+                        return o;
+                    };
+                    // software pipeline: the reads of step j + 1 are in flight while step j is combined
+                    PlaneOps cur = fetch(ki[0]), nxt;
+                    if (!FAST) {
+#pragma unroll
+                        for (int j = 1; j < JS; ++j)
+                            if (j == jlo) cur = fetch(ki[j]);  // uniform
+                    }
+                    nxt = cur;
 #pragma unroll
                     for (int j = 0; j < JS; ++j) {
-                        if (j >= jlo && j < jhi) {  // uniform
-                            const int info = ki[j];
-                            const int tex = info & 0x7ff;
-                            const unsigned xa = dump0 + (((unsigned)info >> 11) & 0xfffffu);
-                            const bool any = info < 0;
+                        if (FAST || (j >= jlo && j < jhi)) {  // uniform
+                            if (j + 1 < JS && (FAST || j + 1 < jhi)) nxt = fetch(ki[j + 1 < JS ? j + 1 : j]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            const bool any = ki[j] < 0;
+#if CELLS_KEEP_POS
                             float fw = fx[j], fe = 1.0f - fw, fn = fy[j], fs = 1.0f - fn;
+#else
+                            // the position is recomputed (its divide chains run in the shadow of the LDS reads): 32
+                            // registers less across the channel loop
+                            float ix, iy;
+                            plane_sample_pos_fast(xf, t2a, t2b, t2c, dtab[min(gk2 + 4 * j, a.D - 1)], cx, cy, rcx, rcy, half_w, half_h, ix, iy);
+                            float fw = ix - floorf(ix), fe = 1.0f - fw, fn = iy - floorf(iy), fs = 1.0f - fn;
+#endif
                             if (!any) { fw = fw * 0.0f; fe = fe * 0.0f; fn = fn * 0.0f; fs = fs * 0.0f; }  // NaN stays NaN, like ATen
-                            const v4f Xc = *(lds_v4f)(size_t)xa;
-                            const v4f G00 = *(lds_v4f)(size_t)(gA + tex * 16);
-                            const v4f G01 = *(lds_v4f)(size_t)(gA + tex * 16 + 16);
-                            const v4f G10 = *(lds_v4f)(size_t)(gA + (tex + pitch) * 16);
-                            const float N11 = *(lds_f)(size_t)(gA + (tex + pitch) * 16 + 16);
-                            const float D2 = *(lds_f)(size_t)(gB + tex * 4);
                             // |sum_t w_t s_t|^2, separable in the x weights (e, w) and the y weights (s, n)
                             const float ee = fe * fe, ww = fw * fw, ew = fe * fw;
-                            const float A = ee * G00.x + ww * G01.x + 2.0f * ew * G00.y;   // top row:    N00, N01, H00
-                            const float B = ee * G10.x + ww * N11 + 2.0f * ew * G10.y;     // bottom row: N10, N11, H10
-                            const float Cq = ee * G00.z + ww * G01.z + ew * (G00.w + D2);  // cross rows: V00, V01, D1 + D2
+                            const float A = ee * cur.G00.x + ww * cur.G01.x + 2.0f * ew * cur.G00.y;   // top row:    N00, N01, H00
+                            const float B = ee * cur.G10.x + ww * cur.N11 + 2.0f * ew * cur.G10.y;     // bottom row: N10, N11, H10
+                            const float Cq = ee * cur.G00.z + ww * cur.G01.z + ew * (cur.G00.w + cur.D2);  // cross rows: V00, V01, D1 + D2
                             const float Q = (fs * fs) * A + (fn * fn) * B + 2.0f * (fs * fn) * Cq;
-                            const float XW = (fs * fe) * Xc.x + (fs * fw) * Xc.y + (fn * fe) * Xc.z + (fn * fw) * Xc.w;
+                            const float XW = (fs * fe) * cur.Xc.x + (fs * fw) * cur.Xc.y + (fn * fe) * cur.Xc.z + (fn * fw) * cur.Xc.w;
                             const float c = div_sigma((Q - 2.0f * XW) + rr);
                             float& o = cost[m * JS + j];
-                            o = (v == 0) ? (0.0f + c) : (o + c);
+                            o = (!MV || v == 0) ? (0.0f + c) : (o + c);
+                            cur = nxt;
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                     jlo = jhi;
+                    CELLS_STAMP(6)  // plane loop
                 }  // passes
             }      // windows
         }          // views
 
         if (bail) {
-            if (tid == 0) {
-                const int tiles_y = (a.H + TH - 1) / TH;
-                tile_flags[b * tiles_x * tiles_y + tile] = 1;
-            }
+            if (tid == 0) *my_flag = FAST ? 1 : 2;
         } else {
             // ---- epilogue from registers: cost store, log-softmax over D, expectation --------------------
             const size_t obase = (size_t)b * a.D * HW + p;
@@ -511,34 +598,44 @@ __global__ __launch_bounds__(NT, 3) void sweep_cells_kernel(SweepArgs a, const f
                 }
                 mx = fmaxf(mx, CELLS_DPP_F(mx, QP_XOR1));
                 mx = fmaxf(mx, CELLS_DPP_F(mx, QP_XOR2));
-                float ssum = 0.0f;
-#pragma unroll
-                for (int i = 0; i < NWIN * JS; ++i) {
-                    const int k = (i / JS) * 4 * JS + (i % JS) * 4 + ge;
-                    if (k < a.D) ssum = ssum + expf(cost[i] - mx);
-                }
-                ssum = ssum + CELLS_DPP_F(ssum, QP_XOR1);
-                ssum = ssum + CELLS_DPP_F(ssum, QP_XOR2);
-                const float ls = logf(ssum);
-                float e = 0.0f;
+                // p_k = e_k / s with e_k = exp(c_k - max): one exp per plane; log p_k = (c_k - max) - log s
+                float ssum = 0.0f, esum = 0.0f;
 #pragma unroll
                 for (int i = 0; i < NWIN * JS; ++i) {
                     const int k = (i / JS) * 4 * JS + (i % JS) * 4 + ge;
                     if (k < a.D) {
-                        const float lp = (cost[i] - mx) - ls;
-                        if (logp_out && live) logp_out[obase + (size_t)k * HW] = lp;
-                        e = e + dtab[k] * expf(lp);
+                        const float ek = expf(cost[i] - mx);
+                        ssum = ssum + ek;
+                        esum = __builtin_fmaf(dtab[k], ek, esum);
+                    }
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+                ssum = ssum + CELLS_DPP_F(ssum, QP_XOR1);
+                ssum = ssum + CELLS_DPP_F(ssum, QP_XOR2);
+                esum = esum + CELLS_DPP_F(esum, QP_XOR1);
+                esum = esum + CELLS_DPP_F(esum, QP_XOR2);
+                const float ls = logf(ssum);
+                if (logp_out && live) {
+#pragma unroll
+                    for (int i = 0; i < NWIN * JS; ++i) {
+                        const int k = (i / JS) * 4 * JS + (i % JS) * 4 + ge;
+                        if (k < a.D) logp_out[obase + (size_t)k * HW] = (cost[i] - mx) - ls;
                     }
                 }
-                e = e + CELLS_DPP_F(e, QP_XOR1);
-                e = e + CELLS_DPP_F(e, QP_XOR2);
+                const float e = esum / ssum;
                 if (depth_out && live && g == 0) depth_out[(size_t)b * HW + p] = e;
             }
         }
+        CELLS_STAMP(7)  // epilogue
         __syncthreads();  // s_item of the next round is visible; nobody still reads this tile's LDS state
         item_par ^= 1;
         item = s_item[item_par];
+        CELLS_STAMP(8)  // end-of-tile barrier
     }
+#ifdef CELLS_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 13; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(queue + 16) + i, stamp_acc[i]);
+#endif
 }
 
 // ---- host side -------------------------------------------------------------------------------------------
@@ -547,7 +644,7 @@ namespace {
 
 struct DeviceInfo {
     int n_cu = 0;
-    bool lds_raised[2] = {false, false};
+    bool lds_raised[8] = {false, false, false, false, false, false, false, false};
 };
 DeviceInfo& device_info(int dev) {
     static DeviceInfo info[64];
@@ -580,23 +677,36 @@ hipError_t launch_sweep_cells(const SweepArgs& a, void* workspace, hipStream_t s
         di.n_cu = n;
     }
     const size_t lds = cells_lds_bytes(a.D);
-    int nblk = (di.n_cu * 3 + 7) & ~7;  // persistent grid: 3 blocks per CU, a multiple of 8
+    int nblk = (di.n_cu * CELLS_OCC + 7) & ~7;  // persistent grid: CELLS_OCC blocks per CU, a multiple of 8
     const long long full = 8ll * ((tiles + 7) / 8) * a.B;
     if (full <= nblk) nblk = (int)full;
-    const int which = a.D <= 64 ? 0 : 1;
-    const void* kern = which == 0 ? (const void*)sweep_cells_kernel<1> : (const void*)sweep_cells_kernel<2>;
-    if (!di.lds_raised[which]) {
-        e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds_bytes(128));
+    const int nwin = a.D <= 64 ? 1 : 2, mv = a.V > 1 ? 1 : 0;
+    typedef void (*kern_t)(SweepArgs, const float4*, int*, int*, int, int, int);
+    static const kern_t kerns[8] = {sweep_cells_kernel<1, false, false>, sweep_cells_kernel<1, false, true>,
+                                    sweep_cells_kernel<1, true, false>,  sweep_cells_kernel<1, true, true>,
+                                    sweep_cells_kernel<2, false, false>, sweep_cells_kernel<2, false, true>,
+                                    sweep_cells_kernel<2, true, false>,  sweep_cells_kernel<2, true, true>};
+    auto launch = [&](int fast, int* q, int only_flagged) -> hipError_t {
+        const int which = (nwin - 1) * 4 + mv * 2 + fast;
+        if (!di.lds_raised[which]) {
+            hipError_t e2 = hipFuncSetAttribute((const void*)kerns[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds_bytes(128));
+            if (e2 != hipSuccess) return e2;
+            di.lds_raised[which] = true;
+        }
+        hipLaunchKernelGGL(kerns[which], dim3(nblk), dim3(NT), lds, stream, a, packed, flags, q, tiles_x, tiles, only_flagged);
+        return hipGetLastError();
+    };
+    // straight-line kernel first (sweep_cells_fast.hip, full windows only), then the generic one on what it flagged
+    // (or on everything)
+    const bool fast_ok = a.D == 64 * nwin;
+    if (fast_ok) {
+        e = launch_sweep_cells_fast(a, packed, flags, queue, tiles_x, tiles, di.n_cu, stream);
         if (e != hipSuccess) return e;
-        di.lds_raised[which] = true;
     }
-    if (which == 0)
-        hipLaunchKernelGGL(sweep_cells_kernel<1>, dim3(nblk), dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles);
-    else
-        hipLaunchKernelGGL(sweep_cells_kernel<2>, dim3(nblk), dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles);
+    e = launch(0, queue + 8, fast_ok ? 1 : 0);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_sweep_direct_flagged(a, flags, tiles_x, tiles, stream);
+    return launch_sweep_direct_flagged(a, flags, tiles_x, tiles, stream, 2);
 }
 
 }  // namespace pdepth

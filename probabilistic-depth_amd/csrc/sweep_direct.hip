@@ -21,7 +21,7 @@ namespace pdepth {
 //                         kernel flagged that tile (sweep_tiled.hip).
 template <int METRIC, int CCH, bool MULTI_CHUNK>
 __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int* __restrict__ tile_flags,
-                                                          int tiles_x, int tiles) {
+                                                          int tiles_x, int tiles, int flag_value) {
     extern __shared__ float lds[];
     const int tid = threadIdx.x;
     const int HW = a.H * a.W;
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int
     bool live;
     if (tile_flags) {
         const int tile = blockIdx.x;
-        if (tile_flags[b * tiles + tile] == 0) return;  // block-uniform
+        if (tile_flags[b * tiles + tile] != flag_value) return;  // block-uniform
         const int x = (tile % tiles_x) * 16 + (tid & 15);
         const int y = (tile / tiles_x) * 4 + (tid >> 4);
         live = x < a.W && y < a.H;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int
 
 template <int METRIC>
 static hipError_t launch_metric(const SweepArgs& a, const int* tile_flags, int tiles_x, int tiles,
-                                hipStream_t stream) {
+                                hipStream_t stream, int flag_value = 1) {
     const int HW = a.H * a.W;
     dim3 grid(tile_flags ? tiles : (HW + 63) / 64, a.B);
     if (a.C <= 68) {
@@ -136,13 +136,13 @@ static hipError_t launch_metric(const SweepArgs& a, const int* tile_flags, int t
         auto kern = sweep_direct_kernel<METRIC, 68, false>;
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, a, tile_flags, tiles_x, tiles);
+        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, a, tile_flags, tiles_x, tiles, flag_value);
     } else {
         const size_t lds = (size_t)a.D * 64 * sizeof(float) * 2;
         auto kern = sweep_direct_kernel<METRIC, 32, true>;
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, a, tile_flags, tiles_x, tiles);
+        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, a, tile_flags, tiles_x, tiles, flag_value);
     }
     return hipGetLastError();
 }
@@ -153,9 +153,9 @@ hipError_t launch_sweep_direct(const SweepArgs& a, hipStream_t stream) {
 }
 
 hipError_t launch_sweep_direct_flagged(const SweepArgs& a, const int* tile_flags, int tiles_x, int tiles,
-                                       hipStream_t stream) {
-    return a.metric == 0 ? launch_metric<0>(a, tile_flags, tiles_x, tiles, stream)
-                         : launch_metric<1>(a, tile_flags, tiles_x, tiles, stream);
+                                       hipStream_t stream, int flag_value) {
+    return a.metric == 0 ? launch_metric<0>(a, tile_flags, tiles_x, tiles, stream, flag_value)
+                         : launch_metric<1>(a, tile_flags, tiles_x, tiles, stream, flag_value);
 }
 
 // Largest D the direct kernel can hold in LDS (two arrays in the chunked variant).
