@@ -51,12 +51,15 @@ pdepth::SweepArgs make_args(const pdepth_sweep_desc* d, const pdepth_camera* cam
     return a;
 }
 
-// Test / A-B hook, read once per process: PDEPTH_SWEEP_IMPL=tiled keeps ALGO_AUTO on the round-1 tiled kernel.
-enum { IMPL_DEFAULT = 0, IMPL_TILED = 1 };
+// Implementation behind ALGO_AUTO for the L2 metric, read once per process: the LDS-tiled band kernel
+// (sweep_tiled.hip, default: the fastest on every BASELINE configuration but the 64x128 model-real one) or, with
+// PDEPTH_SWEEP_IMPL=cells, the cell-list kernels (sweep_cells_fast.hip + sweep_cells.hip), which make no geometric
+// assumption at all and serve as an independent second implementation in the parity suite.
+enum { IMPL_TILED = 0, IMPL_CELLS = 1 };
 int sweep_impl() {
     static const int impl = [] {
         const char* f = getenv("PDEPTH_SWEEP_IMPL");
-        return (f && f[0] == 't') ? IMPL_TILED : IMPL_DEFAULT;
+        return (f && f[0] == 'c') ? IMPL_CELLS : IMPL_TILED;
     }();
     return impl;
 }
@@ -99,8 +102,8 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
                         "query pdepth_sweep_workspace_bytes()", who, need, workspace_bytes);
         if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0)
             return fail(PDEPTH_E_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
-        // L2: the cell-list kernel (sweep_cells.hip); L1 has no correlation form and stays with the tiled kernel
-        if (d->metric == PDEPTH_METRIC_L2 && d->D <= pdepth::sweep_cells_max_planes() && sweep_impl() != IMPL_TILED)
+        // (L1 has no correlation form: always the tiled kernel)
+        if (d->metric == PDEPTH_METRIC_L2 && d->D <= pdepth::sweep_cells_max_planes() && sweep_impl() == IMPL_CELLS)
             return launched(pdepth::launch_sweep_cells(a, workspace, (hipStream_t)stream), who);
         return launched(pdepth::launch_sweep_tiled(a, workspace, (hipStream_t)stream), who);
     }

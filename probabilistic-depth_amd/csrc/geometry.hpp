@@ -129,6 +129,19 @@ __device__ __forceinline__ void plane_sample_pos_fast(const ViewXform& x, float 
     iy = __builtin_fmaf(gy + 1.0f, half_h, -0.5f);
 }
 
+// exp(x) for x <= 0 (softmax: x = cost - max): 2^(x log2 e) with the product split into a rounded head and its
+// exact remainder, so that the argument of v_exp_f32 is exact to an ulp for every x the softmax can produce.  ~1.5 ulp
+// (libm's expf: 1 ulp) in 9 instructions instead of 20.  NaN stays NaN, anything below -1000 gives 0.
+__device__ __forceinline__ float exp_nonpos(float x) {
+    x = x < -1000.0f ? -1000.0f : x;   // (keeps -inf out of the fma below)
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011079e-8f;
+    const float t = x * L2E_HI;
+    const float tl = __builtin_fmaf(x, L2E_HI, -t) + x * L2E_LO;   // x log2 e = t + tl
+    const float ti = rintf(t);
+    const float p = __builtin_amdgcn_exp2f((t - ti) + tl);           // argument in [-0.5, 0.5]
+    return ldexpf(p, (int)ti);
+}
+
 // Bilinear footprint of a sample position: top-left texel, the four weights and a 4-bit
 // in-bounds mask (bit0 nw, bit1 ne, bit2 sw, bit3 se).  Positions that are NaN or far
 // outside the image get mask 0 (all taps read as zero, like padding_mode='zeros').

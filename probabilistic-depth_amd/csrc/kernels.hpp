@@ -47,8 +47,8 @@ int sweep_cells_max_planes();
 hipError_t launch_sweep_cells(const SweepArgs& a, void* workspace, hipStream_t stream);
 
 // sweep_cells_fast.hip: straight-line instantiation (D = 64 or 128), flags the tiles it leaves to the generic kernel
-hipError_t launch_sweep_cells_fast(const SweepArgs& a, const float4* packed, int* flags, int* queue, int tiles_x, int tiles,
-                                   int n_cu, hipStream_t stream);
+hipError_t launch_sweep_cells_fast(const SweepArgs& a, const float4* packed, int* flags, int* queue, int* redo_list,
+                                   int tiles_x, int tiles, int n_cu, hipStream_t stream);
 
 // dpv.hip
 hipError_t launch_dpv_reduce(const float* logits, const float* d_candi, int B, int D, int H,

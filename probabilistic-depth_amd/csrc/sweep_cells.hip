@@ -97,13 +97,14 @@ constexpr int KEY_NONE = INT_MIN;  // cell key of a plane without any tap inside
 // MV = more than one source view: the costs then stay live across the channel loops of the later views (V = 1 has
 // its own instantiation so that they never are).
 // FAST = the straight-line instantiation: D = 64 NWIN exactly and one pass per window and view; a tile that needs
-// more (cell slots, window texels) is flagged 1 and redone by the generic instantiation, which runs on flagged tiles
-// only (only_flagged) and flags what it cannot do either with 2, for the gather kernel.  Straight-line matters: with
+// more (cell slots, window texels) is flagged 1 and redone by the generic instantiation, which then runs on the list of
+// flagged tiles only (redo_list, count in queue[0] of its own counters) and flags what it cannot do either with 2, for
+// the gather kernel.  Straight-line matters: with
 // the uniform guards of the generic code between the steps, hipcc drains lgkmcnt at every join and nothing overlaps.
 template <int NWIN, bool MV, bool FAST>
 __global__ __launch_bounds__(NT, CELLS_OCC) void sweep_cells_kernel(SweepArgs a, const float4* __restrict__ packed,
                                                             int* __restrict__ tile_flags, int* __restrict__ queue,
-                                                            int tiles_x, int ntile, int only_flagged) {
+                                                            int tiles_x, int ntile, const int* __restrict__ redo_list) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ int s_ex[2][NW][8];  // per-wave values of a block-wide reduction, double buffered by parity
     __shared__ int s_item[2];       // work item of this block: current / next
@@ -140,22 +141,28 @@ __global__ __launch_bounds__(NT, CELLS_OCC) void sweep_cells_kernel(SweepArgs a,
     const int band_tiles = qq + (xcd < rr8 ? 1 : 0);
     const int nitems = band_tiles * a.B;
     const bool colmajor = rr8 == 0 && qq % tiles_x == 0;
-    const bool queued = (int)gridDim.x < 8 * ((ntile + 7) / 8) * a.B;
+    const bool listed = redo_list != nullptr;   // work items = entries of the list the fast kernel wrote
+    const bool queued = !listed && (int)gridDim.x < 8 * ((ntile + 7) / 8) * a.B;
     if (queued) {
         if (tid == 0) s_item[0] = atomicAdd(&queue[xcd], 1);
         __syncthreads();
     }
-    int item = queued ? s_item[0] : (int)(blockIdx.x >> 3), item_par = 0;
+    const int nwork = listed ? *(const volatile int*)&queue[0] : nitems;
+    int item = listed ? (int)blockIdx.x : queued ? s_item[0] : (int)(blockIdx.x >> 3), item_par = 0;
 #ifdef CELLS_STAMPS
     unsigned long long stamp_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
-    while (item < nitems) {
+    while (item < nwork) {
         CELLS_STAMP(9)
-        if (tid == 0) s_item[item_par ^ 1] = queued ? atomicAdd(&queue[xcd], 1) : nitems;
-        const int b = item / band_tiles;
-        int tile;
-        {
+        if (tid == 0) s_item[item_par ^ 1] = listed ? item + (int)gridDim.x : queued ? atomicAdd(&queue[xcd], 1) : nwork;
+        int b, tile;
+        if (listed) {
+            const int id = redo_list[item];
+            b = id / ntile;
+            tile = id - b * ntile;
+        } else {
+            b = item / band_tiles;
             const int ti = item - b * band_tiles;
             tile = band_first + ti;
             if (colmajor) {
@@ -164,12 +171,6 @@ __global__ __launch_bounds__(NT, CELLS_OCC) void sweep_cells_kernel(SweepArgs a,
             }
         }
         int* const my_flag = tile_flags + (b * ntile + tile);
-        if (!FAST && only_flagged && *my_flag != 1) {  // block-uniform: this tile was done by the fast instantiation
-            __syncthreads();
-            item_par ^= 1;
-            item = s_item[item_par];
-            continue;
-        }
         const int px = (tile % tiles_x) * TW + q, py = (tile / tiles_x) * TH + wave;
         const bool live = px < a.W && py < a.H;
         const int p = min(py, a.H - 1) * a.W + min(px, a.W - 1);
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(NT, CELLS_OCC) void sweep_cells_kernel(SweepArgs a,
         }          // views
 
         if (bail) {
-            if (tid == 0) *my_flag = FAST ? 1 : 2;
+            if (tid == 0) *my_flag = 2;
         } else {
             // ---- epilogue from registers: cost store, log-softmax over D, expectation --------------------
             const size_t obase = (size_t)b * a.D * HW + p;
@@ -681,29 +682,26 @@ hipError_t launch_sweep_cells(const SweepArgs& a, void* workspace, hipStream_t s
     const long long full = 8ll * ((tiles + 7) / 8) * a.B;
     if (full <= nblk) nblk = (int)full;
     const int nwin = a.D <= 64 ? 1 : 2, mv = a.V > 1 ? 1 : 0;
-    typedef void (*kern_t)(SweepArgs, const float4*, int*, int*, int, int, int);
-    static const kern_t kerns[8] = {sweep_cells_kernel<1, false, false>, sweep_cells_kernel<1, false, true>,
-                                    sweep_cells_kernel<1, true, false>,  sweep_cells_kernel<1, true, true>,
-                                    sweep_cells_kernel<2, false, false>, sweep_cells_kernel<2, false, true>,
-                                    sweep_cells_kernel<2, true, false>,  sweep_cells_kernel<2, true, true>};
-    auto launch = [&](int fast, int* q, int only_flagged) -> hipError_t {
-        const int which = (nwin - 1) * 4 + mv * 2 + fast;
-        if (!di.lds_raised[which]) {
-            hipError_t e2 = hipFuncSetAttribute((const void*)kerns[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds_bytes(128));
-            if (e2 != hipSuccess) return e2;
-            di.lds_raised[which] = true;
-        }
-        hipLaunchKernelGGL(kerns[which], dim3(nblk), dim3(NT), lds, stream, a, packed, flags, q, tiles_x, tiles, only_flagged);
-        return hipGetLastError();
-    };
-    // straight-line kernel first (sweep_cells_fast.hip, full windows only), then the generic one on what it flagged
-    // (or on everything)
+    typedef void (*kern_t)(SweepArgs, const float4*, int*, int*, int, int, const int*);
+    static const kern_t kerns[4] = {sweep_cells_kernel<1, false, false>, sweep_cells_kernel<1, true, false>,
+                                    sweep_cells_kernel<2, false, false>, sweep_cells_kernel<2, true, false>};
+    const int which = (nwin - 1) * 2 + mv;
+    if (!di.lds_raised[which]) {
+        e = hipFuncSetAttribute((const void*)kerns[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells_lds_bytes(128));
+        if (e != hipSuccess) return e;
+        di.lds_raised[which] = true;
+    }
+    // Straight-line kernel first (sweep_cells_fast.hip, D = 64 or 128 only); it appends the tiles it cannot do to
+    // redo_list (count in queue[8]), which then is the work list of the generic kernel.  Otherwise the generic kernel
+    // takes every tile.
+    int* redo_list = reinterpret_cast<int*>(reinterpret_cast<char*>(packed) + (size_t)a.B * a.V * ((a.C + 3) / 4 + 2) * a.H * a.W * sizeof(float4));
     const bool fast_ok = a.D == 64 * nwin;
     if (fast_ok) {
-        e = launch_sweep_cells_fast(a, packed, flags, queue, tiles_x, tiles, di.n_cu, stream);
+        e = launch_sweep_cells_fast(a, packed, flags, queue, redo_list, tiles_x, tiles, di.n_cu, stream);
         if (e != hipSuccess) return e;
     }
-    e = launch(0, queue + 8, fast_ok ? 1 : 0);
+    hipLaunchKernelGGL(kerns[which], dim3(nblk), dim3(NT), lds, stream, a, packed, flags, queue + 8, tiles_x, tiles,
+                       fast_ok ? (const int*)redo_list : (const int*)nullptr);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_sweep_direct_flagged(a, flags, tiles_x, tiles, stream, 2);

@@ -49,22 +49,23 @@ constexpr int NTS = 24;          // texel slots per role and pass (5-bit slot fi
 #define FCELLS_SETS 3
 #endif
 constexpr int WT = FCELLS_WT;    // window texels per ring buffer
-constexpr int NBUF = 3;          // window ring depth
+constexpr int NBUF = 4;          // window ring depth: chunks ch + 1 .. ch + 3 are in flight while chunk ch is computed
 constexpr int SETS = FCELLS_SETS;  // register sets of 4 texels in the channel loop: SETS - 1 groups of reads in flight
 constexpr int SLOTS = (WT + NT - 1) / NT;
 constexpr int BUF_BYTES = WT * 16;
 constexpr int RING_BYTES = NBUF * BUF_BYTES;
 constexpr int DUMP_WAVE_BYTES = NTS * 256;      // X dump of a wave [slot][16 px][4 roles]
 constexpr int TLIST_WAVE_BYTES = 16 * 4 * NTS * 2;  // texel lists of a wave [16 px][4 roles][NTS] 16-bit entries
-constexpr int GRAMA_OFF = RING_BYTES;
-constexpr int GRAMB_OFF = GRAMA_OFF + WT * 16;
-constexpr int REF_OFF = GRAMB_OFF + WT * 4;     // [2 stages][NW][16 channels][16 px] floats
+// The two Gram planes of the window ride the ring as "chunks" nchunk (float4) and nchunk + 1 (floats): they are staged
+// into the buffers that free up during the last iterations of the channel loop and stay there for the plane loop; the
+// X dumps take the two buffers left.
+constexpr int REF_OFF = RING_BYTES;             // [2 stages][NW][16 channels][16 px] floats
 constexpr int DTAB_OFF = REF_OFF + 2 * NW * 1024;
 static_assert(NTS == 24, "the channel loop is written out for 6 groups of 4 slots");
 static_assert(NTS % 8 == 0 && NTS <= 31, "texel lists are read back 8 entries at a time; 5-bit slot fields");
-static_assert(WT % 64 == 0 && SLOTS <= 4, "whole DMA instructions, at most 5 per iteration (wait_but)");
-static_assert(NW * DUMP_WAVE_BYTES <= RING_BYTES && NW * TLIST_WAVE_BYTES <= BUF_BYTES, "dumps / texel lists alias the ring");
-static_assert(RING_BYTES + 1024 <= 65536, "packed 16-bit LDS addresses of the window taps");
+static_assert(WT % 64 == 0 && SLOTS <= 4, "whole DMA instructions, at most 4 per chunk and wave: 9 in flight (wait_but)");
+static_assert(NBUF == 4 && 2 * DUMP_WAVE_BYTES <= BUF_BYTES && NW * TLIST_WAVE_BYTES <= BUF_BYTES, "dumps (two waves per buffer) / texel lists alias the ring");
+static_assert(BUF_BYTES + 1024 <= 65536 && (NBUF - 1) * BUF_BYTES <= 65535, "packed 16-bit LDS addresses of the window taps (buffer 0) + immediate buffer offset");
 static_assert(2 * (DTAB_OFF + 512 + 320) <= 160 * 1024, "two blocks per CU");
 static_assert(WT <= 1024, "window texel index: 10 bits of the plane info, 1023 = no tap inside the image (windows are kept below WT)");
 constexpr int F1 = 0x8421;       // one in each of the four 5-bit fields (role r at bits 5 r .. 5 r + 4)
@@ -76,7 +77,7 @@ constexpr int KEY_NONE = INT_MIN;
 template <int NWIN, bool MV>
 __global__ __launch_bounds__(fast::NT, 2) void sweep_cells_fast_kernel(SweepArgs a, const float4* __restrict__ packed,
                                                                    int* __restrict__ tile_flags, int* __restrict__ queue,
-                                                                   int tiles_x, int ntile) {
+                                                                   int* __restrict__ redo_list, int tiles_x, int ntile) {
     using namespace fast;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ int s_ex[2][NW][8];
@@ -90,7 +91,6 @@ __global__ __launch_bounds__(fast::NT, 2) void sweep_cells_fast_kernel(SweepArgs
     const int r = lane & 3;    // role: texel parity class (x & 1) + 2 (y & 1); planes 16 r .. 16 r + 15; channel 4 ch + r
     const unsigned lds0 = lds_addr_of(lds_raw);
     float* dtab = reinterpret_cast<float*>(lds_raw + DTAB_OFF);
-    const unsigned dump0 = lds0 + wave * DUMP_WAVE_BYTES;
     // texel lists: in the last ring buffer, dead between the block-wide exchange of a pass and the barrier of chunk 0
     const unsigned tlist0 = lds0 + (NBUF - 1) * BUF_BYTES + wave * TLIST_WAVE_BYTES + q * (4 * NTS * 2);
 
@@ -295,22 +295,19 @@ __global__ __launch_bounds__(fast::NT, 2) void sweep_cells_fast_kernel(SweepArgs
                 lds_wait();
                 // ---- role lanes: texel addresses of the lane's slots --------------------------------------------
                 const int wave_n4 = (wave_nt + 3) >> 2;   // groups of 4 slots the wave needs (1..4)
-                int addrp[NTS / 2];  // two 16-bit LDS byte addresses (ring buffer 0) per register
+                int addr[NTS];  // LDS byte address of the texel of every slot in ring buffer 0 (the buffer is an immediate of the read)
                 {
                     const int xp = r & 1, yp = r >> 1;
 #pragma unroll
                     for (int i8 = 0; i8 < NTS / 8; ++i8) {
                         const v4i e4 = *(lds_v4i)(size_t)(tlist0 + (r * NTS + i8 * 8) * 2);
-                        int ad[8];
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             const int e = (e4[u >> 1] >> (16 * (u & 1))) & 0xffff;
                             // this role's texel of the cell: the column (row) of its parity
                             const int tex = (e & 1023) + (((e >> 10) ^ xp) & 1) + ((((e >> 11) ^ yp) & 1) ? pitch : 0);
-                            ad[u] = lds0 + (i8 * 8 + u < mytot ? tex : 0) * 16;
+                            addr[i8 * 8 + u] = lds0 + (i8 * 8 + u < mytot ? tex : 0) * 16;
                         }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) addrp[i8 * 4 + u] = ad[2 * u] | (ad[2 * u + 1] << 16);
                     }
                 }
 
@@ -333,12 +330,22 @@ __global__ __launch_bounds__(fast::NT, 2) void sweep_cells_fast_kernel(SweepArgs
                 int nd = 0;
 #pragma unroll
                 for (int sl = 0; sl < SLOTS; ++sl) nd += (sl * NT + wave * 64 < wtex) ? 1 : 0;
+                // chunk ch < nchunk: channel group ch; chunk nchunk: Gram plane A (float4); chunk nchunk + 1: .x of Gram
+                // plane B as floats.  nd DMA instructions per wave either way.
                 auto stage = [&](int bufi, int ch) {
 #pragma unroll
-                    for (int sl = 0; sl < SLOTS; ++sl)
-                        if (sl * NT + wave * 64 < wtex)  // wave-uniform
-                            dma_b128(src_rsrc, my_lds + bufi * BUF_BYTES + sl * NT * 16, so[sl], ch * HW * 16);
+                    for (int sl = 0; sl < SLOTS; ++sl) {
+                        if (sl * NT + wave * 64 < wtex) {  // wave-uniform
+#ifdef CELLS_ABL_NO_DMA   // ablation build: every chunk re-reads plane 0 (L2 resident), results are wrong
+                            if (ch <= nchunk) dma_b128(src_rsrc, my_lds + bufi * BUF_BYTES + sl * NT * 16, so[sl], 0);
+#else
+                            if (ch <= nchunk) dma_b128(src_rsrc, my_lds + bufi * BUF_BYTES + sl * NT * 16, so[sl], ch * HW * 16);
+#endif
+                            else dma_b32(src_rsrc, lds0 + bufi * BUF_BYTES + (sl * NT + wave * 64) * 4, so[sl], ch * HW * 16);
+                        }
+                    }
                 };
+                const int nvirt = nchunk + 2;   // chunks to stage, the two Gram planes included
                 // reference features of 16 channels: lane l <- pixels 4 (l & 3) .. + 3 of channel 16 st + (l >> 2)
                 // (channels beyond C read as 0 like the packed source; pixels beyond the right image border read the
                 //  start of the next row or, past the last channel plane, 0: they belong to dead pixels and are never stored)
@@ -347,18 +354,10 @@ __global__ __launch_bounds__(fast::NT, 2) void sweep_cells_fast_kernel(SweepArgs
                     const int c = st * 16 + (lane >> 2);
                     dma_b128(ref_rsrc, my_ref + (st & 1) * (NW * 1024), c < a.C ? ref_voff + c * HW * 4 : 0x7fffffff, 0);
                 };
-                {   // Gram planes of the window: plane nchunk as float4, .x of plane nchunk + 1 as floats
-#pragma unroll
-                    for (int sl = 0; sl < SLOTS; ++sl) {
-                        if (sl * NT + wave * 64 < wtex) {
-                            dma_b128(src_rsrc, my_lds + GRAMA_OFF + sl * NT * 16, so[sl], nchunk * HW * 16);
-                            dma_b32(src_rsrc, lds0 + GRAMB_OFF + (sl * NT + wave * 64) * 4, so[sl], (nchunk + 1) * HW * 16);
-                        }
-                    }
-                }
                 stage_ref(0);
                 stage(0, 0);
-                if (1 < nchunk) stage(1, 1);
+                stage(1, 1);   // (nvirt >= 3)
+                stage(2, 2);
                 CELLS_STAMP(3)  // lists, addresses, staging offsets, first DMA
 
                 float X[NTS];
@@ -367,14 +366,12 @@ __global__ __launch_bounds__(fast::NT, 2) void sweep_cells_fast_kernel(SweepArgs
                 float rr = 0.0f;
 
                 // ---- channel loop ---------------------------------------------------------------------------------
-#define FC_AD(i_) (((i_) & 1) ? (pk_[((i_) >> 1) & 1] >> 16) : (pk_[((i_) >> 1) & 1] & 0xffffu))
 #define FC_LOAD4(T, G4, BUF)                                                                              \
     {                                                                                                     \
-        const unsigned pk_[2] = {(unsigned)opaque_v(addrp[2 * (G4)]), (unsigned)opaque_v(addrp[2 * (G4) + 1])}; \
-        T[0] = *(lds_v4f)(size_t)(FC_AD(0) + (BUF) * BUF_BYTES);                                          \
-        T[1] = *(lds_v4f)(size_t)(FC_AD(1) + (BUF) * BUF_BYTES);                                          \
-        T[2] = *(lds_v4f)(size_t)(FC_AD(2) + (BUF) * BUF_BYTES);                                          \
-        T[3] = *(lds_v4f)(size_t)(FC_AD(3) + (BUF) * BUF_BYTES);                                          \
+        T[0] = *(lds_v4f)(size_t)((unsigned)addr[4 * (G4) + 0] + (BUF) * BUF_BYTES);                      \
+        T[1] = *(lds_v4f)(size_t)((unsigned)addr[4 * (G4) + 1] + (BUF) * BUF_BYTES);                      \
+        T[2] = *(lds_v4f)(size_t)((unsigned)addr[4 * (G4) + 2] + (BUF) * BUF_BYTES);                      \
+        T[3] = *(lds_v4f)(size_t)((unsigned)addr[4 * (G4) + 3] + (BUF) * BUF_BYTES);                      \
     }
 #define FC_FMA4(T, G4)                                                                                    \
     _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                       \
@@ -411,16 +408,24 @@ __global__ __launch_bounds__(fast::NT, 2) void sweep_cells_fast_kernel(SweepArgs
                 // Iteration ch: wait until this wave's window DMA of chunk ch has landed (what iteration ch - 1 issued
                 // stays in flight), barrier, refill the buffer of chunk ch - 1 with chunk ch + 2 (and, every fourth
                 // chunk, stage the next 16 reference channels), compute chunk ch.
+#ifdef CELLS_ABL_NO_WAIT   // ablation build: no DMA wait in the channel loop, results are wrong
+#define CELLS_ABL_WAIT(n) (void)(n)
+#else
+#define CELLS_ABL_WAIT(n) wait_but(n)
+#endif
 #define FC_ITER(U)                                                                                        \
     if (ch0 + (U) < nchunk) {                                                                             \
         const int ch = ch0 + (U);                                                                         \
-        const int younger = (ch + 1 < nchunk ? nd : 0) + ((ch >= 1 && ((ch - 1) & 3) == 0 && ((ch - 1) >> 2) + 1 < nstage) ? 1 : 0); \
-        wait_but(younger);                                                                                \
+        /* in flight behind chunk ch: chunks ch + 1, ch + 2 (if they exist) and the ref stage issued with them */ \
+        const int younger = nd * (min(ch + 2, nvirt - 1) - ch) +                                          \
+                            ((((ch - 1) & 3) == 0 && ch >= 1 && ((ch - 1) >> 2) + 1 < nstage) ? 1 : 0) +   \
+                            ((((ch - 2) & 3) == 0 && ch >= 2 && ((ch - 2) >> 2) + 1 < nstage) ? 1 : 0);    \
+        CELLS_ABL_WAIT(younger);                                                                          \
         CELLS_STAMP(10)                                                                                   \
         lds_barrier();                                                                                    \
         CELLS_STAMP(11)                                                                                   \
         if ((ch & 3) == 0 && (ch >> 2) + 1 < nstage) stage_ref((ch >> 2) + 1);                            \
-        if (ch + 2 < nchunk) stage(((U) + 2) % NBUF, ch + 2);                                             \
+        if (ch + 3 < nvirt) stage(((U) + 3) % NBUF, ch + 3);                                              \
         CELLS_STAMP(12)                                                                                   \
         FC_CHUNK(U, ch)                                                                                   \
         CELLS_STAMP(4)                                                                                    \
@@ -429,6 +434,7 @@ __global__ __launch_bounds__(fast::NT, 2) void sweep_cells_fast_kernel(SweepArgs
                     FC_ITER(0)
                     FC_ITER(1)
                     FC_ITER(2)
+                    FC_ITER(3)
                 }
 #undef FC_ITER
 #undef FC_CHUNK
@@ -436,10 +442,13 @@ __global__ __launch_bounds__(fast::NT, 2) void sweep_cells_fast_kernel(SweepArgs
 #undef FC_STEP
 #undef FC_FMA4
 #undef FC_LOAD4
-#undef FC_AD
                 rr = rr + CELLS_DPP_F(rr, QP_XOR1);
                 rr = rr + CELLS_DPP_F(rr, QP_XOR2);
-                lds_barrier();  // every wave is done with the ring: the dumps may overwrite it
+                wait_but(0);    // this wave's share of the Gram planes has landed
+                lds_barrier();  // ... everybody's has, and every wave is done with the channel chunks
+                // Gram plane A sits in buffer nchunk % 4, B in (nchunk + 1) % 4; the dumps of waves 0, 1 go to buffer
+                // (nchunk + 2) % 4, those of waves 2, 3 to (nchunk + 3) % 4
+                const unsigned dump0 = lds0 + ((nchunk + 2 + (wave >> 1)) & 3) * BUF_BYTES + (wave & 1) * DUMP_WAVE_BYTES;
 #pragma unroll
                 for (int i = 0; i < NTS; ++i) *(lds_fw)(size_t)(dump0 + i * 256 + lane * 4) = X[i];
                 lds_wait();
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(fast::NT, 2) void sweep_cells_fast_kernel(SweepArgs
 
                 // ---- plane loop (straight line; the LDS operands of plane j + 1 are in flight during plane j) -----
                 {
-                    const unsigned gA = lds0 + GRAMA_OFF, gB = lds0 + GRAMB_OFF;
+                    const unsigned gA = lds0 + (nchunk & 3) * BUF_BYTES, gB = lds0 + ((nchunk + 1) & 3) * BUF_BYTES;
                     const unsigned xq = dump0 + q * 16;
                     struct PlaneOps { float X0, X1, X2, X3; v4f G00, G01, G10; float N11, D2; };
                     auto fetch = [&](int info) {
@@ -510,7 +519,10 @@ __global__ __launch_bounds__(fast::NT, 2) void sweep_cells_fast_kernel(SweepArgs
         }      // views
 
         if (bail) {
-            if (tid == 0) tile_flags[b * ntile + tile] = 1;
+            if (tid == 0) {  // flag the tile and append it to the generic kernel's work list (count: queue[8])
+                tile_flags[b * ntile + tile] = 1;
+                redo_list[atomicAdd(&queue[8], 1)] = b * ntile + tile;
+            }
         } else {
             // ---- epilogue from registers: cost store, log-softmax over D, expectation ------------------------
             const size_t obase = (size_t)b * a.D * HW + p;
@@ -537,7 +549,7 @@ __global__ __launch_bounds__(fast::NT, 2) void sweep_cells_fast_kernel(SweepArgs
                     for (int i = 0; i < 4; ++i) d4[i] = *(lds_v4f)(size_t)(lds0 + DTAB_OFF + (m * 4 * JS + ke + 4 * i) * 4);
 #pragma unroll
                     for (int j = 0; j < JS; ++j) {
-                        const float ek = expf(cost[m * JS + j] - mx);
+                        const float ek = exp_nonpos(cost[m * JS + j] - mx);
                         ssum = ssum + ek;
                         esum = __builtin_fmaf(d4[j >> 2][j & 3], ek, esum);
                         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -571,13 +583,13 @@ __global__ __launch_bounds__(fast::NT, 2) void sweep_cells_fast_kernel(SweepArgs
 size_t sweep_cells_fast_lds_bytes() { return (size_t)fast::DTAB_OFF + 512; }
 
 // Launches the straight-line kernel on every tile (persistent grid of 2 blocks per CU).  D must be 64 or 128.
-hipError_t launch_sweep_cells_fast(const SweepArgs& a, const float4* packed, int* flags, int* queue, int tiles_x, int tiles,
-                                   int n_cu, hipStream_t stream) {
+hipError_t launch_sweep_cells_fast(const SweepArgs& a, const float4* packed, int* flags, int* queue, int* redo_list,
+                                   int tiles_x, int tiles, int n_cu, hipStream_t stream) {
     using namespace fast;
     int nblk = (n_cu * 2 + 7) & ~7;
     const long long full = 8ll * ((tiles + 7) / 8) * a.B;
     if (full <= nblk) nblk = (int)full;
-    typedef void (*kern_t)(SweepArgs, const float4*, int*, int*, int, int);
+    typedef void (*kern_t)(SweepArgs, const float4*, int*, int*, int*, int, int);
     static const kern_t kerns[4] = {sweep_cells_fast_kernel<1, false>, sweep_cells_fast_kernel<1, true>,
                                     sweep_cells_fast_kernel<2, false>, sweep_cells_fast_kernel<2, true>};
     const int which = (a.D <= 64 ? 0 : 2) + (a.V > 1 ? 1 : 0);
@@ -586,7 +598,7 @@ hipError_t launch_sweep_cells_fast(const SweepArgs& a, const float4* packed, int
     //  hundred ns and keeps this function free of per-device state)
     hipError_t e = hipFuncSetAttribute((const void*)kerns[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kerns[which], dim3(nblk), dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles);
+    hipLaunchKernelGGL(kerns[which], dim3(nblk), dim3(NT), lds, stream, a, packed, flags, queue, redo_list, tiles_x, tiles);
     return hipGetLastError();
 }
 
