@@ -79,6 +79,13 @@ def host_blas_mode():
     return _host_blas
 
 
+def _no_autograd(who, *tensors):
+    """The ctypes kernels are invisible to autograd: refuse inputs that would silently lose (or corrupt) gradients."""
+    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
+        raise RuntimeError(f"{who}: this HIP op has no backward; call it under torch.no_grad() "
+                           "(inference only, like the reference's evaluation loop)")
+
+
 def load():
     """Load libpdepth_hip.so (once).  Raises if it has not been built."""
     global _lib
@@ -177,6 +184,7 @@ def sweep(ref, src, K, R, t, rays, cxcy, d_candi, sigma, metric=METRIC_L2, algo=
     Returns (cost | None, logp | None, depth | None).
     """
     lib = load()
+    _no_autograd("sweep", ref, src)
     _dev(ref, "ref"), _dev(src, "src")
     if ref.dim() != 4 or src.dim() != 5:
         raise RuntimeError("sweep: ref must be [B,C,H,W] and src [B,V,C,H,W]")
@@ -186,8 +194,8 @@ def sweep(ref, src, K, R, t, rays, cxcy, d_candi, sigma, metric=METRIC_L2, algo=
         raise RuntimeError(f"sweep: src shape {tuple(src.shape)} does not match ref {tuple(ref.shape)}")
     if not _inner_contiguous(ref, 3):
         ref = ref.contiguous()
-    if not _inner_contiguous(src, 3):
-        src = src.contiguous()
+    if not _inner_contiguous(src, 3) or (V > 1 and src.stride(1) < C * H * W) or (B > 1 and src.stride(0) < 0):
+        src = src.contiguous()   # (e.g. an expanded view: view stride 0)
     d_candi = d_candi.contiguous()
     D = d_candi.numel()
     dev = ref.device
@@ -228,6 +236,7 @@ def fallback_tiles(B, H, W):
 def dpv_reduce(logits, d_candi, want_logp=True, want_depth=True, inplace=False):
     """logits [B,D,H,W] -> (logp [B,D,H,W] | None, depth [B,H,W] | None)."""
     lib = load()
+    _no_autograd("dpv_reduce", logits)   # (in place it would also overwrite a tensor that carries a grad_fn)
     _dev(logits, "logits")
     if logits.dim() != 4:
         raise RuntimeError("dpv_reduce: logits must be [B,D,H,W]")
@@ -250,6 +259,7 @@ def dpv_reduce(logits, d_candi, want_logp=True, want_depth=True, inplace=False):
 def dpv_expect(dpv, d_candi, bv_log):
     """dpv [B,D,H,W] -> depth [B,H,W] = sum_k d_k * (exp(dpv) if bv_log else dpv)."""
     lib = load()
+    _no_autograd("dpv_expect", dpv)
     _dev(dpv, "dpv")
     if dpv.dim() != 4:
         raise RuntimeError("dpv_expect: dpv must be [B,D,H,W]")
@@ -269,6 +279,7 @@ def dpv_expect(dpv, d_candi, bv_log):
 def dpv_moments(dpv, d_candi, bv_log=True):
     """dpv [B,D,H,W] -> (mean [B,H,W], variance [B,H,W]) of the depth distribution."""
     lib = load()
+    _no_autograd("dpv_moments", dpv)
     _dev(dpv, "dpv")
     if dpv.dim() != 4:
         raise RuntimeError("dpv_moments: dpv must be [B,D,H,W]")
@@ -289,12 +300,13 @@ def dpv_moments(dpv, d_candi, bv_log=True):
 def warp_feature(src, K, R, t, rays, cxcy, d_candi, blas_mode=None):
     """src [B,V,D,H,W] -> out [B,V,D,H,W], channel i warped with depth plane i."""
     lib = load()
+    _no_autograd("warp_feature", src)
     _dev(src, "src")
     if src.dim() != 5:
         raise RuntimeError("warp_feature: src must be [B,V,D,H,W]")
     B, V, C, H, W = src.shape
-    if not _inner_contiguous(src, 3):
-        src = src.contiguous()
+    if not _inner_contiguous(src, 3) or (V > 1 and src.stride(1) < C * H * W) or (B > 1 and src.stride(0) < 0):
+        src = src.contiguous()   # (e.g. an expanded view: view stride 0)
     d_candi = d_candi.contiguous()
     D = d_candi.numel()
     cam, keep = _camera(K, R, t, rays, cxcy, B, V, H * W)
@@ -334,6 +346,7 @@ def sample_coords(K, R, t, rays, cxcy, d_candi, H, W, blas_mode=None, algo=ALGO_
 def dpv_fuse(logp, dmaps, masks, d_candi, var, eps, want_fused=True, want_log=True):
     """logp [B,D,H,W], dmaps [B,H,W], masks [B,H,W] -> (fused | None, log fused | None)."""
     lib = load()
+    _no_autograd("dpv_fuse", logp)
     _dev(logp, "logp")
     logp, dmaps, masks, d_candi = (t.contiguous() for t in (logp, dmaps, masks, d_candi))
     B, D, H, W = logp.shape

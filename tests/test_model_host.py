@@ -30,6 +30,44 @@ def test_state_dict_layout_matches_reference(nmode):
     assert all(k.startswith("based_3d.dres_modules.") for k in extra), extra  # registered here, list in the reference
 
 
+def test_reference_checkpoint_loads_through_the_trainers_zip():
+    """trainer/base_trainer.py:83-90: zip(model keys, checkpoint keys) then a STRICT load_state_dict.  A reference
+    feedback checkpoint has no based_3d.dres_modules.* entries (plain list there, models.py:394-399)."""
+    from collections import OrderedDict
+    g = golden("g8_model.npz")
+    model = get_model(synth.default_cfg("default_feedback"), 0)
+    ref_keys = [str(k) for k in g["default_feedback_state_keys"]]
+    checkpoint = OrderedDict((k, torch.full_like(v, 0.25)) for k, v in model.state_dict().items() if k in set(ref_keys))
+    assert list(checkpoint.keys()) == ref_keys
+    before = {k: v.clone() for k, v in model.state_dict().items() if ".dres_modules." in k}
+    new_weights = OrderedDict()
+    for a, b in zip(list(model.state_dict().keys()), list(checkpoint.keys())):
+        new_weights[a] = checkpoint[b]
+    model.load_state_dict(new_weights)   # strict
+    sd = model.state_dict()
+    assert all(bool((sd[k] == 0.25).all()) for k in ref_keys if sd[k].is_floating_point())
+    assert all(torch.equal(sd[k], v) for k, v in before.items())   # untouched, like the reference's list
+    # a genuinely missing key still fails
+    del new_weights[ref_keys[0]]
+    with pytest.raises(RuntimeError, match="Missing key"):
+        model.load_state_dict(new_weights)
+
+
+def test_hip_ops_refuse_autograd_inputs():
+    """The ctypes kernels have no backward: an input that requires grad must raise instead of silently cutting
+    (or, in place, corrupting) the graph."""
+    from pdepth_amd import _native
+    x = torch.zeros(1, 4, 2, 2, requires_grad=True)
+    with pytest.raises(RuntimeError, match="no backward"):
+        _native.dpv_reduce(x, torch.zeros(4))
+    with pytest.raises(RuntimeError, match="no backward"):
+        _native.dpv_expect(x, torch.zeros(4), True)
+    with torch.no_grad():   # grad mode off: the guard passes (and the CPU tensor is refused by the device check)
+        with pytest.raises(RuntimeError) as ei:
+            _native.dpv_expect(x, torch.zeros(4), True)
+        assert "no backward" not in str(ei.value)
+
+
 def test_get_model_contract():
     cfg = synth.default_cfg("default")
     assert type(get_model(cfg, 0)).__name__ == "BaseModel"
