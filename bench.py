@@ -1,31 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the fused plane-sweep + DPV hot path (BASELINE.json metric: depth-volumes/sec).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1 without a launcher: starts N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the fused sweep+DPV kernel over one batch of synthetic inputs already
-resident in HBM.  Workload = BASELINE.json configs[1]: mono eval, B=4 volumes per GPU, V=1,
-C=67, D=64, sweep resolution 256x512, outputs log-DPV [B,D,H,W] + depth [B,H,W].  With N GPUs
-every rank owns its own B=4 batch (weak scaling, no data-path collective); per-rank metrics
-are all-gathered once at the end (RCCL).  Prints ONE JSON line on rank 0.
+A step = one pass of the fused sweep+DPV entry point (pdepth_sweep_dpv_f32, NCHW features in, log-DPV + depth out)
+over one batch of synthetic inputs already resident in HBM.  Workload = BASELINE.json configs[1]: mono eval, B=4
+volumes per GPU, V=1, C=67, D=64, sweep resolution 256x512.  With N GPUs every rank owns its own B=4 batch (weak
+scaling, no data-path collective); per-rank metrics are all-gathered once at the end (RCCL).  Prints ONE JSON line on
+rank 0.  Next to the headline it reports the same step through the packed-source entry
+(pdepth_sweep_dpv_packed_f32: features already in the kernels' staging layout) as `packed_entry`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-import torch  # noqa: E402
-
-import pdepth_amd  # noqa: E402,F401
-from pdepth_amd import dist as pdist  # noqa: E402
-from pdepth_amd import ops, synth  # noqa: E402
-
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2   # wave-instructions / s: 256 CUs x 4 SIMDs, one wave64 VALU op per 2 clocks at 2.4 GHz
 
 
 def algorithmic_bytes_per_volume(C, V, D, H, W):
@@ -33,26 +31,45 @@ def algorithmic_bytes_per_volume(C, V, D, H, W):
     return 4 * H * W * (C * (1 + V) + D + 1)
 
 
-def cpu_baseline(cfg, budget_s=12.0):
-    """Oracle (CPU restatement of the reference) timed on the host cores: bounded sample."""
+def cpu_baseline(cfg, budget_s=45.0):
+    """Oracle (CPU restatement of the reference) timed on the host cores: a bounded sample -- ONE volume of the same
+    workload per thread count -- at all, 64, 32, 8 and 1 threads (a leg is skipped once the budget is spent; the
+    1-thread leg alone takes ~20 s).  value = the best of them, value_1t = one thread."""
+    import torch
+    from pdepth_amd import synth
     from oracle import ref_cpu as O
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    n, t_total = 0, 0.0
     it = synth.make_item(2000, **cfg)
     K = it["K"]
-    args = (it["ref"][None], it["src"][None], it["d_candi"], it["R"], it["t"], K, it["rays"],
-            K.numpy()[0, 2], K.numpy()[1, 2], 10.0)
-    O.sweep_dpv(*args)  # warm-up (allocator, thread pool)
-    while t_total < budget_s and n < 16:
+    args = (it["ref"][None], it["src"][None], it["d_candi"], it["R"], it["t"], K, it["rays"], K.numpy()[0, 2],
+            K.numpy()[1, 2], 10.0)
+    by_threads, t_used = {}, 0.0
+    for n in sorted({1, 8, 32, 64, cores}, reverse=True):
+        if n > cores or t_used > budget_s:
+            continue
+        torch.set_num_threads(n)
         t0 = time.perf_counter()
         O.sweep_dpv(*args)
-        t_total += time.perf_counter() - t0
-        n += 1
-    return {"value": n / t_total, "unit": "depth-volumes/s", "cores": cores, "kind": "port",
-            "sample": f"{n} volume(s) of the same workload (1 item, V={cfg['V']}, C={cfg['C']}, D={cfg['D']}, "
-                      f"{cfg['H']}x{cfg['W']}) through oracle/ref_cpu.py, torch {torch.__version__} CPU, "
-                      f"{cores} threads"}
+        dt = time.perf_counter() - t0
+        t_used += dt
+        by_threads[str(n)] = 1.0 / dt
+    best = max(by_threads, key=by_threads.get)
+    return {"value": by_threads[best], "unit": "depth-volumes/s", "cores": int(best), "threads_best": int(best),
+            "value_1t": by_threads.get("1"), "by_threads": by_threads, "host_cores": cores, "kind": "port",
+            "sample": f"1 volume per thread count of the same workload (1 item, V={cfg['V']}, C={cfg['C']}, "
+                      f"D={cfg['D']}, {cfg['H']}x{cfg['W']}) through oracle/ref_cpu.py, torch CPU; "
+                      f"{t_used:.0f} s of CPU work in total"}
+
+
+def self_launch(a):
+    """--gpus N without a launcher: start N fresh ranks (one per GPU) BEFORE this process touches the GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
@@ -70,9 +87,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))   # non-zero if any rank fails
+
+    import torch
+    import pdepth_amd
+    from pdepth_amd import dist as pdist
+    from pdepth_amd import ops, synth
+
     rank, world, local_rank = pdist.init_from_env()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    assert world == a.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {a.gpus}"
+    assert world == a.gpus, f"WORLD_SIZE={world} but --gpus {a.gpus}"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -82,61 +107,80 @@ def main():
     d = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
     dc = ops.d_candi_tensor(d["d_candi"], dev)
 
-    def step():
-        return ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], dc, 10.0,
+    def step(src):
+        return ops.sweep_dpv(d["ref"], src, d["K"], d["R"], d["t"], d["rays"], d["cxcy"], dc, 10.0,
                              algo=a.algo, want_cost=False, want_logp=True, want_depth=True)
 
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    pdist.barrier()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
-    t0 = time.perf_counter()
-    ev[0].record()
-    for i in range(a.steps):
-        out = step()
-        ev[i + 1].record()
-    torch.cuda.synchronize(dev)
-    pdist.barrier()
-    wall = time.perf_counter() - t0
-    wall = pdist.max_over_ranks(wall, dev)
+    def timed(src):
+        for _ in range(a.warmup):
+            step(src)
+        torch.cuda.synchronize(dev)
+        pdist.barrier()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+        t0 = time.perf_counter()
+        ev[0].record()
+        for i in range(a.steps):
+            out = step(src)
+            ev[i + 1].record()
+        torch.cuda.synchronize(dev)
+        pdist.barrier()
+        wall = pdist.max_over_ranks(time.perf_counter() - t0, dev)
+        # HIP events on the launch stream (torch's current stream IS the stream the C ABI launches on)
+        kern_ms = sum(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps)) / a.steps
+        return out, wall, kern_ms
 
-    kern_ms = sum(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps)) / a.steps  # HIP events, launch stream
+    out, wall, kern_ms = timed(d["src"])
     depth = out[2]
     metrics = torch.tensor([hi - lo, kern_ms, float(depth.mean()), float(torch.isfinite(depth).all())],
                            dtype=torch.float32, device=dev)
     allm = pdist.gather_metrics(metrics).cpu()
+    fallback = pdepth_amd._native.fallback_tiles(hi - lo, cfg["H"], cfg["W"])
+
+    packed_entry = None
+    if a.algo == "auto":   # secondary: the same step on features already in the kernels' staging layout
+        try:
+            ps = ops.pack_source(d["src"], cfg["D"])
+            out_p, _, kern_p = timed(ps)
+            packed_entry = {"kernel_ms": kern_p, "max_abs_depth_diff_vs_headline": float((out_p[2] - depth).abs().max())}
+        except RuntimeError as e:
+            packed_entry = {"error": str(e)}
 
     if rank == 0:
-        vols = a.batch * world * a.steps
-        bytes_per_launch = algorithmic_bytes_per_volume(cfg["C"], cfg["V"], cfg["D"], cfg["H"], cfg["W"]) * (hi - lo)
-        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        bpv = algorithmic_bytes_per_volume(cfg["C"], cfg["V"], cfg["D"], cfg["H"], cfg["W"])
+        prof = {}
         tj = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(tj):
             try:
-                traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+                prof = json.load(open(tj))
             except Exception:
-                traffic = None
-        line = {
-            "metric": "depth-volumes/sec (D=64, 256x512)", "value": vols / wall, "unit": "depth-volumes/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: default_mono eval, fused sweep+DPV, B={a.batch}/GPU, "
-                                   f"V={cfg['V']}, C={cfg['C']}, D={cfg['D']}, {cfg['H']}x{cfg['W']}, pose={a.pose}, "
-                                   f"algo={a.algo}", "global_batch": a.batch * world, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "fused sweep+DPV = pack_c4_kernel (source re-layout pre-pass) + sweep_tiled_kernel", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         # secondary figure of SURVEY 8(d): flops of the direct formulation, 11*D*h*w*V*C per volume,
-                         # against the dense fp32 vector peak (157.3 TFLOP/s); the band mode executes fewer
-                         "algorithmic_tflops": 11.0 * cfg["D"] * cfg["H"] * cfg["W"] * cfg["V"] * cfg["C"] * (hi - lo)
-                                               / (kern_ms * 1e-3) / 1e12,
-                         "fp32_valu_peak_tflops": 157.3},
-            "per_rank_kernel_ms": [float(x) for x in allm[:, 1]],
-            "gather_fallback_tiles": pdepth_amd._native.fallback_tiles(hi - lo, cfg["H"], cfg["W"]),
-        }
+                prof = {}
+        roof = {"traffic": prof.get("hbm_bytes_per_launch"),
+                "traffic_source": prof.get("source"),
+                "kernel": "fused sweep+DPV call = pack_c4_kernel (source re-layout pre-pass) + sweep_tiled_kernel "
+                          "(+ the gather kernel on flagged tiles)",
+                # secondary figure of SURVEY 8(d): flops of the direct formulation, 11*D*h*w*V*C per volume, against
+                # the dense fp32 vector peak (157.3 TFLOP/s); the band mode executes fewer
+                "algorithmic_tflops": 11.0 * cfg["D"] * cfg["H"] * cfg["W"] * cfg["V"] * cfg["C"] * (hi - lo)
+                                      / (kern_ms * 1e-3) / 1e12,
+                "fp32_valu_peak_tflops": 157.3}
+        if prof.get("valu_wave_instr_per_launch"):
+            # VALU wave-instructions per launch (PMC SQ_INSTS_VALU, committed profile) / issue peak / kernel time
+            roof["valu_frac"] = prof["valu_wave_instr_per_launch"] / (kern_ms * 1e-3) / VALU_ISSUE_PEAK
+            roof["valu_wave_instr_per_launch"] = prof["valu_wave_instr_per_launch"]
+        extras = {"roofline": roof, "gather_fallback_tiles": fallback}
+        if packed_entry is not None:
+            if "kernel_ms" in packed_entry:
+                pa = bpv * (hi - lo) / (packed_entry["kernel_ms"] * 1e-3) / 1e9
+                packed_entry.update({"achieved": pa, "frac": pa / HBM_PEAK_GBS, "unit": "GB/s",
+                                     "what": "pdepth_sweep_dpv_packed_f32: source already packed "
+                                             "(pdepth_pack_source_f32 outside the timed region)"})
+            extras["packed_entry"] = packed_entry
+        line = pdist.assemble_bench_line(
+            allm, wall, steps=a.steps, warmup=a.warmup, batch_per_gpu=a.batch, world=world,
+            metric="depth-volumes/sec (D=64, 256x512)", unit="depth-volumes/s",
+            workload=f"BASELINE configs[1]: default_mono eval, fused sweep+DPV, B={a.batch}/GPU, V={cfg['V']}, "
+                     f"C={cfg['C']}, D={cfg['D']}, {cfg['H']}x{cfg['W']}, pose={a.pose}, algo={a.algo}",
+            bytes_per_volume=bpv, hbm_peak_gbs=HBM_PEAK_GBS, extras=extras)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)

@@ -115,6 +115,24 @@ int pdepth_sweep_dpv_f32(const pdepth_sweep_desc *desc, const pdepth_camera *cam
                          float *cost, float *logp, float *depth,
                          void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * The same fused sweep for a caller that keeps its source features in the kernels' staging layout -- e.g. the epilogue
+ * of the feature encoder (models/models.py:518-534 is where the reference concatenates the 64 learned channels with
+ * the RGB thumbnail) -- so that the NCHW -> channel-group-planar re-layout is paid once per frame instead of once per
+ * sweep call (it is 10 % of the time and 30 % of the memory traffic of pdepth_sweep_dpv_f32):
+ *   pdepth_pack_source_f32      : src [B,V,C,H,W] (strides from desc) -> workspace (the pre-pass of the entry above:
+ *                                 float4 texels of 4 channels, planes [ceil(C/4)][H][W], + 2 Gram planes);
+ *   pdepth_sweep_dpv_packed_f32 : the sweep on a workspace packed by that call for the same desc (B, V, C, H, W and
+ *                                 algo = PDEPTH_ALGO_AUTO; any cameras, depth candidates, sigma, metric, reference
+ *                                 features).  Outputs as pdepth_sweep_dpv_f32.
+ * PDEPTH_E_ARG if the shape does not run on a packed source (then use pdepth_sweep_dpv_f32).
+ */
+int pdepth_pack_source_f32(const pdepth_sweep_desc *desc, const float *src, void *workspace,
+                           size_t workspace_bytes, void *stream);
+int pdepth_sweep_dpv_packed_f32(const pdepth_sweep_desc *desc, const pdepth_camera *cam, const float *ref,
+                                const float *d_candi, float *cost, float *logp, float *depth,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
 /* Bytes of scratch the two sweep entry points need for `desc` (0 for ALGO_DIRECT); the workspace
  * must be 256-byte aligned.  ALGO_AUTO without it returns PDEPTH_E_WORKSPACE.  For ALGO_AUTO it holds
  * one flag per 16x4 tile, 8 work-queue counters and a channel-group-planar copy of the source views

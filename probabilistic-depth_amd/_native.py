@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = (
     "pdepth_dpv_expect_f32", "pdepth_warp_feature_f32", "pdepth_sample_coords_f32",
     "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32", "pdepth_inverse_warp_f32",
     "pdepth_dpv_moments_f32", "pdepth_correlation_backward_f32",
+    "pdepth_pack_source_f32", "pdepth_sweep_dpv_packed_f32",
 )
 
 
@@ -106,6 +107,9 @@ def load():
                                           c_void_p, c_void_p, c_size_t, c_void_p]
     lib.pdepth_sweep_dpv_f32.argtypes = [POINTER(SweepDesc), POINTER(Camera), c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.pdepth_pack_source_f32.argtypes = [POINTER(SweepDesc), c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.pdepth_sweep_dpv_packed_f32.argtypes = [POINTER(SweepDesc), POINTER(Camera), c_void_p, c_void_p, c_void_p,
+                                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.pdepth_dpv_reduce_f32.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                           c_void_p, c_void_p]
     lib.pdepth_dpv_expect_f32.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
@@ -175,46 +179,97 @@ def _blas(blas_mode):
     return host_blas_mode() if blas_mode is None else int(blas_mode)
 
 
+class PackedSource:
+    """Source views [B,V,C,H,W] in the sweep kernels' staging layout (pdepth_pack_source_f32): a workspace to hand to
+    sweep() in place of src, for callers that sweep the same source features more than once or write them once per
+    frame.  Owns its device memory; do not use it from two streams at once."""
+
+    def __init__(self, ws, shape):
+        self.ws, self.shape = ws, tuple(shape)   # shape = (B, V, C, H, W)
+
+
+def pack_source(src, n_planes=64):
+    """src [B,V,C,H,W] fp32 device tensor -> PackedSource (n_planes only selects the algorithm, like desc.D)."""
+    lib = load()
+    _no_autograd("pack_source", src)
+    _dev(src, "src")
+    if src.dim() != 5:
+        raise RuntimeError("pack_source: src must be [B,V,C,H,W]")
+    B, V, C, H, W = src.shape
+    if not _inner_contiguous(src, 3) or (V > 1 and src.stride(1) < C * H * W):
+        src = src.contiguous()
+    desc = SweepDesc(B, V, C, int(n_planes), H, W, METRIC_L2, ALGO_AUTO, BLAS_FMA, 1.0, C * H * W,
+                     src.stride(0) if B > 1 else V * C * H * W, src.stride(1) if V > 1 else C * H * W)
+    ws_bytes = lib.pdepth_sweep_workspace_bytes(ctypes.byref(desc))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=src.device)
+    with torch.cuda.device(src.device):
+        rc = lib.pdepth_pack_source_f32(ctypes.byref(desc), _dev(src, "src"), ws.data_ptr(), ws_bytes, _stream(src.device))
+    _check(rc, lib)
+    return PackedSource(ws, (B, V, C, H, W))
+
+
 def sweep(ref, src, K, R, t, rays, cxcy, d_candi, sigma, metric=METRIC_L2, algo=ALGO_AUTO,
           want_cost=True, want_logp=False, want_depth=False, blas_mode=None):
     """Batched plane sweep (+ optional fused DPV reduction).
 
-    ref [B,C,H,W], src [B,V,C,H,W] (batch/view strides free, inner C,H,W dense), K [B,3,3],
+    ref [B,C,H,W], src [B,V,C,H,W] (batch/view strides free, inner C,H,W dense) or a PackedSource, K [B,3,3],
     R [B,V,3,3], t [B,V,3], rays [B,3,HW], cxcy [B,2], d_candi [D] -- fp32 device tensors.
     Returns (cost | None, logp | None, depth | None).
     """
     lib = load()
-    _no_autograd("sweep", ref, src)
-    _dev(ref, "ref"), _dev(src, "src")
-    if ref.dim() != 4 or src.dim() != 5:
+    packed = src if isinstance(src, PackedSource) else None
+    _no_autograd("sweep", ref, None if packed else src)
+    _dev(ref, "ref")
+    if ref.dim() != 4:
         raise RuntimeError("sweep: ref must be [B,C,H,W] and src [B,V,C,H,W]")
     B, C, H, W = ref.shape
-    V = src.shape[1]
-    if tuple(src.shape) != (B, V, C, H, W):
-        raise RuntimeError(f"sweep: src shape {tuple(src.shape)} does not match ref {tuple(ref.shape)}")
+    if packed:
+        if (packed.shape[0], packed.shape[2], packed.shape[3], packed.shape[4]) != (B, C, H, W):
+            raise RuntimeError(f"sweep: packed source {packed.shape} does not match ref {tuple(ref.shape)}")
+        if packed.ws.device != ref.device:
+            raise RuntimeError("sweep: packed source lives on another device")
+        V = packed.shape[1]
+    else:
+        _dev(src, "src")
+        if src.dim() != 5:
+            raise RuntimeError("sweep: ref must be [B,C,H,W] and src [B,V,C,H,W]")
+        V = src.shape[1]
+        if tuple(src.shape) != (B, V, C, H, W):
+            raise RuntimeError(f"sweep: src shape {tuple(src.shape)} does not match ref {tuple(ref.shape)}")
+        if not _inner_contiguous(src, 3) or (V > 1 and src.stride(1) < C * H * W) or (B > 1 and src.stride(0) < 0):
+            src = src.contiguous()   # (e.g. an expanded view: view stride 0)
     if not _inner_contiguous(ref, 3):
         ref = ref.contiguous()
-    if not _inner_contiguous(src, 3) or (V > 1 and src.stride(1) < C * H * W) or (B > 1 and src.stride(0) < 0):
-        src = src.contiguous()   # (e.g. an expanded view: view stride 0)
     d_candi = d_candi.contiguous()
     D = d_candi.numel()
     dev = ref.device
     cam, keep = _camera(K, R, t, rays, cxcy, B, V, H * W)
     desc = SweepDesc(B, V, C, D, H, W, int(metric), int(algo), _blas(blas_mode), float(sigma),
                      ref.stride(0) if B > 1 else C * H * W,
-                     src.stride(0) if B > 1 else V * C * H * W,
-                     src.stride(1) if V > 1 else C * H * W)
+                     (src.stride(0) if B > 1 else V * C * H * W) if not packed else V * C * H * W,
+                     (src.stride(1) if V > 1 else C * H * W) if not packed else C * H * W)
     ws_bytes = lib.pdepth_sweep_workspace_bytes(ctypes.byref(desc))
-    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev) if ws_bytes else None
+    if packed:
+        if ws_bytes == 0 or packed.ws.numel() < ws_bytes:
+            raise RuntimeError("sweep: this shape / algorithm does not run on a packed source")
+        ws = packed.ws
+    else:
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev) if ws_bytes else None
     cost = torch.empty((B, D, H, W), dtype=torch.float32, device=dev) if want_cost else None
     logp = torch.empty((B, D, H, W), dtype=torch.float32, device=dev) if want_logp else None
     depth = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_depth else None
     with torch.cuda.device(dev):
-        rc = lib.pdepth_sweep_dpv_f32(
-            ctypes.byref(desc), ctypes.byref(cam), _dev(ref, "ref"), _dev(src, "src"), _dev(d_candi, "d_candi"),
-            cost.data_ptr() if want_cost else None, logp.data_ptr() if want_logp else None,
-            depth.data_ptr() if want_depth else None, ws.data_ptr() if ws is not None else None, ws_bytes,
-            _stream(dev))
+        if packed:
+            rc = lib.pdepth_sweep_dpv_packed_f32(
+                ctypes.byref(desc), ctypes.byref(cam), _dev(ref, "ref"), _dev(d_candi, "d_candi"),
+                cost.data_ptr() if want_cost else None, logp.data_ptr() if want_logp else None,
+                depth.data_ptr() if want_depth else None, ws.data_ptr(), ws_bytes, _stream(dev))
+        else:
+            rc = lib.pdepth_sweep_dpv_f32(
+                ctypes.byref(desc), ctypes.byref(cam), _dev(ref, "ref"), _dev(src, "src"), _dev(d_candi, "d_candi"),
+                cost.data_ptr() if want_cost else None, logp.data_ptr() if want_logp else None,
+                depth.data_ptr() if want_depth else None, ws.data_ptr() if ws is not None else None, ws_bytes,
+                _stream(dev))
     _check(rc, lib)
     del keep
     global _last_workspace

@@ -75,11 +75,20 @@ size_t tiled_ws_bytes(const pdepth_sweep_desc* d) {
     return pdepth::sweep_tiled_workspace_bytes(d->B, d->V, d->C, d->H, d->W);
 }
 
+// does ALGO_AUTO run on the packed (channel-group-planar) copy of the source for this shape?
+bool uses_packed_source(const pdepth_sweep_desc* d) {
+    return d->algo == PDEPTH_ALGO_AUTO && d->D <= pdepth::sweep_tiled_max_planes() && d->W <= 32767 && d->H <= 32767 &&
+           (long long)((d->C + 3) / 4 + 2) * d->H * d->W * 16 < (1ll << 31);
+}
+
+// packed_ready: src is NULL and the workspace already holds the packed source (pdepth_pack_source_f32)
 int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const float* ref,
                  const float* src, const float* d_candi, float* cost, float* logp, float* depth,
-                 void* workspace, size_t workspace_bytes, void* stream, const char* who) {
+                 void* workspace, size_t workspace_bytes, void* stream, const char* who, bool packed_ready = false) {
     if (int rc = check_desc(d, cam, who)) return rc;
-    if (!ref || !src || !d_candi) return fail(PDEPTH_E_ARG, "%s: null input pointer", who);
+    if (!ref || (!src && !packed_ready) || !d_candi) return fail(PDEPTH_E_ARG, "%s: null input pointer", who);
+    if (packed_ready && !uses_packed_source(d))
+        return fail(PDEPTH_E_ARG, "%s: this shape / algorithm does not run on a packed source (use pdepth_sweep_dpv_f32)", who);
     if (!cost && !logp && !depth) return fail(PDEPTH_E_ARG, "%s: no output requested", who);
     if (d->metric != PDEPTH_METRIC_L2 && d->metric != PDEPTH_METRIC_L1)
         return fail(PDEPTH_E_ARG, "%s: undefined metric for feature distance (%d)", who, d->metric);
@@ -94,8 +103,7 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
     a.cost_out = cost; a.logp_out = logp; a.depth_out = depth;
     // the tiled kernel addresses one view through a 32-bit buffer descriptor (C*H*W*4 bytes < 2^31)
     // (the tiled kernels also pack a footprint as two 16-bit coordinates)
-    if (d->algo == PDEPTH_ALGO_AUTO && d->D <= pdepth::sweep_tiled_max_planes() && d->W <= 32767 && d->H <= 32767 &&
-        (long long)((d->C + 3) / 4 + 2) * d->H * d->W * 16 < (1ll << 31)) {
+    if (uses_packed_source(d)) {
         const size_t need = tiled_ws_bytes(d);
         if (!workspace || workspace_bytes < need)
             return fail(PDEPTH_E_WORKSPACE, "%s: ALGO_AUTO needs %zu bytes of workspace (got %zu); "
@@ -104,8 +112,8 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
             return fail(PDEPTH_E_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
         // (L1 has no correlation form: always the tiled kernel)
         if (d->metric == PDEPTH_METRIC_L2 && d->D <= pdepth::sweep_cells_max_planes() && sweep_impl() == IMPL_CELLS)
-            return launched(pdepth::launch_sweep_cells(a, workspace, (hipStream_t)stream), who);
-        return launched(pdepth::launch_sweep_tiled(a, workspace, (hipStream_t)stream), who);
+            return launched(pdepth::launch_sweep_cells(a, workspace, (hipStream_t)stream, packed_ready), who);
+        return launched(pdepth::launch_sweep_tiled(a, workspace, (hipStream_t)stream, packed_ready), who);
     }
     return launched(pdepth::launch_sweep_direct(a, (hipStream_t)stream), who);
 }
@@ -136,6 +144,35 @@ int pdepth_sweep_dpv_f32(const pdepth_sweep_desc* desc, const pdepth_camera* cam
                          float* depth, void* workspace, size_t workspace_bytes, void* stream) {
     return sweep_common(desc, cam, ref, src, d_candi, cost, logp, depth, workspace, workspace_bytes, stream,
                         "pdepth_sweep_dpv_f32");
+}
+
+int pdepth_pack_source_f32(const pdepth_sweep_desc* desc, const float* src, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+    const char* who = "pdepth_pack_source_f32";
+    if (!desc || !src) return fail(PDEPTH_E_ARG, "%s: null pointer", who);
+    if (desc->B <= 0 || desc->V <= 0 || desc->C <= 0 || desc->D <= 0 || desc->H <= 0 || desc->W <= 0)
+        return fail(PDEPTH_E_ARG, "%s: non-positive dimension", who);
+    if (desc->src_vstride < (long long)desc->C * desc->H * desc->W || desc->src_bstride < 0)
+        return fail(PDEPTH_E_ARG, "%s: bad strides", who);
+    if (!uses_packed_source(desc))
+        return fail(PDEPTH_E_ARG, "%s: this shape / algorithm does not run on a packed source", who);
+    const size_t need = tiled_ws_bytes(desc);
+    if (!workspace || workspace_bytes < need)
+        return fail(PDEPTH_E_WORKSPACE, "%s: needs %zu bytes of workspace (got %zu)", who, need, workspace_bytes);
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0)
+        return fail(PDEPTH_E_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
+    pdepth::SweepArgs a{};
+    a.src = src;
+    a.B = desc->B; a.V = desc->V; a.C = desc->C; a.D = desc->D; a.H = desc->H; a.W = desc->W;
+    a.src_bstride = desc->src_bstride; a.src_vstride = desc->src_vstride;
+    return launched(pdepth::launch_pack_c4(a, workspace, (hipStream_t)stream), who);
+}
+
+int pdepth_sweep_dpv_packed_f32(const pdepth_sweep_desc* desc, const pdepth_camera* cam, const float* ref,
+                                const float* d_candi, float* cost, float* logp, float* depth, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    return sweep_common(desc, cam, ref, nullptr, d_candi, cost, logp, depth, workspace, workspace_bytes, stream,
+                        "pdepth_sweep_dpv_packed_f32", true);
 }
 
 int pdepth_dpv_reduce_f32(const float* logits, const float* d_candi, int32_t B, int32_t D, int32_t H,

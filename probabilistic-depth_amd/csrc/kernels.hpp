@@ -37,14 +37,17 @@ int sweep_direct_max_planes(int C);
 // sweep_tiled.hip
 size_t sweep_tiled_workspace_bytes(int B, int V, int C, int H, int W);
 int sweep_tiled_max_planes();
-hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t stream);      // picks a variant
-hipError_t launch_sweep_tiled_n1(const SweepArgs& a, void* workspace, hipStream_t stream);   // one 16x4 tile per block
-hipError_t launch_sweep_tiled_n2(const SweepArgs& a, void* workspace, hipStream_t stream);   // two tiles per block
-hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t stream);          // pre-pass of both
+// packed_ready: the workspace already holds the packed source of exactly these views (pdepth_pack_source_f32)
+hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false);     // picks a variant
+hipError_t launch_sweep_tiled_n1(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false);  // one 16x4 tile per block
+hipError_t launch_sweep_tiled_n2(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false);  // two tiles per block
+hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t stream);          // pre-pass of both (also clears flags + queues)
+hipError_t clear_sweep_flags(const SweepArgs& a, void* workspace, hipStream_t stream);
+int sweep_device_cus();
 
 // sweep_cells.hip (L2 only; same workspace as the tiled kernel)
 int sweep_cells_max_planes();
-hipError_t launch_sweep_cells(const SweepArgs& a, void* workspace, hipStream_t stream);
+hipError_t launch_sweep_cells(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false);
 
 // sweep_cells_fast.hip: straight-line instantiation (D = 64 or 128), flags the tiles it leaves to the generic kernel
 hipError_t launch_sweep_cells_fast(const SweepArgs& a, const float4* packed, int* flags, int* queue, int* redo_list,

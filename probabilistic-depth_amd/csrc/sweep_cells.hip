@@ -660,23 +660,19 @@ int sweep_cells_max_planes() { return 128; }
 
 // Launches the pre-pass, the cell-list kernel, then the gather kernel on the tiles it flagged.
 // The workspace layout is the one of sweep_tiled.hip (flags, queue counters, packed source).
-hipError_t launch_sweep_cells(const SweepArgs& a, void* workspace, hipStream_t stream) {
+hipError_t launch_sweep_cells(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready) {
     const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
     const int tiles = tiles_x * tiles_y;
     const size_t flag_only = ((size_t)a.B * tiles * sizeof(int) + 255) & ~(size_t)255;
     int* flags = reinterpret_cast<int*>(workspace);
     int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + flag_only);
     float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + flag_only + 256);
-    hipError_t e = launch_pack_c4(a, workspace, stream);
+    hipError_t e = packed_ready ? clear_sweep_flags(a, workspace, stream) : launch_pack_c4(a, workspace, stream);
     if (e != hipSuccess) return e;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     DeviceInfo& di = device_info(dev);
-    if (di.n_cu == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        di.n_cu = n;
-    }
+    di.n_cu = sweep_device_cus();
     const size_t lds = cells_lds_bytes(a.D);
     int nblk = (di.n_cu * CELLS_OCC + 7) & ~7;  // persistent grid: CELLS_OCC blocks per CU, a multiple of 8
     const long long full = 8ll * ((tiles + 7) / 8) * a.B;

@@ -878,34 +878,49 @@ hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t strea
 
 // Two tiles per block pay off when two such blocks fit a CU (the cost tiles of both sub-tiles live in LDS: D <= 64)
 // and the image is large enough for the wider windows not to dominate; measured on the BASELINE configurations.
-hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t stream) {
+// PDEPTH_TILED_VARIANT=1|2 (tests: force a variant, any shape) is read once per process.
+hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready) {
+    static const int forced = [] {
+        const char* f = getenv("PDEPTH_TILED_VARIANT");
+        return (f && (f[0] == '1' || f[0] == '2')) ? f[0] - '0' : 0;
+    }();
     bool two = a.D <= 64 && (long long)a.H * a.W >= 96 * 1024 && a.W >= 128;
-    if (const char* f = getenv("PDEPTH_TILED_VARIANT")) {  // tests: force a variant ("1" / "2"), any shape
-        if (f[0] == '1') two = false;
-        if (f[0] == '2') two = true;
+    if (forced) two = forced == 2;
+    return two ? launch_sweep_tiled_n2(a, workspace, stream, packed_ready) : launch_sweep_tiled_n1(a, workspace, stream, packed_ready);
+}
+
+// The pre-pass also clears the tile flags and queue counters; a call on an already packed source clears them itself.
+hipError_t clear_sweep_flags(const SweepArgs& a, void* workspace, hipStream_t stream) {
+    return hipMemsetAsync(workspace, 0, flag_bytes(a.B, a.H, a.W), stream);
+}
+
+// CU count of the current device (cached per device)
+int sweep_device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
     }
-    return two ? launch_sweep_tiled_n2(a, workspace, stream) : launch_sweep_tiled_n1(a, workspace, stream);
+    return cus[dev];
 }
 #endif
 
 // Launches the pre-pass, this variant's tiled kernel, then the gather kernel on the tiles it flagged.
-hipError_t PDEPTH_CAT(launch_sweep_tiled_n, PDEPTH_NSUB)(const SweepArgs& a, void* workspace, hipStream_t stream) {
+hipError_t PDEPTH_CAT(launch_sweep_tiled_n, PDEPTH_NSUB)(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready) {
     const int tiles16_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;  // the gather kernel's (and the flags') tiles
     const int tiles_x = (a.W + TW * NSUB - 1) / (TW * NSUB);                  // this kernel's work items per row
     const int tiles = tiles_x * tiles_y;
     int* flags = reinterpret_cast<int*>(workspace);
     float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + flag_bytes(a.B, a.H, a.W));
-    hipError_t e = launch_pack_c4(a, workspace, stream);
+    hipError_t e = packed_ready ? clear_sweep_flags(a, workspace, stream) : launch_pack_c4(a, workspace, stream);
     if (e != hipSuccess) return e;
     const size_t lds = tiled_lds_bytes(a.D);
     int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + flag_only_bytes(a.B, a.H, a.W));
     // persistent grid: as many blocks as the device holds at once (3 per CU at D <= 64), a multiple of 8
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-            n_cu = 256;
-    }
+    const int n_cu = sweep_device_cus();
     const int per_cu = (int)((160 * 1024) / (lds + 640));
     constexpr int max_per_cu = PDEPTH_OCC * 4 / NW;  // blocks per CU the register budget allows
     int nblk = n_cu * (per_cu < 1 ? 1 : per_cu > max_per_cu ? max_per_cu : per_cu);
@@ -913,15 +928,21 @@ hipError_t PDEPTH_CAT(launch_sweep_tiled_n, PDEPTH_NSUB)(const SweepArgs& a, voi
     const long long full = 8ll * ((tiles + 7) / 8) * a.B;  // one block per item of the largest XCD band, times 8
     if (full <= nblk) nblk = (int)full;
     dim3 grid(nblk);
+    // (the dynamic-LDS attribute is per kernel, sticky and the same on every device: set it whenever more than the
+    //  default is needed -- no cached state, and a failure is reported instead of surfacing as a launch error)
     if (a.metric == 0) {
         auto kern = PDEPTH_VARIANT::sweep_tiled_kernel<0>;
-        static size_t lds_set0 = 64 * 1024;  // (the attribute is per kernel and sticky: raise it only when needed)
-        if (lds > lds_set0) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set0 = lds; }
+        if (lds > 64 * 1024) {
+            e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles);
     } else {
         auto kern = PDEPTH_VARIANT::sweep_tiled_kernel<1>;
-        static size_t lds_set1 = 64 * 1024;
-        if (lds > lds_set1) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set1 = lds; }
+        if (lds > 64 * 1024) {
+            e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles);
     }
     e = hipGetLastError();

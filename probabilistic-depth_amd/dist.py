@@ -58,3 +58,40 @@ def max_over_ranks(x: float, device) -> float:
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def assemble_bench_line(allm, wall, *, steps, warmup, batch_per_gpu, world, metric, unit, workload,
+                        bytes_per_volume, hbm_peak_gbs, dtype="f32", extras=None):
+    """Rank-0 aggregation of a benchmark run -> the dict bench.py prints as its ONE JSON line.
+
+    allm [world, >=2]: the gathered per-rank vectors (column 0 = volumes the rank owns per step, column 1 = its average
+    kernel time per step in ms, HIP events); wall = max over ranks of the wall time of the `steps` timed steps.
+    value = volumes ALL ranks processed / wall (whole-job throughput); roofline.achieved is per launch, from rank 0's
+    kernel time and its own volumes.  Pure function of its arguments (the gloo test drives it with two ranks).
+    """
+    allm = allm.detach().cpu().double()
+    if allm.shape[0] != world:
+        raise ValueError(f"gathered metrics of {allm.shape[0]} ranks, world size {world}")
+    per_step = float(allm[:, 0].sum())
+    vols = per_step * steps
+    kern_ms = float(allm[0, 1])
+    bytes_per_launch = bytes_per_volume * float(allm[0, 0])
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    line = {
+        "metric": metric, "value": vols / wall, "unit": unit, "n_gpus": int(world), "steps": int(steps),
+        "warmup": int(warmup), "ms_per_step": wall / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": workload, "global_batch": int(per_step), "per_gpu_batch": int(batch_per_gpu),
+                   "parallelism": f"dp{int(world)}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": hbm_peak_gbs, "unit": "GB/s",
+                     "frac": achieved / hbm_peak_gbs, "traffic": None, "kernel_ms": kern_ms,
+                     "algorithmic_bytes_per_launch": bytes_per_launch},
+        "per_rank_kernel_ms": [float(x) for x in allm[:, 1]],
+    }
+    if extras:
+        for k, v in extras.items():
+            if k == "roofline":
+                line["roofline"].update(v)
+            else:
+                line[k] = v
+    return line

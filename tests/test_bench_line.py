@@ -1,0 +1,74 @@
+"""CPU suite: bench.py's N > 1 reporting path.  Two gloo ranks gather their metric vectors exactly as bench.py does
+and rank 0 assembles the JSON line with the function bench.py uses (pdist.assemble_bench_line)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import pdepth_amd  # noqa: F401
+from pdepth_amd import dist as pdist
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rank(rank, world, port, out_path):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, w, _ = pdist.init_from_env(backend="gloo")
+    lo, hi = pdist.shard_range(4 * w, r, w)                 # weak scaling: 4 volumes per rank
+    pdist.barrier()
+    wall = pdist.max_over_ranks(0.010 * (1 + r), torch.device("cpu"))     # rank 1 is the slower one: 20 ms
+    vec = torch.tensor([hi - lo, 0.5 + 0.25 * r, 21.5, 1.0], dtype=torch.float32)
+    allm = pdist.gather_metrics(vec)
+    if r == 0:
+        line = pdist.assemble_bench_line(allm, wall, steps=10, warmup=2, batch_per_gpu=4, world=w, metric="m", unit="u",
+                                         workload="w", bytes_per_volume=1000, hbm_peak_gbs=8000.0,
+                                         extras={"roofline": {"traffic": 123}, "gather_fallback_tiles": 0})
+        json.dump(line, open(out_path, "w"))
+    pdist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_bench_line(tmp_path):
+    out = str(tmp_path / "line.json")
+    mp.spawn(_rank, args=(2, _free_port(), out), nprocs=2, join=True)
+    line = json.load(open(out))
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["config"]["parallelism"] == "dp2"
+    assert line["value"] == pytest.approx(8 * 10 / 0.020)          # all ranks' volumes / slowest rank's wall
+    assert line["ms_per_step"] == pytest.approx(2.0)
+    assert line["per_rank_kernel_ms"] == pytest.approx([0.5, 0.75])
+    assert line["roofline"]["achieved"] == pytest.approx(4 * 1000 / 0.5e-3 / 1e9)   # rank 0's launch
+    assert line["roofline"]["traffic"] == 123 and line["scaling"] == "weak" and line["vs_baseline"] is None
+    json.dumps(line)
+
+
+def test_assemble_rejects_a_wrong_world_size():
+    with pytest.raises(ValueError):
+        pdist.assemble_bench_line(torch.zeros(1, 4), 1.0, steps=1, warmup=0, batch_per_gpu=4, world=2, metric="m",
+                                  unit="u", workload="w", bytes_per_volume=1, hbm_peak_gbs=1.0)
+
+
+def test_self_launch_starts_ranks_before_touching_the_gpu():
+    """`python bench.py --gpus 2` with no launcher must start the ranks itself and fail non-zero when they fail: here
+    (no GPU) every rank dies on the GPU assertion, after torch.distributed.run has started them with WORLD_SIZE=2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode != 0
+    if not torch.cuda.is_available():
+        assert "bench.py needs a GPU" in p.stderr
