@@ -56,8 +56,12 @@ enum { PDEPTH_BLAS_FMA = 0, PDEPTH_BLAS_SEPARATE = 1 };
  * selector: AUTO = explicit shared-reciprocal fma divide chain, DIRECT = compiler IEEE divides; the two are
  * bit-identical for every position within reach of the image, tests/test_hip_parity.py) */
 enum {
-    PDEPTH_ALGO_AUTO = 0,   /* fastest algorithm valid for the given geometry          */
-    PDEPTH_ALGO_DIRECT = 1  /* per-plane bilinear gather, reference op order (any pose) */
+    PDEPTH_ALGO_AUTO = 0,    /* fastest algorithm valid for the given geometry          */
+    PDEPTH_ALGO_DIRECT = 1,  /* per-plane bilinear gather, reference op order (any pose) */
+    /* implementation selectors (parity tests, A/B timing): what AUTO may pick, forced.  Same workspace as AUTO. */
+    PDEPTH_ALGO_TILED_1 = 2, /* LDS-tiled band kernel, one 16x4 tile per block                          */
+    PDEPTH_ALGO_TILED_2 = 3, /* LDS-tiled band kernel, two tiles per block (D <= 64)                    */
+    PDEPTH_ALGO_CELLS = 4    /* cell-list kernels (L2 metric, D <= 128; other inputs: PDEPTH_E_ARG)     */
 };
 
 /* Geometry + layout of one batched sweep call. */

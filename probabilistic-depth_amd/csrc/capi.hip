@@ -46,7 +46,7 @@ pdepth::SweepArgs make_args(const pdepth_sweep_desc* d, const pdepth_camera* cam
     a.d_candi = d_candi;
     a.B = d->B; a.V = d->V; a.C = d->C; a.D = d->D; a.H = d->H; a.W = d->W;
     a.metric = d->metric; a.sigma = d->sigma; a.blas_mode = d->blas_mode;
-    a.fast_div = d->algo == PDEPTH_ALGO_AUTO;
+    a.fast_div = d->algo != PDEPTH_ALGO_DIRECT;
     a.ref_bstride = d->ref_bstride; a.src_bstride = d->src_bstride; a.src_vstride = d->src_vstride;
     return a;
 }
@@ -77,7 +77,7 @@ size_t tiled_ws_bytes(const pdepth_sweep_desc* d) {
 
 // does ALGO_AUTO run on the packed (channel-group-planar) copy of the source for this shape?
 bool uses_packed_source(const pdepth_sweep_desc* d) {
-    return d->algo == PDEPTH_ALGO_AUTO && d->D <= pdepth::sweep_tiled_max_planes() && d->W <= 32767 && d->H <= 32767 &&
+    return d->algo != PDEPTH_ALGO_DIRECT && d->D <= pdepth::sweep_tiled_max_planes() && d->W <= 32767 && d->H <= 32767 &&
            (long long)((d->C + 3) / 4 + 2) * d->H * d->W * 16 < (1ll << 31);
 }
 
@@ -92,8 +92,14 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
     if (!cost && !logp && !depth) return fail(PDEPTH_E_ARG, "%s: no output requested", who);
     if (d->metric != PDEPTH_METRIC_L2 && d->metric != PDEPTH_METRIC_L1)
         return fail(PDEPTH_E_ARG, "%s: undefined metric for feature distance (%d)", who, d->metric);
-    if (d->algo != PDEPTH_ALGO_AUTO && d->algo != PDEPTH_ALGO_DIRECT)
+    if (d->algo < PDEPTH_ALGO_AUTO || d->algo > PDEPTH_ALGO_CELLS)
         return fail(PDEPTH_E_ARG, "%s: unknown algo %d", who, d->algo);
+    if (d->algo == PDEPTH_ALGO_CELLS && (d->metric != PDEPTH_METRIC_L2 || d->D > pdepth::sweep_cells_max_planes()))
+        return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_CELLS needs the L2 metric and D <= %d", who, pdepth::sweep_cells_max_planes());
+    if (d->algo == PDEPTH_ALGO_TILED_2 && d->D > 64)
+        return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_TILED_2 needs D <= 64", who);
+    if (d->algo >= PDEPTH_ALGO_TILED_1 && !uses_packed_source(d))
+        return fail(PDEPTH_E_ARG, "%s: the selected implementation does not support this shape", who);
     if (!(d->sigma > 0.0f) && !(d->sigma < 0.0f))
         return fail(PDEPTH_E_ARG, "%s: sigma must be non-zero", who);
     if (d->D > pdepth::sweep_direct_max_planes(d->C))
@@ -110,8 +116,13 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
                         "query pdepth_sweep_workspace_bytes()", who, need, workspace_bytes);
         if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0)
             return fail(PDEPTH_E_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
+        if (d->algo == PDEPTH_ALGO_TILED_1)
+            return launched(pdepth::launch_sweep_tiled_n1(a, workspace, (hipStream_t)stream, packed_ready), who);
+        if (d->algo == PDEPTH_ALGO_TILED_2)
+            return launched(pdepth::launch_sweep_tiled_n2(a, workspace, (hipStream_t)stream, packed_ready), who);
         // (L1 has no correlation form: always the tiled kernel)
-        if (d->metric == PDEPTH_METRIC_L2 && d->D <= pdepth::sweep_cells_max_planes() && sweep_impl() == IMPL_CELLS)
+        if (d->algo == PDEPTH_ALGO_CELLS || (d->metric == PDEPTH_METRIC_L2 && d->D <= pdepth::sweep_cells_max_planes() &&
+                                             sweep_impl() == IMPL_CELLS))
             return launched(pdepth::launch_sweep_cells(a, workspace, (hipStream_t)stream, packed_ready), who);
         return launched(pdepth::launch_sweep_tiled(a, workspace, (hipStream_t)stream, packed_ready), who);
     }
@@ -126,7 +137,7 @@ int pdepth_abi_version(void) { return PDEPTH_ABI_VERSION; }
 const char* pdepth_last_error(void) { return g_err; }
 
 size_t pdepth_sweep_workspace_bytes(const pdepth_sweep_desc* desc) {
-    if (!desc || desc->algo != PDEPTH_ALGO_AUTO) return 0;
+    if (!desc || desc->algo == PDEPTH_ALGO_DIRECT) return 0;
     if (desc->B <= 0 || desc->D <= 0 || desc->H <= 0 || desc->W <= 0) return 0;
     return tiled_ws_bytes(desc);
 }

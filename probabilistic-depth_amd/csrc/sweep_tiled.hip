@@ -878,14 +878,9 @@ hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t strea
 
 // Two tiles per block pay off when two such blocks fit a CU (the cost tiles of both sub-tiles live in LDS: D <= 64)
 // and the image is large enough for the wider windows not to dominate; measured on the BASELINE configurations.
-// PDEPTH_TILED_VARIANT=1|2 (tests: force a variant, any shape) is read once per process.
+// (PDEPTH_ALGO_TILED_1 / _2 force a variant.)
 hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready) {
-    static const int forced = [] {
-        const char* f = getenv("PDEPTH_TILED_VARIANT");
-        return (f && (f[0] == '1' || f[0] == '2')) ? f[0] - '0' : 0;
-    }();
-    bool two = a.D <= 64 && (long long)a.H * a.W >= 96 * 1024 && a.W >= 128;
-    if (forced) two = forced == 2;
+    const bool two = a.D <= 64 && (long long)a.H * a.W >= 96 * 1024 && a.W >= 128;
     return two ? launch_sweep_tiled_n2(a, workspace, stream, packed_ready) : launch_sweep_tiled_n1(a, workspace, stream, packed_ready);
 }
 

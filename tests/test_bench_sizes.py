@@ -1,0 +1,121 @@
+"""GPU suite: parity at the sizes that are benchmarked (BASELINE configs 2, 3 and 5), for every implementation behind
+ALGO_AUTO.  Tolerances as in test_hip_parity.py: cost / logp 2e-4 abs + 2e-5 rel, depth 1e-4 abs (north star)."""
+import numpy as np
+import pytest
+import torch
+
+import pdepth_amd  # noqa: F401
+from pdepth_amd import ops, synth
+from util import DEPTH_ATOL, oracle_batch, to_dev
+
+pytestmark = pytest.mark.gpu
+COST_ATOL, COST_RTOL = 2e-4, 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU suite needs a GPU"
+    return torch.device("cuda:0")
+
+
+def _sweep(d, algo, **kw):
+    return ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0,
+                         algo=algo, want_cost=True, **kw)
+
+
+@pytest.mark.parametrize("pose", ["mono", "stereo"])
+def test_bench_workload_against_the_oracle(dev, pose):
+    """EXACTLY what bench.py times (configs[1]: mono, B=4, C=67, D=64, 256x512, seeds of config id 2; config 3's
+    stereo pose as well): one full volume of the batch through the CPU oracle -- cost, log-DPV and depth -- for every
+    implementation; the other three volumes of each implementation against the gather kernel (reference op order)."""
+    b = synth.make_batch(2, 4, C=67, D=64, H=256, W=512, V=1, pose=pose)
+    d = to_dev(b, dev)
+    item = 1
+    one = {k: (v[item:item + 1] if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    ocost, ologp, odepth = oracle_batch(one)
+    cd, ld, dd = _sweep(d, "direct")
+    for algo in ("auto", "tiled1", "tiled2", "cells", "direct"):
+        cost, logp, depth = _sweep(d, algo)
+        np.testing.assert_allclose(cost[item].cpu().numpy(), ocost[0].numpy(), rtol=COST_RTOL, atol=COST_ATOL, err_msg=algo)
+        np.testing.assert_allclose(logp[item].cpu().numpy(), ologp[0].numpy(), rtol=0, atol=2e-4, err_msg=algo)
+        err = (depth[item].cpu() - odepth[0]).abs().max().item()
+        assert err <= DEPTH_ATOL, f"{algo} ({pose}): depth differs from the oracle by {err:.3e}"
+        # all four volumes: same answer as the gather kernel (itself pinned to the oracle on volume `item`)
+        assert (depth - dd).abs().max().item() <= 1e-4, algo
+        assert ((cost - cd).abs() / (1.0 + cd.abs())).max().item() < 2e-5, algo
+    # the packed-source entry is the same computation
+    ps = ops.pack_source(d["src"], 64)
+    cp, lp, dp = ops.sweep_dpv(d["ref"], ps, d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0, want_cost=True)
+    ca, la, da = _sweep(d, "auto")
+    assert torch.equal(cp, ca) and torch.equal(lp, la) and torch.equal(dp, da)
+
+
+def test_config5_reduced_area_against_the_oracle(dev):
+    """BASELINE config 5 (D=128, 4 source views, C=67) at 64x128: every plane / view / channel loop bound of the full
+    problem, an area the oracle finishes in seconds."""
+    b = synth.make_batch(5, 2, C=67, D=128, H=64, W=128, V=4, pose="mono")
+    ocost, ologp, odepth = oracle_batch(b)
+    d = to_dev(b, dev)
+    for algo in ("auto", "tiled1", "cells", "direct"):
+        cost, logp, depth = _sweep(d, algo)
+        np.testing.assert_allclose(cost.cpu().numpy(), ocost.numpy(), rtol=COST_RTOL, atol=COST_ATOL, err_msg=algo)
+        np.testing.assert_allclose(logp.cpu().numpy(), ologp.numpy(), rtol=0, atol=2e-4, err_msg=algo)
+        assert (depth.cpu() - odepth).abs().max().item() <= DEPTH_ATOL, algo
+
+
+def test_config5_full_size_properties(dev):
+    """Config 5 at its full size (one volume of the per-GPU share: D=128, 512x1024, V=4, C=67; the oracle would need
+    18 GB per view here): size-independent properties, and agreement of the fast implementations with the gather
+    kernel, which evaluates in the reference's op order and is pinned to the oracle at every smaller size."""
+    b = synth.make_batch(5, 1, C=67, D=128, H=512, W=1024, V=4, pose="mono")
+    d = to_dev(b, dev)
+    cd, ld, dd = _sweep(d, "direct")
+    assert torch.isfinite(cd).all() and (cd >= 0).all()
+    for algo in ("auto", "cells"):
+        cost, logp, depth = _sweep(d, algo)
+        assert torch.isfinite(cost).all() and (cost >= 0).all()
+        assert (torch.exp(logp).sum(1) - 1).abs().max().item() < 2e-5              # a distribution over D
+        assert depth.min().item() >= 5.0 - 1e-4 and depth.max().item() <= 40.0 + 1e-4
+        lp2, dp2 = ops.dpv_reduce(cost, d["d_candi"])                              # fused == unfused chain
+        assert (lp2 - logp).abs().max().item() < 5e-5 and (dp2 - depth).abs().max().item() < DEPTH_ATOL
+        rel = ((cost - cd).abs() / (1.0 + cd.abs())).max().item()
+        assert rel < 2e-5, f"{algo}: cost differs from the gather kernel by {rel:.2e} (relative)"
+        # two kernels that are each within 1e-4 of the reference may be 2e-4 apart (four views and 128 planes: the
+        # logits, and with them the weight of one ulp of a cost, are at their largest here)
+        assert (depth - dd).abs().max().item() <= 2e-4, algo
+    # linearity of the whole path in the features: scaling ref and src by s scales every cost by s^2
+    s = 0.5
+    c2 = ops.sweep_cost(d["ref"] * s, d["src"] * s, d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0)
+    ca = ops.sweep_cost(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0)
+    assert ((c2 - ca * s * s).abs() / (1.0 + ca.abs())).max().item() < 1e-5
+
+
+def test_band_mode_on_encoder_features(dev):
+    """The correlation form (Q - 2XW) + |r|^2 cancels when features are large against their differences.  Real encoder
+    outputs are not N(0,1): non-zero mean per channel, ref and src strongly correlated.  Take the feature maps of the
+    host model's encoder (seeded weights, two consecutive synthetic frames) and require the 1e-4 depth bound of the
+    fast implementations against the oracle evaluated on those very features."""
+    from pdepth_amd.models import get_model
+    torch.manual_seed(0)
+    cfg = synth.default_cfg("default")
+    model = get_model(cfg, 0).to(dev).eval()
+    synth.seed_weights(model, seed=8)
+    rng = np.random.default_rng(31)
+    base = rng.uniform(0, 1, size=(2, 1, 3, 256, 512)).astype(np.float32)
+    rgb = np.concatenate([np.roll(base, 3, axis=4) * 0.9 + 0.05, base], axis=1)   # [B, V+1, 3, H, W], last = reference
+    frames = torch.from_numpy(rgb)
+    with torch.no_grad():
+        feat = model._features({"rgb": frames.to(dev)})
+    feat = feat[-1] if isinstance(feat, (tuple, list)) else feat
+    assert feat.dim() == 5 and feat.shape[2] == 67, feat.shape                                # [B, V+1, C, h, w]
+    B, V1, C, h, w = feat.shape
+    b = synth.make_batch(41, B, C=C, D=64, H=h, W=w, V=V1 - 1, pose="stereo")
+    b["ref"], b["src"] = feat[:, -1].float().cpu().contiguous(), feat[:, :-1].float().cpu().contiguous()
+    mean_abs = float(b["ref"].mean(dim=(0, 2, 3)).abs().mean())
+    ocost, ologp, odepth = oracle_batch(b)
+    d = to_dev(b, dev)
+    for algo in ("auto", "tiled1", "cells", "direct"):
+        cost, logp, depth = _sweep(d, algo)
+        err = (depth.cpu() - odepth).abs().max().item()
+        assert err <= DEPTH_ATOL, f"{algo}: depth differs by {err:.3e} on encoder features (mean |channel mean| {mean_abs:.2f})"
+        np.testing.assert_allclose(cost.cpu().numpy(), ocost.numpy(), rtol=COST_RTOL, atol=COST_ATOL, err_msg=algo)

@@ -384,21 +384,22 @@ def test_fuzz_large_tiled_against_gather(dev):
     print(f"large fuzz: worst relative difference {worst:.2e}, {fallback} tiles through the gather kernel")
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
-def test_both_tiled_kernel_variants_on_small_ragged_shapes(dev, variant, monkeypatch):
-    """The library holds two builds of the tiled kernel (one / two 16x4 tiles per block) and picks one per call by
-    shape; PDEPTH_TILED_VARIANT forces one, so that both meet the ragged sizes, odd tile counts, multi-view and
-    D > 64 cases whatever the heuristic would choose."""
-    monkeypatch.setenv("PDEPTH_TILED_VARIANT", variant)
+@pytest.mark.parametrize("variant", ["tiled1", "tiled2", "cells"])
+def test_every_sweep_implementation_on_small_ragged_shapes(dev, variant):
+    """The library holds two builds of the tiled kernel (one / two 16x4 tiles per block; ALGO_AUTO picks one per call
+    by shape) and the cell-list kernels; the implementation selectors force one, so that each meets the ragged sizes,
+    odd tile counts, multi-view and D > 64 cases whatever the heuristic would choose."""
     rng = np.random.default_rng(7)
     for case in range(30):
         H, W = int(rng.integers(3, 90)), int(rng.integers(3, 150))
-        C, D, V = int(rng.integers(1, 20)), int(rng.integers(1, 100)), int(rng.integers(1, 3))
+        C, D, V = int(rng.integers(1, 20)), int(rng.integers(1, 100 if variant != "tiled2" else 65)), int(rng.integers(1, 3))
+        if variant == "cells" and case % 3 == 0:
+            D = 64 if case % 2 else 128   # the straight-line kernel only runs full 64-plane windows
         b = synth.make_batch(700 + case, 2 if case % 4 == 0 else 1, C=C, D=D, H=H, W=W, V=V,
                              pose=("mono", "stereo", "wide")[case % 3], cx_off=float(rng.uniform(-2, 2)))
         d = to_dev(b, dev)
         args = (d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 9.0)
-        ca, la, da = ops.sweep_dpv(*args, want_cost=True, algo="auto")
+        ca, la, da = ops.sweep_dpv(*args, want_cost=True, algo=variant)
         cd, ld, dd = ops.sweep_dpv(*args, want_cost=True, algo="direct")
         ca, cd = ca.cpu().numpy(), cd.cpu().numpy()
         assert np.array_equal(np.isnan(ca), np.isnan(cd)), f"case {case}: NaN pattern differs"

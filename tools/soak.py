@@ -8,7 +8,7 @@ dev=torch.device('cuda')
 rng=np.random.default_rng(int(sys.argv[1]) if len(sys.argv)>1 else 1)
 worst=0; n=0; fb=0
 for case in range(int(sys.argv[2]) if len(sys.argv)>2 else 200):
-    os.environ['PDEPTH_TILED_VARIANT']=str(1+case%2)
+    algo=('tiled1','tiled2')[case%2]
     H,W=int(rng.integers(2,200)),int(rng.integers(2,400)); C,D,V=int(rng.integers(1,72)),int(rng.integers(1,161)),int(rng.integers(1,4))
     B=int(rng.integers(1,3))
     pose=('mono','stereo','wide','identity')[int(rng.integers(0,4))]
@@ -23,7 +23,7 @@ for case in range(int(sys.argv[2]) if len(sys.argv)>2 else 200):
     elif k==4: b['d_candi']=np.sort(rng.uniform(0.5,60.0,size=D))[::-1].copy()
     d={kk:(v.to(dev) if isinstance(v,torch.Tensor) else v) for kk,v in b.items()}
     metric='L1' if case%7==3 else 'L2'
-    ca=ops.sweep_cost(d['ref'],d['src'],d['K'],d['R'],d['t'],d['rays'],d['cxcy'],d['d_candi'],8.0,feat_dist=metric,algo='auto').cpu().numpy(); fb+=_native.fallback_tiles(B,H,W)
+    ca=ops.sweep_cost(d['ref'],d['src'],d['K'],d['R'],d['t'],d['rays'],d['cxcy'],d['d_candi'],8.0,feat_dist=metric,algo=algo).cpu().numpy(); fb+=_native.fallback_tiles(B,H,W)
     cd=ops.sweep_cost(d['ref'],d['src'],d['K'],d['R'],d['t'],d['rays'],d['cxcy'],d['d_candi'],8.0,feat_dist=metric,algo='direct').cpu().numpy()
     if not np.array_equal(np.isnan(ca),np.isnan(cd)): print('NaN pattern differs',case,pose,H,W,C,D,V,B,k,metric); continue
     fin=np.isfinite(cd)
