@@ -154,6 +154,21 @@ int pdepth_dpv_reduce_f32(const float *logits, const float *d_candi, int32_t B, 
                           int32_t H, int32_t W, float *logp, float *depth, void *stream);
 
 /*
+ * The same single pass with optional extras (any output may be NULL, not all): replaces, next to the lines above,
+ *   addend       [B,D,H,W] or NULL : x = logits + addend before the softmax -- the feedback update
+ *                                    F.log_softmax(BV_cur + BV_resi, dim=1)            (models/models.py:694)
+ *   prob         [B,D,H,W]         : exp(logp), the decoder's input torch.exp(BV_cur_upd) (models/models.py:697, :651)
+ *   variance     [B,H,W]           : sum_k (d_k - E[d])^2 p_k, the inline lines of the evaluation loop
+ *                                                                        (trainer/default_trainer.py:333-336)
+ *   logp_quarter [B,D,H/4,W/4]     : F.interpolate(logp, scale_factor=0.25, mode='nearest'), the prev_output of the
+ *                                    next frame                          (trainer/default_trainer.py:221)
+ * logp may alias logits; no other aliasing.
+ */
+int pdepth_dpv_reduce_ex_f32(const float *logits, const float *addend, const float *d_candi, int32_t B, int32_t D,
+                             int32_t H, int32_t W, float *logp, float *prob, float *depth, float *variance,
+                             float *logp_quarter, void *stream);
+
+/*
  * Expectation only: depth[b,y,x] = sum_k d_k * (bv_log ? exp(dpv[b,k,y,x]) : dpv[b,k,y,x]).
  * Replaces dpv_to_depthmap (utils/img_utils.py:52-61), batched over B.
  */
@@ -185,6 +200,24 @@ int pdepth_warp_feature_f32(const pdepth_sweep_desc *desc, const pdepth_camera *
  */
 int pdepth_sample_coords_f32(const pdepth_sweep_desc *desc, const pdepth_camera *cam,
                              const float *d_candi, float *ix, float *iy, void *stream);
+
+/*
+ * Uncertainty-field collapse: replaces gen_ufield (utils/img_utils.py:268-358; called through compute_unc_field
+ * :178-181 by the evaluation loop, trainer/default_trainer.py:243-244), batched over B.
+ *   dpv [B,D,H,W] (log-DPV if bv_log, else probabilities), intr [B,3,3] full-resolution intrinsics, mask [B,H,W] or
+ *   NULL (validity of the ground-truth volume).  unc_ang = rows the volume is shifted by (cfgx["unc_ang"]; 0 = no
+ *   shift), [z_start, z_end] = height band (cfgx: unc_shift, unc_shift + unc_span), min_depth / quash as in the
+ *   reference's branches (:269-290: cfgx and ILIM 3 / 1, KITTI 0 / 0), oob_depth = the depth the reference assigns to
+ *   rows shifted in from outside (sum_k d_k for a log-DPV -- exp of the zero padding -- else 0).
+ *   plane [B,D,W] = per column the mean depth distribution of the pixels in the band (NaN for columns without one, as
+ *   in the reference), depth_zero [B,H,W] = E[d] masked to those pixels.  The min/max normalisation (:353-355) is a
+ *   [D,W] post-process left to the host.  Workspace: pdepth_ufield_workspace_bytes (two [B,H,W] maps + [B,W]).
+ */
+size_t pdepth_ufield_workspace_bytes(int32_t B, int32_t H, int32_t W);
+int pdepth_ufield_f32(const float *dpv, const float *d_candi, const float *intr, const float *mask, int32_t B,
+                      int32_t D, int32_t H, int32_t W, int32_t bv_log, float unc_ang, float z_start, float z_end,
+                      float min_depth, int32_t quash, float oob_depth, float *plane, float *depth_zero,
+                      void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * DPV Bayesian fusion of the upsample mode: replaces gen_dpv_withmask (utils/img_utils.py:360-375, with

@@ -26,7 +26,7 @@ import torch.nn.functional as F
 __all__ = [
     "powerf", "unit_rays", "intrinsics_from_fov", "plane_coords", "sweep_cost",
     "warp_feature", "log_dpv", "dpv_to_depthmap", "sweep_dpv", "sample_coords", "gen_dpv_withmask", "dpv_fuse",
-    "correlation", "inverse_warp",
+    "correlation", "inverse_warp", "dpv_variance", "gen_ufield",
 ]
 
 
@@ -183,16 +183,90 @@ def dpv_to_depthmap(dpv, d_candi, BV_log=False):
 
 
 def dpv_variance(dpv_log, d_candi):
-    """Mean and variance of the depth distribution of a [1,D,H,W] log-DPV -> ([H,W], [H,W]).
+    """Mean and variance of the depth distribution of a [1,D,H,W] log-DPV -> ([H,W], [H,W]), float64.
 
     trainer/default_trainer.py:333-336 (evaluation loop, inline): z = exp(logDPV.squeeze(0)),
-    mean = sum(d * z, 0), variance = sum((d - mean)**2 * z, 0).  Restated op for op; the reference has no callable
-    for it, so this restatement is pinned by inspection only."""
+    mean = sum(d * z, 0), variance = sum((d - mean)**2 * z, 0) with d = torch.tensor(d_candi) -- a FLOAT64 tensor
+    (d_candi is a float64 numpy array), so both sums are promoted to float64.  Pinned by fixture g13, which executes
+    those four lines of the reference file itself (tests/golden/make_golden_r2.py)."""
     z = torch.exp(dpv_log.squeeze(0))
-    d = torch.tensor(d_candi).unsqueeze(1).unsqueeze(1).float()
+    d = torch.tensor(np.asarray(d_candi)).unsqueeze(1).unsqueeze(1)
     mean = torch.sum(d * z, dim=0)
     variance = torch.sum(((d - mean) ** 2) * z, dim=0)
     return mean, variance
+
+
+def _convert_flowfield(flow):
+    """Pixel offsets -> the normalised grid the reference hands to grid_sample.  utils/img_utils.py:170-176."""
+    yv, xv = torch.meshgrid([torch.arange(0, flow.shape[1]).float(), torch.arange(0, flow.shape[2]).float()], indexing="ij")
+    ystep = 2. / float(flow.shape[1] - 1)
+    xstep = 2. / float(flow.shape[2] - 1)
+    flow[0, :, :, 0] = -1 + xv * xstep - flow[0, :, :, 0] * xstep
+    flow[0, :, :, 1] = -1 + yv * ystep - flow[0, :, :, 1] * ystep
+    return flow
+
+
+def _depth_to_pts(depthf, intr):
+    """[1,H,W] depth -> [3,H,W] points with integer pixel coordinates.  utils/img_utils.py:111-134."""
+    depth = depthf[0]
+    fx, cx, fy, cy = intr[0, 0], intr[0, 2], intr[1, 1], intr[1, 2]
+    yf, xf = torch.meshgrid([torch.arange(0, depth.shape[0]).float(), torch.arange(0, depth.shape[1]).float()], indexing="ij")
+    yf = (yf - cy) / fy
+    xf = (xf - cx) / fx
+    return torch.cat([torch.mul(xf, depth).unsqueeze(0), torch.mul(yf, depth).unsqueeze(0), depth.unsqueeze(0)], 0)
+
+
+def gen_ufield(dpv, d_candi, intr, unc_ang, unc_shift, unc_span, BV_log=True, mask=None, normalize=False):
+    """Uncertainty-field collapse of a [1,D,H,W] (log-)DPV -> (plane [1,D,W], masked depth map [1,H,W]).
+
+    utils/img_utils.py:268-358 with the cfgx branch (:269-275: pshift = unc_ang rows, z band [unc_shift, unc_shift +
+    unc_span], maxd 100, mind 3, quash on): shift the volume by pshift rows (grid_sample nearest over a flow field
+    built with the (size-1) convention, :292-300 -- the grid is NOT the identity of align_corners=False sampling: the
+    last column / rows can fall out of the image), depth maps of the shifted and the original volume (:306-307),
+    height-band + range mask on the shifted points (:311-315), optional validity mask (:316-321), quash to the
+    nearest surface per column (:324-331), shift the mask back (:334-338), masked depth (:338), masked column sums of
+    the probabilities divided by the column's mask count (:341-349), optional min/max normalisation (:353-355).
+    """
+    zstart, zend, maxd, mind = unc_shift, unc_shift + unc_span, 100., 3.
+    H, W = dpv.shape[2], dpv.shape[3]
+    if unc_ang != 0:
+        flow = torch.zeros((1, H, W, 2)).float()
+        flow_inv = torch.zeros((1, H, W, 2)).float()
+        flow[:, :, :, 1] = unc_ang
+        flow_inv[:, :, :, 1] = -unc_ang
+        _convert_flowfield(flow)
+        _convert_flowfield(flow_inv)
+        dpv_shifted = F.grid_sample(dpv, flow, mode='nearest', align_corners=False)
+    else:
+        dpv_shifted = dpv.clone()
+    depth_shifted = dpv_to_depthmap(dpv_shifted, d_candi, BV_log=BV_log)
+    depth_pred = dpv_to_depthmap(dpv, d_candi, BV_log=BV_log)
+    pts = _depth_to_pts(depth_shifted, intr)
+    zero_mask = (~((pts[1] > zend) | (pts[1] < zstart) | (pts[2] > maxd - 1) | (pts[2] < mind))).float()
+    if mask is not None:
+        if unc_ang != 0:
+            mask_shifted = F.grid_sample(mask.unsqueeze(1), flow, mode='nearest', align_corners=False).squeeze(1)
+        else:
+            mask_shifted = mask.clone()
+        zero_mask = zero_mask * mask_shifted.squeeze(0)
+    cleaned = (depth_shifted * zero_mask).squeeze(0)
+    cleaned[cleaned == 0] = 1000
+    min_col, _ = torch.min(cleaned, axis=0)
+    quash = ((cleaned > min_col - 1.) & (cleaned < min_col + 1.)).float()
+    zero_mask = zero_mask * quash
+    if unc_ang != 0:
+        zm_pred = F.grid_sample(zero_mask.unsqueeze(0).unsqueeze(0), flow_inv, mode='nearest', align_corners=False).squeeze(0).squeeze(0)
+    else:
+        zm_pred = zero_mask.clone()
+    depth_zero = depth_pred * zm_pred
+    zm_rep = zm_pred.repeat([len(d_candi), 1, 1]).unsqueeze(0)
+    plane = torch.sum((torch.exp(dpv) if BV_log else dpv) * zm_rep, axis=2)
+    plane = plane / torch.sum(zero_mask, axis=0)
+    if normalize:
+        minval, _ = plane.min(1)
+        maxval, _ = plane.max(1)
+        plane = (plane - minval) / (maxval - minval)
+    return plane, depth_zero
 
 
 def sweep_dpv(feat_ref, feat_src, d_candi, R, t, K, rays, cx, cy, sigma, metric="L2"):

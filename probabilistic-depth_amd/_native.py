@@ -10,6 +10,7 @@ import ctypes
 import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
+import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -26,7 +27,8 @@ EXPORTED_SYMBOLS = (
     "pdepth_dpv_expect_f32", "pdepth_warp_feature_f32", "pdepth_sample_coords_f32",
     "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32", "pdepth_inverse_warp_f32",
     "pdepth_dpv_moments_f32", "pdepth_correlation_backward_f32",
-    "pdepth_pack_source_f32", "pdepth_sweep_dpv_packed_f32",
+    "pdepth_pack_source_f32", "pdepth_sweep_dpv_packed_f32", "pdepth_dpv_reduce_ex_f32",
+    "pdepth_ufield_workspace_bytes", "pdepth_ufield_f32",
 )
 
 
@@ -112,6 +114,13 @@ def load():
                                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.pdepth_dpv_reduce_f32.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                           c_void_p, c_void_p]
+    lib.pdepth_dpv_reduce_ex_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.pdepth_ufield_workspace_bytes.restype = c_size_t
+    lib.pdepth_ufield_workspace_bytes.argtypes = [c_int32, c_int32, c_int32]
+    lib.pdepth_ufield_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                      c_float, c_float, c_float, c_float, c_int32, c_float, c_void_p, c_void_p, c_void_p,
+                                      c_size_t, c_void_p]
     lib.pdepth_dpv_expect_f32.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                           c_void_p, c_void_p]
     lib.pdepth_dpv_moments_f32.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
@@ -309,6 +318,81 @@ def dpv_reduce(logits, d_candi, want_logp=True, want_depth=True, inplace=False):
                                        depth.data_ptr() if want_depth else None, _stream(dev))
     _check(rc, lib)
     return logp, depth
+
+
+def dpv_reduce_ex(logits, d_candi, addend=None, want_logp=True, want_prob=False, want_depth=False, want_var=False,
+                  want_quarter=False, inplace=False):
+    """(logits [+ addend]) [B,D,H,W] -> dict of the requested outputs: logp, prob = exp(logp) [B,D,H,W], depth, var
+    [B,H,W], quarter = nearest quarter-resolution logp [B,D,H//4,W//4] -- one pass (pdepth_dpv_reduce_ex_f32)."""
+    lib = load()
+    _no_autograd("dpv_reduce_ex", logits, addend)
+    _dev(logits, "logits")
+    if logits.dim() != 4:
+        raise RuntimeError("dpv_reduce_ex: logits must be [B,D,H,W]")
+    logits = logits.contiguous()
+    B, D, H, W = logits.shape
+    if addend is not None:
+        _dev(addend, "addend")
+        if tuple(addend.shape) != (B, D, H, W):
+            raise RuntimeError(f"dpv_reduce_ex: addend shape {tuple(addend.shape)} != logits {tuple(logits.shape)}")
+        addend = addend.contiguous()
+    d_candi = d_candi.contiguous()
+    if d_candi.numel() != D:
+        raise RuntimeError(f"dpv_reduce_ex: d_candi has {d_candi.numel()} entries, volume has D={D}")
+    dev = logits.device
+    out = {}
+    if want_logp:
+        out["logp"] = logits if inplace else torch.empty_like(logits)
+    if want_prob:
+        out["prob"] = torch.empty_like(logits)
+    if want_depth:
+        out["depth"] = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    if want_var:
+        out["var"] = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    if want_quarter:
+        out["quarter"] = torch.empty((B, D, H // 4, W // 4), dtype=torch.float32, device=dev)
+    ptr = lambda k: out[k].data_ptr() if k in out else None
+    with torch.cuda.device(dev):
+        rc = lib.pdepth_dpv_reduce_ex_f32(_dev(logits, "logits"), addend.data_ptr() if addend is not None else None,
+                                          _dev(d_candi, "d_candi"), B, D, H, W, ptr("logp"), ptr("prob"), ptr("depth"),
+                                          ptr("var"), ptr("quarter"), _stream(dev))
+    _check(rc, lib)
+    return out
+
+
+def ufield(dpv, d_candi, intr, mask, bv_log, unc_ang, z_start, z_end, min_depth, quash):
+    """dpv [B,D,H,W], intr [B,3,3], mask [B,H,W] | None -> (plane [B,D,W], depth_zero [B,H,W])  (pdepth_ufield_f32)."""
+    lib = load()
+    _no_autograd("ufield", dpv)
+    _dev(dpv, "dpv"), _dev(intr, "intr")
+    if dpv.dim() != 4:
+        raise RuntimeError("ufield: dpv must be [B,D,H,W]")
+    dpv = dpv.contiguous()
+    B, D, H, W = dpv.shape
+    intr = intr.contiguous().float()
+    if tuple(intr.shape) != (B, 3, 3):
+        raise RuntimeError(f"ufield: intr must be [{B},3,3], got {tuple(intr.shape)}")
+    if mask is not None:
+        _dev(mask, "mask")
+        if tuple(mask.shape) != (B, H, W):
+            raise RuntimeError(f"ufield: mask must be [{B},{H},{W}], got {tuple(mask.shape)}")
+        mask = mask.contiguous().float()
+    d_candi = d_candi.contiguous()
+    # depth of rows shifted in from outside the image: dpv_to_depthmap of the zero padding (exp(0) = 1 per plane)
+    oob = float(d_candi.sum().item()) if bv_log else 0.0
+    dev = dpv.device
+    ws_bytes = lib.pdepth_ufield_workspace_bytes(B, H, W)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    plane = torch.empty((B, D, W), dtype=torch.float32, device=dev)
+    dzero = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pdepth_ufield_f32(_dev(dpv, "dpv"), _dev(d_candi, "d_candi"), intr.data_ptr(),
+                                   mask.data_ptr() if mask is not None else None, B, D, H, W, 1 if bv_log else 0,
+                                   float(unc_ang), float(np.float32(z_start)), float(np.float32(z_end)), float(min_depth),
+                                   1 if quash else 0, oob, plane.data_ptr(), dzero.data_ptr(), ws.data_ptr(), ws_bytes,
+                                   _stream(dev))
+    _check(rc, lib)
+    return plane, dzero
 
 
 def dpv_expect(dpv, d_candi, bv_log):

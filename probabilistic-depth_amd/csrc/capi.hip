@@ -196,6 +196,20 @@ int pdepth_dpv_reduce_f32(const float* logits, const float* d_candi, int32_t B, 
                                               (hipStream_t)stream), "pdepth_dpv_reduce_f32");
 }
 
+int pdepth_dpv_reduce_ex_f32(const float* logits, const float* addend, const float* d_candi, int32_t B, int32_t D,
+                             int32_t H, int32_t W, float* logp, float* prob, float* depth, float* variance,
+                             float* logp_quarter, void* stream) {
+    const char* who = "pdepth_dpv_reduce_ex_f32";
+    if (!logits || !d_candi) return fail(PDEPTH_E_ARG, "%s: null input", who);
+    if (!logp && !prob && !depth && !variance && !logp_quarter) return fail(PDEPTH_E_ARG, "%s: no output requested", who);
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return fail(PDEPTH_E_ARG, "%s: non-positive dimension", who);
+    if (logp_quarter && (H < 4 || W < 4)) return fail(PDEPTH_E_ARG, "%s: quarter output needs H, W >= 4", who);
+    if (prob == logits || variance == logits || (addend && (logp == addend || prob == addend)))
+        return fail(PDEPTH_E_ARG, "%s: only logp may alias logits", who);
+    return launched(pdepth::launch_dpv_reduce_ex(logits, addend, d_candi, B, D, H, W, logp, prob, depth, variance,
+                                                 logp_quarter, (hipStream_t)stream), who);
+}
+
 int pdepth_dpv_expect_f32(const float* dpv, const float* d_candi, int32_t B, int32_t D, int32_t H,
                           int32_t W, int32_t bv_log, float* depth, void* stream) {
     if (!dpv || !d_candi || !depth) return fail(PDEPTH_E_ARG, "pdepth_dpv_expect_f32: null pointer");
@@ -234,6 +248,24 @@ int pdepth_sample_coords_f32(const pdepth_sweep_desc* desc, const pdepth_camera*
     if (!d_candi || !ix || !iy) return fail(PDEPTH_E_ARG, "pdepth_sample_coords_f32: null pointer");
     pdepth::SweepArgs a = make_args(&d, cam, nullptr, nullptr, d_candi);
     return launched(pdepth::launch_sample_coords(a, ix, iy, (hipStream_t)stream), "pdepth_sample_coords_f32");
+}
+
+size_t pdepth_ufield_workspace_bytes(int32_t B, int32_t H, int32_t W) {
+    return (B > 0 && H > 0 && W > 0) ? pdepth::ufield_workspace_bytes(B, H, W) : 0;
+}
+
+int pdepth_ufield_f32(const float* dpv, const float* d_candi, const float* intr, const float* mask, int32_t B, int32_t D,
+                      int32_t H, int32_t W, int32_t bv_log, float unc_ang, float z_start, float z_end, float min_depth,
+                      int32_t quash, float oob_depth, float* plane, float* depth_zero, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    const char* who = "pdepth_ufield_f32";
+    if (!dpv || !d_candi || !intr || !plane || !depth_zero) return fail(PDEPTH_E_ARG, "%s: null pointer", who);
+    if (B <= 0 || D <= 0 || H <= 1 || W <= 1) return fail(PDEPTH_E_ARG, "%s: bad dimension", who);
+    const size_t need = pdepth::ufield_workspace_bytes(B, H, W);
+    if (!workspace || workspace_bytes < need)
+        return fail(PDEPTH_E_WORKSPACE, "%s: needs %zu bytes of workspace (got %zu)", who, need, workspace_bytes);
+    return launched(pdepth::launch_ufield(dpv, d_candi, intr, mask, B, D, H, W, bv_log, unc_ang, z_start, z_end, min_depth,
+                                          quash, oob_depth, plane, depth_zero, workspace, (hipStream_t)stream), who);
 }
 
 int pdepth_dpv_fuse_f32(const float* logp, const float* dmaps, const float* masks, const float* d_candi,

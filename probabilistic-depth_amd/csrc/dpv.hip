@@ -128,6 +128,154 @@ __global__ __launch_bounds__(256) void dpv_reduce_scalar_kernel(const float* x,
     if (depth) depth[(size_t)b * HW + pix] = e;
 }
 
+// Extended reduction (pdepth_dpv_reduce_ex_f32): the same single pass with optional extras, all from the registers
+// that already hold the column --
+//   addend   : x = logits + addend before the softmax   (feedback update log_softmax(BV_cur + BV_resi), models.py:694)
+//   prob     : exp(logp), the decoder's input            (models.py:697 torch.exp(BV_cur_upd), :651)
+//   variance : sum_k (d_k - E[d])^2 p_k                   (trainer/default_trainer.py:333-336)
+//   quarter  : logp at every 4th row and column, [B,D,H/4,W/4] = F.interpolate(logp, scale_factor=0.25,
+//              mode='nearest'), the next frame's prev_output (trainer/default_trainer.py:221)
+struct DpvExtras {
+    const float* addend;
+    float* prob;
+    float* variance;
+    float* quarter;
+    int W;
+};
+
+template <int RPL>
+__global__ __launch_bounds__(256) void dpv_reduce_ex_vec4_kernel(const float* __restrict__ x, const float* __restrict__ dc,
+                                                                 int D, int HW, float* logp, float* __restrict__ depth,
+                                                                 DpvExtras ex) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int g = lane >> 4;
+    const int quads = HW >> 2;
+    const int q = wave * 16 + (lane & 15);
+    const bool live = q < quads;
+    const int b = blockIdx.y;
+    const size_t off = (size_t)b * D * HW + (size_t)(live ? q : 0) * 4;
+    float4 v[RPL];
+    const float ninf = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        const int k = g + 4 * i;
+        v[i] = make_float4(ninf, ninf, ninf, ninf);
+        if (k < D && live) {
+            v[i] = load_nt(x + off + (size_t)k * HW);
+            if (ex.addend) {
+                const float4 a = load_nt(ex.addend + off + (size_t)k * HW);
+                v[i].x += a.x; v[i].y += a.y; v[i].z += a.z; v[i].w += a.w;
+            }
+        }
+    }
+    float4 m = v[0];
+#pragma unroll
+    for (int i = 1; i < RPL; ++i) {
+        m.x = fmaxf(m.x, v[i].x); m.y = fmaxf(m.y, v[i].y); m.z = fmaxf(m.z, v[i].z); m.w = fmaxf(m.w, v[i].w);
+    }
+#pragma unroll
+    for (int s = 16; s <= 32; s <<= 1) {
+        const float4 o = shfl_xor4(m, s);
+        m.x = fmaxf(m.x, o.x); m.y = fmaxf(m.y, o.y); m.z = fmaxf(m.z, o.z); m.w = fmaxf(m.w, o.w);
+    }
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        if (g + 4 * i < D) {
+            v[i].x -= m.x; v[i].y -= m.y; v[i].z -= m.z; v[i].w -= m.w;
+            sum.x += expf(v[i].x); sum.y += expf(v[i].y); sum.z += expf(v[i].z); sum.w += expf(v[i].w);
+        }
+    }
+#pragma unroll
+    for (int s = 16; s <= 32; s <<= 1) {
+        const float4 o = shfl_xor4(sum, s);
+        sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
+    }
+    const float4 ls = make_float4(logf(sum.x), logf(sum.y), logf(sum.z), logf(sum.w));
+    float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+    // quarter-resolution copy: this lane's first pixel, when its row is a multiple of 4 (W % 4 == 0: a quad never
+    // straddles rows and starts at a column that is a multiple of 4)
+    const int pix = q * 4, py = pix / ex.W, pxq = (pix - py * ex.W) >> 2;
+    const int Wq = ex.W >> 2, Hq = (HW / ex.W) >> 2;
+    const bool qrow = ex.quarter && live && (py & 3) == 0 && (py >> 2) < Hq && pxq < Wq;
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) {
+        const int k = g + 4 * i;
+        if (k < D) {
+            const float4 lp = make_float4(v[i].x - ls.x, v[i].y - ls.y, v[i].z - ls.z, v[i].w - ls.w);
+            v[i] = lp;
+            const float4 p = make_float4(expf(lp.x), expf(lp.y), expf(lp.z), expf(lp.w));
+            if (live) {
+                if (logp) store_nt(logp + off + (size_t)k * HW, lp);
+                if (ex.prob) store_nt(ex.prob + off + (size_t)k * HW, p);
+                if (qrow) ex.quarter[((size_t)b * D + k) * Hq * Wq + (size_t)(py >> 2) * Wq + pxq] = lp.x;
+            }
+            const float dk = dc[k];
+            e.x += dk * p.x; e.y += dk * p.y; e.z += dk * p.z; e.w += dk * p.w;
+        }
+    }
+#pragma unroll
+    for (int s = 16; s <= 32; s <<= 1) {
+        const float4 o = shfl_xor4(e, s);
+        e.x += o.x; e.y += o.y; e.z += o.z; e.w += o.w;
+    }
+    if (depth && live && g == 0) *reinterpret_cast<float4*>(depth + (size_t)b * HW + (size_t)q * 4) = e;
+    if (ex.variance) {   // second sweep over the registers: sum_k (d_k - mean)^2 p_k with the mean just formed
+        float4 var = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int k = g + 4 * i;
+            if (k < D) {
+                const float dk = dc[k];
+                const float4 dd = make_float4(dk - e.x, dk - e.y, dk - e.z, dk - e.w);
+                var.x += (dd.x * dd.x) * expf(v[i].x); var.y += (dd.y * dd.y) * expf(v[i].y);
+                var.z += (dd.z * dd.z) * expf(v[i].z); var.w += (dd.w * dd.w) * expf(v[i].w);
+            }
+        }
+#pragma unroll
+        for (int s = 16; s <= 32; s <<= 1) {
+            const float4 o = shfl_xor4(var, s);
+            var.x += o.x; var.y += o.y; var.z += o.z; var.w += o.w;
+        }
+        if (live && g == 0) *reinterpret_cast<float4*>(ex.variance + (size_t)b * HW + (size_t)q * 4) = var;
+    }
+}
+
+// any D / any H, W: one pixel per thread (re-reads hit L2)
+__global__ __launch_bounds__(256) void dpv_reduce_ex_scalar_kernel(const float* x, const float* __restrict__ dc, int D,
+                                                                   int HW, float* logp, float* __restrict__ depth,
+                                                                   DpvExtras ex) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const int b = blockIdx.y;
+    const size_t off = (size_t)b * D * HW + pix;
+    auto at = [&](int k) { return x[off + (size_t)k * HW] + (ex.addend ? ex.addend[off + (size_t)k * HW] : 0.0f); };
+    float m = -INFINITY;
+    for (int k = 0; k < D; ++k) m = fmaxf(m, at(k));
+    float s = 0.f;
+    for (int k = 0; k < D; ++k) s += expf(at(k) - m);
+    const float ls = logf(s);
+    const int py = pix / ex.W, px = pix - py * ex.W, Wq = ex.W >> 2, Hq = (HW / ex.W) >> 2;
+    const bool qpix = ex.quarter && (py & 3) == 0 && (px & 3) == 0 && (py >> 2) < Hq && (px >> 2) < Wq;
+    float e = 0.f;
+    for (int k = 0; k < D; ++k) {   // (logp may alias logits: nothing is read again after this sweep unless variance)
+        const float lp = (at(k) - m) - ls;
+        e += dc[k] * expf(lp);
+    }
+    float var = 0.f;
+    for (int k = 0; k < D; ++k) {
+        const float lp = (at(k) - m) - ls, p = expf(lp), dd = dc[k] - e;
+        var += (dd * dd) * p;
+        if (ex.prob) ex.prob[off + (size_t)k * HW] = p;
+        if (qpix) ex.quarter[((size_t)b * D + k) * Hq * Wq + (size_t)(py >> 2) * Wq + (px >> 2)] = lp;
+    }
+    if (logp)
+        for (int k = 0; k < D; ++k) logp[off + (size_t)k * HW] = (at(k) - m) - ls;   // last: logp may alias logits
+    if (depth) depth[(size_t)b * HW + pix] = e;
+    if (ex.variance) ex.variance[(size_t)b * HW + pix] = var;
+}
+
 // Expectation with the wave layout of dpv_reduce_vec4_kernel: lane = (plane group g, pixel quad q), all loads of a
 // lane issued up front (RPL 16-byte non-temporal loads in flight per lane), partial sums combined by xor-shuffles.
 template <bool BV_LOG, int RPL>
@@ -213,6 +361,28 @@ hipError_t launch_dpv_reduce(const float* logits, const float* d_candi, int B, i
     } else {
         dim3 grid((HW + 255) / 256, B);
         hipLaunchKernelGGL(dpv_reduce_scalar_kernel, grid, dim3(256), 0, stream, logits, d_candi, D, HW, logp, depth);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_dpv_reduce_ex(const float* logits, const float* addend, const float* d_candi, int B, int D, int H, int W,
+                                float* logp, float* prob, float* depth, float* variance, float* quarter, hipStream_t stream) {
+    const int HW = H * W;
+    DpvExtras ex{addend, prob, variance, quarter, W};
+    const bool vec = (W % 4 == 0) && aligned16(logits) && (!addend || aligned16(addend)) && (!logp || aligned16(logp)) &&
+                     (!prob || aligned16(prob)) && (!depth || aligned16(depth)) && (!variance || aligned16(variance)) &&
+                     D <= 128 && !(logp == logits && addend);   // (in place with an addend: the scalar kernel's order)
+    if (vec) {
+        dim3 grid((HW / 4 + 63) / 64, B);
+        if (D <= 32)
+            hipLaunchKernelGGL(dpv_reduce_ex_vec4_kernel<8>, grid, dim3(256), 0, stream, logits, d_candi, D, HW, logp, depth, ex);
+        else if (D <= 64)
+            hipLaunchKernelGGL(dpv_reduce_ex_vec4_kernel<16>, grid, dim3(256), 0, stream, logits, d_candi, D, HW, logp, depth, ex);
+        else
+            hipLaunchKernelGGL(dpv_reduce_ex_vec4_kernel<32>, grid, dim3(256), 0, stream, logits, d_candi, D, HW, logp, depth, ex);
+    } else {
+        dim3 grid((HW + 255) / 256, B);
+        hipLaunchKernelGGL(dpv_reduce_ex_scalar_kernel, grid, dim3(256), 0, stream, logits, d_candi, D, HW, logp, depth, ex);
     }
     return hipGetLastError();
 }

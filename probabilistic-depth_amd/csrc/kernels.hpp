@@ -56,12 +56,20 @@ hipError_t launch_sweep_cells_fast(const SweepArgs& a, const float4* packed, int
 // dpv.hip
 hipError_t launch_dpv_reduce(const float* logits, const float* d_candi, int B, int D, int H,
                              int W, float* logp, float* depth, hipStream_t stream);
+hipError_t launch_dpv_reduce_ex(const float* logits, const float* addend, const float* d_candi, int B, int D, int H, int W,
+                                float* logp, float* prob, float* depth, float* variance, float* quarter, hipStream_t stream);
 hipError_t launch_dpv_expect(const float* dpv, const float* d_candi, int B, int D, int H, int W,
                              int bv_log, float* depth, hipStream_t stream);
 
 // warp.hip
 hipError_t launch_warp_feature(const SweepArgs& a, float* out, hipStream_t stream);
 hipError_t launch_sample_coords(const SweepArgs& a, float* ix, float* iy, hipStream_t stream);
+
+// ufield.hip
+size_t ufield_workspace_bytes(int B, int H, int W);
+hipError_t launch_ufield(const float* dpv, const float* d_candi, const float* intr, const float* mask, int B, int D, int H,
+                         int W, int bv_log, float unc_ang, float zstart, float zend, float mind, int quash, float oob_depth,
+                         float* plane, float* depth_zero, void* workspace, hipStream_t stream);
 
 // extras.hip
 hipError_t launch_dpv_moments(const float* dpv, const float* d_candi, int B, int D, int H, int W, int bv_log,

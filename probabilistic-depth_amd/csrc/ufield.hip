@@ -1,0 +1,144 @@
+// Uncertainty-field collapse of a depth probability volume: pdepth_ufield_f32.
+//
+// Replaces gen_ufield (utils/img_utils.py:268-358, cfgx branch; consumer compute_unc_field :178-181 from
+// trainer/default_trainer.py:243-244): the [D,H,W] volume of one view is collapsed to a [D,W] "bird's eye" plane -- per
+// image column the mean of the depth distributions of the pixels that lie in a height band above the ground -- plus
+// the depth map masked to those pixels.  The reference makes ~12 passes over [D,H,W] tensors (two grid_samples of the
+// whole volume, exp, repeat of the mask over D, multiply, sum); here the volume is read twice (expectation, collapse)
+// and everything in between works on [H,W] maps:
+//
+//   1. depth_pred = E[d] of the volume                                   (dpv.hip, launch_dpv_expect)
+//   2. ufield_mask_kernel, one block per column: the depth map of the volume shifted by `unc_ang` rows IS the shifted
+//      depth map (dpv_to_depthmap works per pixel), so only depth_pred is gathered through the reference's nearest
+//      sampling grid; height-band / range mask of the shifted points, validity mask, "quash" to the nearest surface
+//      of the column (block-wide min), column counts ax;
+//   3. ufield_collapse_kernel: plane[d,x] = sum_y p(d,y,x) * mask_back(y,x) / ax(x), mask_back = the mask sampled
+//      through the inverse shift; lanes along x (coalesced rows), 4 planes per block share the mask reads.
+//
+// The sampling grid is reproduced literally: the reference builds it with the (size - 1) convention
+// (convert_flowfield, :170-176) but samples with grid_sample's default align_corners=False, so it is NOT a pure row
+// shift -- e.g. for even W the last column rounds out of the image and reads padding zeros (which, for a log-DPV, the
+// reference then exponentiates to ones).  nearest = round-half-to-even of fma(g + 1, size / 2, -0.5), as ATen's CPU
+// kernel evaluates it (geometry.hpp has the same un-normalisation for the bilinear sampler).
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace pdepth {
+
+namespace {
+
+// source index of the reference's nearest sampling for destination index i, pixel offset `shift`; -1 = outside
+__device__ __forceinline__ int nearest_src(int i, float shift, int size, bool sampled) {
+    if (!sampled) return i;   // unc_ang == 0: the reference clones instead of sampling (:301)
+    const float step = 2.0f / (float)(size - 1);
+    const float g = (-1.0f + (float)i * step) - shift * step;          // convert_flowfield, op for op
+    const float pos = __builtin_fmaf(g + 1.0f, (float)size / 2.0f, -0.5f);
+    const float r = rintf(pos);                                        // round half to even, like Vec::round
+    return (r >= 0.0f && r < (float)size) ? (int)r : -1;
+}
+
+}  // namespace
+
+// grid (W, B), block 256.  zero_mask [B,H,W], ax [B,W].
+__global__ __launch_bounds__(256) void ufield_mask_kernel(const float* __restrict__ depth_pred, const float* __restrict__ intr,
+                                                          const float* __restrict__ mask, int H, int W, float pshift,
+                                                          float zstart, float zend, float mind, int quash, float oob_depth,
+                                                          float* __restrict__ zero_mask, float* __restrict__ ax) {
+    __shared__ float s_red[256];
+    const int x = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float cy = intr[b * 9 + 5], fy = intr[b * 9 + 4];
+    const float maxd = 100.0f;
+    const bool sampled = pshift != 0.0f;
+    const int sx = nearest_src(x, 0.0f, W, sampled);
+    const float* dp = depth_pred + (size_t)b * H * W;
+    float colmin = INFINITY;
+    // pass 1: band mask and the column minimum of the masked depth
+    for (int y = tid; y < H; y += 256) {
+        const int sy = nearest_src(y, pshift, H, sampled);
+        const bool inb = sx >= 0 && sy >= 0;
+        const float d = inb ? dp[(size_t)sy * W + sx] : oob_depth;
+        const float yf = ((float)y - cy) / fy;
+        const float Y = yf * d;
+        float zm = !((Y > zend) || (Y < zstart) || (d > maxd - 1.0f) || (d < mind)) ? 1.0f : 0.0f;
+        if (mask) zm = zm * (inb ? mask[(size_t)b * H * W + (size_t)sy * W + sx] : 0.0f);
+        float cleaned = d * zm;
+        if (cleaned == 0.0f) cleaned = 1000.0f;
+        colmin = fminf(colmin, cleaned);
+        zero_mask[(size_t)b * H * W + (size_t)y * W + x] = zm;   // (provisional: multiplied by the quash mask below)
+    }
+    s_red[tid] = colmin;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) s_red[tid] = fminf(s_red[tid], s_red[tid + s]);
+        __syncthreads();
+    }
+    colmin = s_red[0];
+    __syncthreads();
+    // pass 2: quash everything that is not within 1 m of the column's nearest surface; count
+    float cnt = 0.0f;
+    for (int y = tid; y < H; y += 256) {
+        const int sy = nearest_src(y, pshift, H, sampled);
+        const bool inb = sx >= 0 && sy >= 0;
+        const float d = inb ? dp[(size_t)sy * W + sx] : oob_depth;
+        float zm = zero_mask[(size_t)b * H * W + (size_t)y * W + x];
+        float cleaned = d * zm;
+        if (cleaned == 0.0f) cleaned = 1000.0f;
+        const bool keep = !quash || ((cleaned > colmin - 1.0f) && (cleaned < colmin + 1.0f));
+        zm = zm * (keep ? 1.0f : 0.0f);
+        zero_mask[(size_t)b * H * W + (size_t)y * W + x] = zm;
+        cnt += zm;
+    }
+    s_red[tid] = cnt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) s_red[tid] += s_red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) ax[b * W + x] = s_red[0];
+}
+
+// grid (ceil(W/64), ceil(D/4), B), block (64, 4): lane = column, threadIdx.y = plane of the group.
+template <bool BV_LOG>
+__global__ __launch_bounds__(256) void ufield_collapse_kernel(const float* __restrict__ dpv, const float* __restrict__ depth_pred,
+                                                              const float* __restrict__ zero_mask, const float* __restrict__ ax,
+                                                              int D, int H, int W, float pshift, float* __restrict__ plane,
+                                                              float* __restrict__ depth_zero) {
+    const int x = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
+    if (x >= W || k >= D) return;
+    const bool sampled = pshift != 0.0f;
+    const int sx = nearest_src(x, 0.0f, W, sampled);
+    const float* zm = zero_mask + (size_t)b * H * W;
+    const float* v = dpv + ((size_t)b * D + k) * H * W + x;
+    float acc = 0.0f;
+    for (int y = 0; y < H; ++y) {
+        const int sy = nearest_src(y, -pshift, H, sampled);   // the mask is shifted back (flowfield_inv)
+        const float m = (sx >= 0 && sy >= 0) ? zm[(size_t)sy * W + sx] : 0.0f;
+        const float p = BV_LOG ? expf(v[(size_t)y * W]) : v[(size_t)y * W];
+        acc = acc + p * m;
+        if (k == 0) depth_zero[(size_t)b * H * W + (size_t)y * W + x] = depth_pred[(size_t)b * H * W + (size_t)y * W + x] * m;
+    }
+    plane[((size_t)b * D + k) * W + x] = acc / ax[b * W + x];   // 0 / 0 = NaN where no pixel of the column qualifies, as in the reference
+}
+
+size_t ufield_workspace_bytes(int B, int H, int W) { return ((size_t)B * (2 * (size_t)H * W + W) * sizeof(float) + 255) & ~(size_t)255; }
+
+hipError_t launch_ufield(const float* dpv, const float* d_candi, const float* intr, const float* mask, int B, int D, int H,
+                         int W, int bv_log, float unc_ang, float zstart, float zend, float mind, int quash, float oob_depth,
+                         float* plane, float* depth_zero, void* workspace, hipStream_t stream) {
+    float* depth_pred = static_cast<float*>(workspace);
+    float* zero_mask = depth_pred + (size_t)B * H * W;
+    float* ax = zero_mask + (size_t)B * H * W;
+    hipError_t e = launch_dpv_expect(dpv, d_candi, B, D, H, W, bv_log, depth_pred, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ufield_mask_kernel, dim3(W, B), dim3(256), 0, stream, depth_pred, intr, mask, H, W, unc_ang, zstart, zend,
+                       mind, quash, oob_depth, zero_mask, ax);
+    dim3 grid((W + 63) / 64, (D + 3) / 4, B), block(64, 4);
+    if (bv_log)
+        hipLaunchKernelGGL(ufield_collapse_kernel<true>, grid, block, 0, stream, dpv, depth_pred, zero_mask, ax, D, H, W, unc_ang, plane, depth_zero);
+    else
+        hipLaunchKernelGGL(ufield_collapse_kernel<false>, grid, block, 0, stream, dpv, depth_pred, zero_mask, ax, D, H, W, unc_ang, plane, depth_zero);
+    return hipGetLastError();
+}
+
+}  // namespace pdepth

@@ -25,11 +25,17 @@ def eval_step(model, model_input, prev_output=None):
     model_input["prev_output"] = prev_output
     out = model([model_input])[0]
     d_candi = model_input["d_candi"]
-    nxt = F.interpolate(out["output_refined"][-1].detach(), scale_factor=0.25, mode="nearest")
+    # the host model's DPV passes leave the depth maps and the next prev_output behind (one pass over each volume
+    # instead of three); any other model gets the reference's op sequence
+    aux = getattr(model, "last_aux", None) or {}
+    nxt = aux.get("prev_output")
+    if nxt is None:
+        nxt = F.interpolate(out["output_refined"][-1].detach(), scale_factor=0.25, mode="nearest")
+    low, ref = aux.get("depth_lowres"), aux.get("depth_refined")
     return {
         "output": out,
-        "depth_lowres": ops.dpv_expect(out["output"][-1], d_candi, BV_log=True),
-        "depth_refined": ops.dpv_expect(out["output_refined"][-1], d_candi, BV_log=True),
+        "depth_lowres": low if low is not None else ops.dpv_expect(out["output"][-1], d_candi, BV_log=True),
+        "depth_refined": ref if ref is not None else ops.dpv_expect(out["output_refined"][-1], d_candi, BV_log=True),
         "prev_output": nxt,
     }
 

@@ -9,7 +9,7 @@ def get_model(cfg, id):
         return BaseModel(cfg, id)
     if cfg.data.model_name == "packnet":
         # The PackNet encoder/decoder is a separate dense CNN that is out of this package's scope
-        # (SURVEY.md section 2 row 5); its hot path -- sweep -> log_softmax -> E[d] -- is available
-        # fused as ops.sweep_dpv for a PackNet-style caller.
-        raise NotImplementedError("packnet: network not provided; use ops.sweep_dpv for its sweep+DPV head")
+        # (SURVEY.md section 2 row 5); its hot path -- sweep -> log_softmax -> E[d], packnet.py:343-396 -- is
+        # models.packnet_head.PacknetHead (one fused launch for the whole batch).
+        raise NotImplementedError("packnet: network not provided; its sweep+DPV head is models.packnet_head.PacknetHead")
     raise NotImplementedError(cfg.data.model_name)

@@ -153,10 +153,18 @@ class BaseDecoder(nn.Module):
         self.conv2_2 = nn.Conv2d(d1, d1, kernel_size=3, stride=1, padding=1, bias=True)
         self.apply(_he_init)
 
-    def forward(self, dpv_raw, img_features):
+    def forward(self, dpv_raw, img_features, d_candi=None):
+        """Returns the refined log-DPV.  With d_candi, the same pass over the full-resolution volume also leaves the
+        refined depth map and the nearest quarter-resolution log-DPV (the next frame's prev_output,
+        trainer/default_trainer.py:221) in self.aux for the evaluation harness."""
         x = self.conv0_1(self.conv0(torch.cat([dpv_raw, img_features[0]], dim=1)))
         x = self.conv1_1(self.conv1(torch.cat([self.trans_conv0(x), img_features[1]], dim=1)))
         x = self.conv2_2(self.conv2_1(self.conv2(torch.cat([self.trans_conv1(x), img_features[2]], dim=1))))
+        self.aux = None
+        if d_candi is not None and x.shape[2] >= 4 and x.shape[3] >= 4:
+            r = ops.dpv_reduce_ex(x, d_candi, want_logp=True, want_depth=True, want_quarter=True, inplace=True)  # models.py:351
+            self.aux = {"depth_refined": r["depth"], "prev_output": r["quarter"]}
+            return r["logp"]
         logp, _ = ops.dpv_reduce(x, None, want_logp=True, want_depth=False, inplace=True)  # models.py:351
         return logp
 
@@ -275,8 +283,12 @@ class BaseModel(nn.Module):
         return ops.sweep_cost(feats[:, -1], feats[:, :-1], K, R, t, rays, cxcy, model_input["d_candi"],
                               self.sigma_soft_max, feat_dist="L2", algo=self.sweep_algo, blas=self.sweep_blas)
 
-    def _low_res_dpv(self, cost_volumes, d_candi):
+    def _low_res_dpv(self, cost_volumes, d_candi, want_prob=False):
+        """log-DPV of the cost volume (models.py:555-560); with want_prob also exp(logp) and E[d] from the same pass."""
         x = self.conv0_2(self.conv0_1(self.conv0(cost_volumes)))
+        if want_prob:
+            r = ops.dpv_reduce_ex(x, d_candi, want_logp=True, want_prob=True, want_depth=True, inplace=True)
+            return r["logp"], r["prob"], r["depth"]
         logp, _ = ops.dpv_reduce(x, d_candi, want_logp=True, want_depth=False, inplace=True)  # models.py:560
         return logp
 
@@ -301,10 +313,17 @@ class BaseModel(nn.Module):
         return BV, cost_volumes, last, first, warped
 
     def forward_int(self, model_input):
+        # self.last_aux: by-products of the DPV passes (depth maps, next prev_output) for harness.eval_step; the
+        # returned dict keeps exactly the reference's keys (models.py:656,678,699)
+        self.last_aux = None
+        d_candi = model_input["d_candi"]
         if self.nmode == "default":
-            BV_cur, _, feats, _ = self.forward_encoder(model_input)
-            feats.append(model_input["rgb"][:, -1])
-            BV_refined = self.base_decoder(torch.exp(BV_cur), img_features=feats)
+            half, raw, feats_all = self._features(model_input)
+            cost_volumes = self._sweep(feats_all, model_input)
+            BV_cur, prob, depth_low = self._low_res_dpv(cost_volumes, d_candi, want_prob=True)   # models.py:560 + :651
+            feats = [feats_all[:, -1, :-3], half[:, -1], model_input["rgb"][:, -1]]
+            BV_refined = self.base_decoder(prob, img_features=feats, d_candi=d_candi)
+            self.last_aux = dict(self.base_decoder.aux or {}, depth_lowres=depth_low)
             return {"output": [BV_cur], "output_refined": [BV_refined], "flow": None, "flow_refined": None}
         if self.nmode == "default_upsample":
             BV_cur, _, feats, _ = self.forward_encoder(model_input)
@@ -323,9 +342,11 @@ class BaseModel(nn.Module):
             else:
                 prev = model_input["prev_output"].unsqueeze(1)
             resi = self.based_3d(torch.cat([BV_cur.unsqueeze(1), prev, warped], dim=1), prob=False)
-            BV_upd, _ = ops.dpv_reduce((BV_cur + resi).contiguous(), model_input["d_candi"], want_logp=True,
-                                       want_depth=False, inplace=True)  # models.py:694
-            BV_refined = self.base_decoder(torch.exp(BV_upd), img_features=last)
+            # log_softmax(BV_cur + BV_resi), its exp for the decoder and E[d] in one pass (models.py:694,:697)
+            r = ops.dpv_reduce_ex(BV_cur, d_candi, addend=resi.contiguous(), want_logp=True, want_prob=True, want_depth=True)
+            BV_upd = r["logp"]
+            BV_refined = self.base_decoder(r["prob"], img_features=last, d_candi=d_candi)
+            self.last_aux = dict(self.base_decoder.aux or {}, depth_lowres=r["depth"])
             return {"output": [BV_cur, BV_upd], "output_refined": [BV_refined], "flow": None, "flow_refined": None}
         raise Exception("Nmode wrong")
 

@@ -89,6 +89,30 @@ def dpv_reduce(logits, d_candi, want_logp=True, want_depth=True, inplace=False):
     return _native.dpv_reduce(logits, dc, want_logp, want_depth, inplace)
 
 
+def dpv_reduce_ex(logits, d_candi=None, addend=None, want_logp=True, want_prob=False, want_depth=False, want_var=False,
+                  want_quarter=False, inplace=False):
+    """One pass over (logits [+ addend]): log_softmax over D and any of exp(logp), E[d], Var[d], the nearest
+    quarter-resolution log-DPV (the next frame's prev_output).  Returns a dict with the requested outputs.
+
+    models/models.py:694 + :697 (feedback update and decoder input), trainer/default_trainer.py:333-336 (variance),
+    :221 (prev_output)."""
+    if d_candi is None:
+        if want_depth or want_var:
+            raise RuntimeError("dpv_reduce_ex: d_candi is required for the depth / variance outputs")
+        dc = torch.zeros(logits.shape[1], dtype=torch.float32, device=logits.device)
+    else:
+        dc = d_candi_tensor(d_candi, logits.device)
+    return _native.dpv_reduce_ex(logits, dc, addend, want_logp, want_prob, want_depth, want_var, want_quarter, inplace)
+
+
+def ufield(dpv, d_candi, intr, mask=None, BV_log=True, unc_ang=5, z_start=0.6, z_end=0.9, min_depth=0.0, quash=False):
+    """Uncertainty-field collapse, batched: (plane [B,D,W], masked depth [B,H,W]) of a (log-)DPV [B,D,H,W]
+    (utils/img_utils.py:268-358).  mask [B,H,W] | [B,1,H,W] | None."""
+    if mask is not None and mask.dim() == 4:
+        mask = mask[:, 0]
+    return _native.ufield(dpv, d_candi_tensor(d_candi, dpv.device), intr, mask, BV_log, unc_ang, z_start, z_end, min_depth, quash)
+
+
 def dpv_expect(dpv, d_candi, BV_log=False):
     """depth [B,H,W] from a (log-)DPV [B,D,H,W] (utils/img_utils.py:52-61, batched)."""
     return _native.dpv_expect(dpv, d_candi_tensor(d_candi, dpv.device), BV_log)

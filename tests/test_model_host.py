@@ -117,7 +117,9 @@ def test_model_matches_reference_capture(nmode):
         e_low = np.abs(r["depth_lowres"].cpu().numpy() - g[tag + "_depth_low"]).max()
         e_ref = np.abs(r["depth_refined"].cpu().numpy() - g[tag + "_depth_ref"]).max()
         print(f"[{tag}] max|dlogDPV|={e_dpv:.3e} max|ddepth_low|={e_low:.3e} max|ddepth_refined|={e_ref:.3e}")
-        assert e_dpv < 2e-4 and e_low < 1e-3 and e_ref < 1e-3
+        # default mode: the north star's 1e-4 on both depth maps (measured 2.3e-5 / 2.5e-5); feedback mode adds the
+        # 3-D convolutions on MIOpen vs mkldnn in front of the low-resolution DPV (measured 1.9e-4 / 2.3e-4)
+        assert e_dpv < 2e-4 and e_ref < 1e-4 and e_low < (1e-4 if nmode == "default" else 6e-4)
         if nmode == "default" and frame == 0:
             # cost volume inside the model: encoder features differ (MIOpen vs mkldnn), the sweep does not
             with torch.no_grad():   # (the HIP ops refuse inputs that require grad; eval_step runs under no_grad itself)
