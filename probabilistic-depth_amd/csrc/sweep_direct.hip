@@ -26,11 +26,13 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int
     const int tid = threadIdx.x;
     const int HW = a.H * a.W;
     const int b = blockIdx.y;
+    // Flagged mode: a small grid strides over the tiles, so that the usual case -- nothing flagged -- costs a few
+    // flag reads per block instead of one (empty) block per tile.
+    for (int tile = blockIdx.x; tile < (tile_flags ? tiles : (int)gridDim.x); tile += gridDim.x) {
     int pix;
     bool live;
     if (tile_flags) {
-        const int tile = blockIdx.x;
-        if (tile_flags[b * tiles + tile] != flag_value) return;  // block-uniform
+        if (tile_flags[b * tiles + tile] != flag_value) continue;  // block-uniform
         const int x = (tile % tiles_x) * 16 + (tid & 15);
         const int y = (tile / tiles_x) * 4 + (tid >> 4);
         live = x < a.W && y < a.H;
@@ -124,13 +126,15 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int
         }
         if (a.depth_out && live) a.depth_out[(size_t)b * HW + pix] = e;
     }
+    __syncthreads();   // (one wave per block: orders this tile's LDS reads before the next tile's writes)
+    }  // tiles
 }
 
 template <int METRIC>
 static hipError_t launch_metric(const SweepArgs& a, const int* tile_flags, int tiles_x, int tiles,
                                 hipStream_t stream, int flag_value = 1) {
     const int HW = a.H * a.W;
-    dim3 grid(tile_flags ? tiles : (HW + 63) / 64, a.B);
+    dim3 grid(tile_flags ? (tiles < 256 ? tiles : 256) : (HW + 63) / 64, a.B);
     if (a.C <= 68) {
         const size_t lds = (size_t)a.D * 64 * sizeof(float);
         auto kern = sweep_direct_kernel<METRIC, 68, false>;

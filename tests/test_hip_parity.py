@@ -325,7 +325,7 @@ def test_fuzz_tiled_against_gather(dev):
     must agree with the gather kernel, which evaluates every pixel independently in the reference's op order.
     Catches windowing / splitting / zero-padding mistakes that the handful of structured cases could miss."""
     rng = np.random.default_rng(2024)
-    worst = 0.0
+    worst, worst_depth = 0.0, 0.0
     for case in range(120):
         H, W = int(rng.integers(3, 70)), int(rng.integers(3, 110))
         C, D, V = int(rng.integers(1, 12)), int(rng.integers(1, 80)), int(rng.integers(1, 4))
@@ -354,8 +354,12 @@ def test_fuzz_tiled_against_gather(dev):
         assert err < 2e-5, f"case {case} (kind {kind}, {H}x{W}, C={C}, D={D}, V={V}): tiled vs gather differ by {err:.3e} (relative)"
         fin = np.isfinite(dd.cpu().numpy())
         if fin.any():
-            assert np.abs(da.cpu().numpy() - dd.cpu().numpy())[fin].max() < 2e-3 * max(1.0, float(np.max(b["d_candi"])) / 40.0)
-    print(f"fuzz: worst relative cost difference tiled vs gather {worst:.2e}")
+            # the north star's 1e-4 (at the reference's 5..40 m range; scaled with the depth range of the case) between
+            # the two kernels as well: measured worst 3.6e-5
+            ddiff = np.abs(da.cpu().numpy() - dd.cpu().numpy())[fin].max()
+            worst_depth = max(worst_depth, ddiff / max(1.0, float(np.max(b["d_candi"])) / 40.0))
+            assert ddiff < 1e-4 * max(1.0, float(np.max(b["d_candi"])) / 40.0), f"case {case}: depth differs by {ddiff:.2e}"
+    print(f"fuzz: worst relative cost difference tiled vs gather {worst:.2e}, worst depth difference (40 m scale) {worst_depth:.2e}")
 
 
 def test_fuzz_large_tiled_against_gather(dev):
@@ -407,5 +411,6 @@ def test_every_sweep_implementation_on_small_ragged_shapes(dev, variant):
         assert err < 2e-6, f"variant {variant} case {case} ({H}x{W}, C={C}, D={D}, V={V}): {err:.3e}"
         fin = np.isfinite(dd.cpu().numpy())
         if fin.any():
-            assert np.abs(da.cpu().numpy() - dd.cpu().numpy())[fin].max() < 2e-3
+            ddiff = np.abs(da.cpu().numpy() - dd.cpu().numpy())[fin].max()
+            assert ddiff < 1.5e-4 * max(1.0, float(np.max(b["d_candi"])) / 40.0), f"variant {variant} case {case}: depth differs by {ddiff:.2e}"
 
