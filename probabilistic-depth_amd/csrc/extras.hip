@@ -14,6 +14,62 @@
 
 namespace pdepth {
 
+// Single pass: lane = pixel, the D planes of the column live in registers between the three sweeps over k (Gaussian
+// and its sum; fused product and its sum; normalise + write), so the log-DPV is read once and each output written
+// once: 4*HW*(D*(1+outputs)+2) bytes.  DREG = planes held in registers (64 or 128); deeper volumes take the
+// re-reading kernel below.
+template <int DREG>
+__global__ __launch_bounds__(256) void dpv_fuse_reg_kernel(const float* __restrict__ logp,
+                                                           const float* __restrict__ dmaps,
+                                                           const float* __restrict__ masks,
+                                                           const float* __restrict__ dc, int D, int HW, float var,
+                                                           float eps, float* __restrict__ fused,
+                                                           float* __restrict__ logfused) {
+    __shared__ float s_dc[DREG];
+    for (int k = threadIdx.x; k < DREG; k += 256) s_dc[k] = k < D ? dc[k] : 0.0f;
+    __syncthreads();
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const int b = blockIdx.y;
+    const float dmap = dmaps[(size_t)b * HW + pix];
+    const float mask = masks[(size_t)b * HW + pix];
+    const float inv_mask = 1.0f - mask;
+    const float sigma = sqrtf(var);
+    const float two_var = 2.0f * (sigma * sigma);  // 2 * torch.pow(sig, 2)
+    const float uni = 1.0f / (float)D;
+    const float* lp = logp + (size_t)b * D * HW + pix;
+    float v[DREG], x[DREG];
+#pragma unroll
+    for (int k = 0; k < DREG; ++k) x[k] = k < D ? __builtin_nontemporal_load(lp + (size_t)k * HW) : 0.0f;
+    float sumg = 0.0f;
+#pragma unroll
+    for (int k = 0; k < DREG; ++k) {
+        const float a = fabsf(s_dc[k] - dmap);
+        v[k] = expf(-(a * a) / two_var);
+        if (k < D) sumg = sumg + v[k];
+    }
+    float sumf = 0.0f;
+#pragma unroll
+    for (int k = 0; k < DREG; ++k) {
+        float t = v[k] / sumg;
+        if (t != t) t = -1.0f;                       // zero_invalid (img_utils.py:45)
+        const float m = t * mask + uni * inv_mask;   // img_utils.py:371
+        v[k] = expf(x[k] + logf(fminf(fmaxf(m, eps), 1.0f)));
+        if (k < D) sumf = sumf + v[k];
+    }
+    float* of = fused ? fused + (size_t)b * D * HW + pix : nullptr;
+    float* ol = logfused ? logfused + (size_t)b * D * HW + pix : nullptr;
+#pragma unroll
+    for (int k = 0; k < DREG; ++k) {
+        if (k < D) {
+            const float f = fminf(fmaxf(v[k] / sumf, eps), 1.0f);
+            if (of) __builtin_nontemporal_store(f, of + (size_t)k * HW);
+            if (ol) __builtin_nontemporal_store(logf(f), ol + (size_t)k * HW);
+        }
+    }
+}
+
+// Any D: the column is re-read (from L2) in the second and third sweep.
 __global__ __launch_bounds__(256) void dpv_fuse_kernel(const float* __restrict__ logp,
                                                        const float* __restrict__ dmaps,
                                                        const float* __restrict__ masks,
@@ -90,8 +146,12 @@ hipError_t launch_dpv_fuse(const float* logp, const float* dmaps, const float* m
                            int B, int D, int H, int W, float var, float eps, float* fused, float* logfused,
                            hipStream_t stream) {
     dim3 grid((H * W + 255) / 256, B);
-    hipLaunchKernelGGL(dpv_fuse_kernel, grid, dim3(256), 0, stream, logp, dmaps, masks, d_candi, D, H * W, var, eps,
-                       fused, logfused);
+    if (D <= 64)
+        hipLaunchKernelGGL(dpv_fuse_reg_kernel<64>, grid, dim3(256), 0, stream, logp, dmaps, masks, d_candi, D, H * W, var, eps, fused, logfused);
+    else if (D <= 128)
+        hipLaunchKernelGGL(dpv_fuse_reg_kernel<128>, grid, dim3(256), 0, stream, logp, dmaps, masks, d_candi, D, H * W, var, eps, fused, logfused);
+    else
+        hipLaunchKernelGGL(dpv_fuse_kernel, grid, dim3(256), 0, stream, logp, dmaps, masks, d_candi, D, H * W, var, eps, fused, logfused);
     return hipGetLastError();
 }
 
@@ -172,44 +232,96 @@ int correlation_max_radius() { return RMAX; }
 // Backward of the correlation: with out[b,d,y,x] = (1/C) sum_c x1[b,c,y,x] * x2[b,c,y+dy,x+dx] (zero padded),
 //   grad_x1[b,c,y,x] = (1/C) sum_d go[b,d,y,x]       * x2[b,c,y+dy,x+dx]
 //   grad_x2[b,c,y,x] = (1/C) sum_d go[b,d,y-dy,x-dx] * x1[b,c,y-dy,x-dx]
-// (correlation_cuda_kernel.cu:116-300 computes the same two sums over its padded NHWC repacks).  One thread
-// per (pixel, channel); the (2r+1)^2 gradient values of a pixel are re-read per channel from L1/L2.
+// (correlation_cuda_kernel.cu:116-300 computes the same two sums over its padded NHWC repacks).
+// Block = 16x16 pixels x CCH channels: the x1 and x2 halo tiles of the channel chunk are staged in LDS once and
+// serve all (2r+1)^2 displacements; a thread reads the two gradient values of a displacement (its own pixel for
+// grad_x1, the mirrored pixel for grad_x2) once from global memory and uses them for the CCH channels, so
+// the gradient volume is read C/CCH times instead of C times and the features once per tile (+halo) instead of
+// (2r+1)^2 times.  Per (pixel, channel) the sum runs over d in ascending order with one fma each, like the
+// forward's twin in the oracle.
+template <bool WANT1, bool WANT2>
 __global__ __launch_bounds__(256) void correlation_bwd_kernel(const float* __restrict__ x1,
                                                               const float* __restrict__ x2,
                                                               const float* __restrict__ go, int C, int H, int W,
                                                               int r, int s2, float* __restrict__ g1,
                                                               float* __restrict__ g2) {
+    extern __shared__ float smem[];
+    const int halo = r * s2;
+    const int TWH = CT + 2 * halo;
+    float* t1 = smem;                       // [CCH][TWH][TWH] x1 with halo (for grad_x2)
+    float* t2 = smem + CCH * TWH * TWH;     // [CCH][TWH][TWH] x2 with halo (for grad_x1)
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int x0 = blockIdx.x * CT, y0 = blockIdx.y * CT;
+    const int c0 = blockIdx.z % ((C + CCH - 1) / CCH) * CCH, b = blockIdx.z / ((C + CCH - 1) / CCH);
+    const int x = x0 + tx, y = y0 + ty;
     const int HW = H * W;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= HW) return;
-    const int c = blockIdx.y, b = blockIdx.z;
-    const int y = pix / W, x = pix - y * W;
     const int nd = 2 * r + 1;
-    const float* a1 = x1 + ((size_t)b * C + c) * HW;
-    const float* a2 = x2 + ((size_t)b * C + c) * HW;
+    for (int idx = threadIdx.x; idx < CCH * TWH * TWH; idx += 256) {
+        const int cc = idx / (TWH * TWH), rem = idx - cc * TWH * TWH;
+        const int ry = rem / TWH, rx = rem - ry * TWH;
+        const int gx = x0 - halo + rx, gy = y0 - halo + ry, c = c0 + cc;
+        const bool in = c < C && gx >= 0 && gx < W && gy >= 0 && gy < H;
+        const size_t off = ((size_t)b * C + c) * HW + gy * W + gx;
+        if (WANT2) t1[idx] = in ? x1[off] : 0.0f;
+        if (WANT1) t2[idx] = in ? x2[off] : 0.0f;
+    }
+    __syncthreads();
+    const bool inside = x < W && y < H;
     const float* gb = go + (size_t)b * nd * nd * HW;
-    float s1 = 0.0f, s2acc = 0.0f;
+    float a1[CCH], a2[CCH];
+#pragma unroll
+    for (int cc = 0; cc < CCH; ++cc) a1[cc] = a2[cc] = 0.0f;
     for (int i = 0; i < nd; ++i) {
         const int dy = (i - r) * s2;
         for (int j = 0; j < nd; ++j) {
             const int dx = (j - r) * s2;
             const float* gd = gb + (size_t)(i * nd + j) * HW;
-            const int yp = y + dy, xp = x + dx;  // x2 position paired with (y, x)
-            if (yp >= 0 && yp < H && xp >= 0 && xp < W) s1 = __builtin_fmaf(gd[pix], a2[yp * W + xp], s1);
-            const int ym = y - dy, xm = x - dx;  // x1 position whose pair is (y, x)
-            if (ym >= 0 && ym < H && xm >= 0 && xm < W) s2acc = __builtin_fmaf(gd[ym * W + xm], a1[ym * W + xm], s2acc);
+            if (WANT1) {
+                // x2 position paired with (y, x); outside the image the staged tile holds zeros, but the reference sum
+                // skips those terms -- adding +-0 leaves every partial sum unchanged
+                const float g = inside ? gd[y * W + x] : 0.0f;
+                const float* p = t2 + (ty + halo + dy) * TWH + (tx + halo + dx);
+#pragma unroll
+                for (int cc = 0; cc < CCH; ++cc) a1[cc] = __builtin_fmaf(g, p[cc * TWH * TWH], a1[cc]);
+            }
+            if (WANT2) {
+                const int ym = y - dy, xm = x - dx;  // x1 position whose pair is (y, x)
+                const float g = (inside && ym >= 0 && ym < H && xm >= 0 && xm < W) ? gd[ym * W + xm] : 0.0f;
+                const float* p = t1 + (ty + halo - dy) * TWH + (tx + halo - dx);
+#pragma unroll
+                for (int cc = 0; cc < CCH; ++cc) a2[cc] = __builtin_fmaf(g, p[cc * TWH * TWH], a2[cc]);
+            }
         }
     }
+    if (!inside) return;
     const float inv = 1.0f / (float)C;
-    if (g1) g1[((size_t)b * C + c) * HW + pix] = s1 * inv;
-    if (g2) g2[((size_t)b * C + c) * HW + pix] = s2acc * inv;
+#pragma unroll
+    for (int cc = 0; cc < CCH; ++cc) {
+        if (c0 + cc >= C) break;
+        const size_t o = ((size_t)b * C + c0 + cc) * HW + y * W + x;
+        if (WANT1) g1[o] = a1[cc] * inv;
+        if (WANT2) g2[o] = a2[cc] * inv;
+    }
 }
 
 hipError_t launch_correlation_backward(const float* x1, const float* x2, const float* go, int B, int C, int H, int W,
                                        int radius, int stride2, float* g1, float* g2, hipStream_t stream) {
-    dim3 grid((H * W + 255) / 256, C, B);
-    hipLaunchKernelGGL(correlation_bwd_kernel, grid, dim3(256), 0, stream, x1, x2, go, C, H, W, radius, stride2, g1, g2);
-    return hipGetLastError();
+    const int TWH = CT + 2 * radius * stride2;
+    const size_t lds = (size_t)2 * CCH * TWH * TWH * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    dim3 grid((W + CT - 1) / CT, (H + CT - 1) / CT, B * ((C + CCH - 1) / CCH));
+    auto go_launch = [&](auto kern) -> hipError_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, x1, x2, go, C, H, W, radius, stride2, g1, g2);
+        return hipGetLastError();
+    };
+    if (g1 && g2) return go_launch(correlation_bwd_kernel<true, true>);
+    if (g1) return go_launch(correlation_bwd_kernel<true, false>);
+    if (g2) return go_launch(correlation_bwd_kernel<false, true>);
+    return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -163,3 +163,45 @@ def test_hip_correlation_backward():
     idx = [i * 9 + j for i in range(0, 9, 2) for j in range(0, 9, 2)]
     full[:, idx].backward(go)
     np.testing.assert_allclose(ad.grad.cpu().numpy(), ac.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_correlation_backward_ragged_tiles_and_channel_chunks():
+    """More than one 16x16 tile in both directions, a channel count that is not a multiple of the chunk of 8, and each
+    combination of requested gradients, against autograd through the oracle."""
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(6)
+    for (C, H, W, r, s2) in ((19, 21, 35, 2, 1), (8, 33, 18, 4, 2), (3, 16, 16, 1, 1)):
+        nd = 2 * r // s2 + 1
+        a = torch.from_numpy(rng.normal(size=(2, C, H, W)).astype(np.float32))
+        b = torch.from_numpy(rng.normal(size=(2, C, H, W)).astype(np.float32))
+        go = torch.from_numpy(rng.normal(size=(2, nd * nd, H, W)).astype(np.float32))
+        ac, bc = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        full = O.correlation(ac, bc, r)
+        idx = [i * (2 * r + 1) + j for i in range(0, 2 * r + 1, s2) for j in range(0, 2 * r + 1, s2)]
+        full[:, idx].backward(go)
+        for need in ((True, True), (True, False), (False, True)):
+            ad, bd = a.to(dev).requires_grad_(need[0]), b.to(dev).requires_grad_(need[1])
+            ops.correlation(ad, bd, r, 1, r, 1, s2).backward(go.to(dev))
+            if need[0]:
+                np.testing.assert_allclose(ad.grad.cpu().numpy(), ac.grad.numpy(), rtol=1e-5, atol=2e-6)
+            if need[1]:
+                np.testing.assert_allclose(bd.grad.cpu().numpy(), bc.grad.numpy(), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_hip_dpv_fuse_every_depth_count_path():
+    """D <= 64 and D <= 128 keep the column in registers, deeper volumes re-read it: all against the oracle."""
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(7)
+    for (B, D, H, W) in ((2, 64, 9, 70), (1, 33, 5, 300), (1, 128, 7, 40), (1, 100, 4, 9), (1, 130, 6, 11)):
+        d = np.linspace(3.0, 60.0, D)
+        logp = torch.log_softmax(torch.from_numpy(rng.normal(size=(B, D, H, W)).astype(np.float32) * 3), dim=1)
+        masks = torch.from_numpy((rng.uniform(size=(B, 1, H, W)) > 0.6).astype(np.float32))
+        dmaps = torch.from_numpy(rng.uniform(3.0, 60.0, size=(B, H, W)).astype(np.float32)) * masks[:, 0]
+        want_fused, want_log = O.dpv_fuse(logp, dmaps, masks, d, 0.3)
+        fused, logf = ops.dpv_fuse(logp.to(dev), dmaps.to(dev), masks.to(dev), d, var=0.3)
+        np.testing.assert_allclose(fused.cpu().numpy(), want_fused.numpy(), rtol=2e-5, atol=1e-9)
+        np.testing.assert_allclose(logf.cpu().numpy(), want_log.numpy(), rtol=1e-5, atol=3e-5)
+        only_log = ops.dpv_fuse(logp.to(dev), dmaps.to(dev), masks.to(dev), d, var=0.3, want_fused=False)
+        assert only_log[0] is None and torch.equal(only_log[1], logf)
