@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--planes", type=int, default=64)
     ap.add_argument("--views", type=int, default=1)
     ap.add_argument("--pose", default="mono", choices=["mono", "stereo"])
-    ap.add_argument("--algo", default="auto", choices=["auto", "direct"])
+    ap.add_argument("--algo", default="auto", choices=["auto", "direct", "tiled1", "tiled2", "cells"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -149,7 +149,7 @@ def main():
         bpv = algorithmic_bytes_per_volume(cfg["C"], cfg["V"], cfg["D"], cfg["H"], cfg["W"])
         prof = {}
         tj = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj):
+        if os.path.exists(tj) and a.algo == "auto" and a.pose == "mono":   # the committed counters are of the default workload
             try:
                 prof = json.load(open(tj))
             except Exception:

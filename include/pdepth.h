@@ -17,6 +17,9 @@
  *     is available from pdepth_last_error() (thread local).  Mirrors the reference's
  *     "kernel launcher returns 0/1, wrapper raises" convention
  *     (models/correlation_package/correlation_cuda_kernel.cu:383-392, correlation_cuda.cc:81-83);
+ *   - the sweep kernels order their tiles per XCD assuming the SPX partition mode of the MI355X
+ *     (workgroup i is dispatched to XCD i mod 8, each XCD with its own L2); under another
+ *     partition mode the results are the same and only L2 locality is lost;
  *   - arithmetic type is fp32 throughout (d_candi is float64 on the
  *     host and cast to fp32 at use, warping/homography.py:115, utils/img_utils.py:58).
  */
@@ -30,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PDEPTH_ABI_VERSION 1
+#define PDEPTH_ABI_VERSION 2   /* 2: packed-source entries, dpv_reduce_ex, ufield, implementation selectors */
 
 enum {
     PDEPTH_OK = 0,

@@ -139,7 +139,7 @@ def load():
                "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32", "pdepth_inverse_warp_f32",
                "pdepth_dpv_moments_f32", "pdepth_correlation_backward_f32"):
         getattr(lib, fn).restype = c_int
-    if lib.pdepth_abi_version() != 1:
+    if lib.pdepth_abi_version() != 2:
         raise RuntimeError("libpdepth_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -156,39 +156,44 @@ hipError_t launch_dpv_fuse(const float* logp, const float* dmaps, const float* m
 }
 
 // ---------------------------------------------------------------------------------------------------
-// correlation forward: block = 16x16 output pixels; the x2 halo tile and the x1 tile of a channel chunk
-// are staged in LDS; every thread keeps all (2r+1)^2 <= 81 displacement sums of its pixel in registers.
+// correlation forward: block = 16x16 output pixels x ONE row of displacements (dy); the x2 tile of that row (halo in
+// x only) and the x1 tile of a channel chunk are staged in LDS; every thread keeps the 2r+1 <= 9 sums of its pixel
+// and row in registers.  Splitting the displacement rows over blocks gives (2r+1) x more workgroups (a 64x128 map has
+// only 32 tiles) and 9 instead of 81 live accumulators; the price is that the x2 rows are staged once per row of
+// displacements (from L2).  Sum over c in ascending order, one fma each, scaled by 1/C at the end.
 // ---------------------------------------------------------------------------------------------------
 constexpr int CT = 16;       // tile edge
 constexpr int CCH = 8;       // channels per chunk
-constexpr int RMAX = 4;      // max displacement radius (in units of stride2) held in registers: 81 sums
+constexpr int RMAX = 4;      // max displacement radius (in units of stride2)
 
 template <int R>
 __global__ __launch_bounds__(256) void correlation_fwd_kernel(const float* __restrict__ x1,
                                                               const float* __restrict__ x2, int C, int H, int W,
                                                               int s2, float* __restrict__ out) {
     extern __shared__ float smem[];
+    constexpr int ND = 2 * R + 1;
     const int halo = R * s2;
-    const int TWH = CT + 2 * halo;           // halo tile edge
-    float* t2 = smem;                        // [CCH][TWH][TWH]
-    float* t1 = smem + CCH * TWH * TWH;      // [CCH][CT*CT]
+    const int TW = CT + 2 * halo;            // row length of the x2 tile
+    float* t2 = smem;                        // [CCH][CT][TW]
+    float* t1 = smem + CCH * CT * TW;        // [CCH][CT*CT]
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int x0 = blockIdx.x * CT, y0 = blockIdx.y * CT;
-    const int b = blockIdx.z;
+    const int i = blockIdx.z % ND, b = blockIdx.z / ND;
+    const int dy = (i - R) * s2;
     const int x = x0 + tx, y = y0 + ty;
     const int HW = H * W;
-    constexpr int ND = 2 * R + 1;
-    float acc[ND * ND];
+    float acc[ND];
 #pragma unroll
-    for (int i = 0; i < ND * ND; ++i) acc[i] = 0.0f;
+    for (int j = 0; j < ND; ++j) acc[j] = 0.0f;
     for (int c0 = 0; c0 < C; c0 += CCH) {
         __syncthreads();
-        for (int idx = threadIdx.x; idx < CCH * TWH * TWH; idx += 256) {
-            const int cc = idx / (TWH * TWH), rem = idx - cc * TWH * TWH;
-            const int ry = rem / TWH, rx = rem - ry * TWH;
-            const int gx = x0 - halo + rx, gy = y0 - halo + ry, c = c0 + cc;
+        for (int idx = threadIdx.x; idx < CCH * CT * TW; idx += 256) {
+            const int cc = idx / (CT * TW), rem = idx - cc * CT * TW;
+            const int ry = rem / TW, rx = rem - ry * TW;
+            const int gx = x0 - halo + rx, gy = y0 + dy + ry, c = c0 + cc;
             t2[idx] = (c < C && gx >= 0 && gx < W && gy >= 0 && gy < H) ? x2[((size_t)b * C + c) * HW + gy * W + gx] : 0.0f;
         }
+#pragma unroll
         for (int cc = 0; cc < CCH; ++cc) {
             const int c = c0 + cc;
             t1[cc * 256 + threadIdx.x] = (c < C && x < W && y < H) ? x1[((size_t)b * C + c) * HW + y * W + x] : 0.0f;
@@ -197,34 +202,40 @@ __global__ __launch_bounds__(256) void correlation_fwd_kernel(const float* __res
 #pragma unroll
         for (int cc = 0; cc < CCH; ++cc) {
             const float a = t1[cc * 256 + threadIdx.x];
-            const float* row = t2 + cc * TWH * TWH + (ty + halo) * TWH + (tx + halo);
+            const float* row = t2 + (cc * CT + ty) * TW + tx;
 #pragma unroll
-            for (int dy = -R; dy <= R; ++dy)
-#pragma unroll
-                for (int dx = -R; dx <= R; ++dx)
-                    acc[(dy + R) * ND + (dx + R)] = __builtin_fmaf(a, row[dy * s2 * TWH + dx * s2], acc[(dy + R) * ND + (dx + R)]);
+            for (int j = 0; j < ND; ++j) acc[j] = __builtin_fmaf(a, row[j * s2], acc[j]);
         }
     }
     if (x < W && y < H) {
         const float inv = 1.0f / (float)C;
 #pragma unroll
-        for (int i = 0; i < ND * ND; ++i) out[((size_t)b * ND * ND + i) * HW + y * W + x] = acc[i] * inv;
+        for (int j = 0; j < ND; ++j) out[((size_t)b * ND * ND + i * ND + j) * HW + y * W + x] = acc[j] * inv;
     }
 }
 
 hipError_t launch_correlation_forward(const float* x1, const float* x2, int B, int C, int H, int W, int radius,
                                       int stride2, float* out, hipStream_t stream) {
-    dim3 grid((W + CT - 1) / CT, (H + CT - 1) / CT, B);
-    const int TWH = CT + 2 * radius * stride2;
-    const size_t lds = (size_t)(CCH * TWH * TWH + CCH * 256) * sizeof(float);
+    const int ND = 2 * radius + 1;
+    dim3 grid((W + CT - 1) / CT, (H + CT - 1) / CT, B * ND);
+    const int TW = CT + 2 * radius * stride2;
+    const size_t lds = (size_t)(CCH * CT * TW + CCH * 256) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto go_launch = [&](auto kern) -> hipError_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, x1, x2, C, H, W, stride2, out);
+        return hipGetLastError();
+    };
     switch (radius) {
-        case 1: hipLaunchKernelGGL(correlation_fwd_kernel<1>, grid, dim3(256), lds, stream, x1, x2, C, H, W, stride2, out); break;
-        case 2: hipLaunchKernelGGL(correlation_fwd_kernel<2>, grid, dim3(256), lds, stream, x1, x2, C, H, W, stride2, out); break;
-        case 3: hipLaunchKernelGGL(correlation_fwd_kernel<3>, grid, dim3(256), lds, stream, x1, x2, C, H, W, stride2, out); break;
-        case 4: hipLaunchKernelGGL(correlation_fwd_kernel<4>, grid, dim3(256), lds, stream, x1, x2, C, H, W, stride2, out); break;
+        case 1: return go_launch(correlation_fwd_kernel<1>);
+        case 2: return go_launch(correlation_fwd_kernel<2>);
+        case 3: return go_launch(correlation_fwd_kernel<3>);
+        case 4: return go_launch(correlation_fwd_kernel<4>);
         default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 int correlation_max_radius() { return RMAX; }

@@ -98,27 +98,47 @@ __global__ __launch_bounds__(256) void ufield_mask_kernel(const float* __restric
     if (tid == 0) ax[b * W + x] = s_red[0];
 }
 
-// grid (ceil(W/64), ceil(D/4), B), block (64, 4): lane = column, threadIdx.y = plane of the group.
+// grid (ceil(W/64), ceil(D/4), B), block (64, 8): lane = column, threadIdx.y = eighth of the rows; every thread
+// accumulates 4 planes over its rows (4 independent loads per row, 4 rows unrolled, the mask read once for the 4
+// planes: the kernel lives on loads in flight), the eighths are combined through LDS in row order.
 template <bool BV_LOG>
-__global__ __launch_bounds__(256) void ufield_collapse_kernel(const float* __restrict__ dpv, const float* __restrict__ depth_pred,
+__global__ __launch_bounds__(512) void ufield_collapse_kernel(const float* __restrict__ dpv, const float* __restrict__ depth_pred,
                                                               const float* __restrict__ zero_mask, const float* __restrict__ ax,
                                                               int D, int H, int W, float pshift, float* __restrict__ plane,
                                                               float* __restrict__ depth_zero) {
-    const int x = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
-    if (x >= W || k >= D) return;
+    __shared__ float s_part[8][4][64];
+    const int x = blockIdx.x * 64 + threadIdx.x, k0 = blockIdx.y * 4, b = blockIdx.z, seg = threadIdx.y;
+    const bool col = x < W;
     const bool sampled = pshift != 0.0f;
-    const int sx = nearest_src(x, 0.0f, W, sampled);
+    const int sx = col ? nearest_src(x, 0.0f, W, sampled) : -1;
     const float* zm = zero_mask + (size_t)b * H * W;
-    const float* v = dpv + ((size_t)b * D + k) * H * W + x;
-    float acc = 0.0f;
-    for (int y = 0; y < H; ++y) {
-        const int sy = nearest_src(y, -pshift, H, sampled);   // the mask is shifted back (flowfield_inv)
-        const float m = (sx >= 0 && sy >= 0) ? zm[(size_t)sy * W + sx] : 0.0f;
-        const float p = BV_LOG ? expf(v[(size_t)y * W]) : v[(size_t)y * W];
-        acc = acc + p * m;
-        if (k == 0) depth_zero[(size_t)b * H * W + (size_t)y * W + x] = depth_pred[(size_t)b * H * W + (size_t)y * W + x] * m;
+    const size_t HW = (size_t)H * W;
+    const float* v = dpv + ((size_t)b * D + k0) * HW + x;
+    const int rows = (H + 7) / 8, y_lo = seg * rows, y_hi = min(H, y_lo + rows);
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (col) {
+#pragma unroll 4
+        for (int y = y_lo; y < y_hi; ++y) {
+            const int sy = nearest_src(y, -pshift, H, sampled);   // the mask is shifted back (flowfield_inv)
+            const float m = (sx >= 0 && sy >= 0) ? zm[(size_t)sy * W + sx] : 0.0f;
+            float p[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[j] = (k0 + j < D) ? v[j * HW + (size_t)y * W] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] + (BV_LOG ? expf(p[j]) : p[j]) * m;
+            if (k0 == 0) depth_zero[(size_t)b * HW + (size_t)y * W + x] = depth_pred[(size_t)b * HW + (size_t)y * W + x] * m;
+        }
     }
-    plane[((size_t)b * D + k) * W + x] = acc / ax[b * W + x];   // 0 / 0 = NaN where no pixel of the column qualifies, as in the reference
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s_part[seg][j][threadIdx.x] = acc[j];
+    __syncthreads();
+    const int j = threadIdx.y;   // thread (lane, j) finishes plane k0 + j of column x
+    if (col && j < 4 && k0 + j < D) {
+        float sum = s_part[0][j][threadIdx.x];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) sum = sum + s_part[q][j][threadIdx.x];
+        plane[((size_t)b * D + k0 + j) * W + x] = sum / ax[b * W + x];   // 0 / 0 = NaN where no pixel of the column qualifies, as in the reference
+    }
 }
 
 size_t ufield_workspace_bytes(int B, int H, int W) { return ((size_t)B * (2 * (size_t)H * W + W) * sizeof(float) + 255) & ~(size_t)255; }
@@ -133,7 +153,7 @@ hipError_t launch_ufield(const float* dpv, const float* d_candi, const float* in
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(ufield_mask_kernel, dim3(W, B), dim3(256), 0, stream, depth_pred, intr, mask, H, W, unc_ang, zstart, zend,
                        mind, quash, oob_depth, zero_mask, ax);
-    dim3 grid((W + 63) / 64, (D + 3) / 4, B), block(64, 4);
+    dim3 grid((W + 63) / 64, (D + 3) / 4, B), block(64, 8);
     if (bv_log)
         hipLaunchKernelGGL(ufield_collapse_kernel<true>, grid, block, 0, stream, dpv, depth_pred, zero_mask, ax, D, H, W, unc_ang, plane, depth_zero);
     else

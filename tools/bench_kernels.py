@@ -39,31 +39,85 @@ def sweep_case(name, B, C, D, H, W, V, pose, algo="auto", steps=20):
                       "fallback_tiles": pdepth_amd._native.fallback_tiles(B, H, W)}), flush=True)
 
 
+def line(case, ms, byt, **kw):
+    """One roofline line: algorithmic bytes of the case / measured time against the 8 TB/s HBM peak."""
+    rec = {"case": case, "ms": ms, "algorithmic_MB": byt / 1e6, "algorithmic_GBps": byt / ms / 1e6,
+           "hbm_frac": byt / ms / 1e6 / 8000.0}
+    rec.update(kw)
+    print(json.dumps(rec), flush=True)
+
+
 def main():
     sweep_case("cfg2 mono 256x512 B=4", 4, 67, 64, 256, 512, 1, "mono")
     sweep_case("cfg3 stereo 256x512 B=4 (per-GPU share of B=32)", 4, 67, 64, 256, 512, 1, "stereo")
     sweep_case("cfg1/2 model-real 64x128 B=4", 4, 67, 64, 64, 128, 1, "mono", steps=50)
     sweep_case("cfg5 D=128 512x1024 V=4 B=2 (per-GPU share of B=16)", 2, 67, 128, 512, 1024, 4, "mono", steps=5)
     sweep_case("cfg2 mono 256x512 B=4 gather kernel", 4, 67, 64, 256, 512, 1, "mono", algo="direct", steps=5)
+    # the implementations behind "auto", forced (A/B): one-tile and two-tile builds of the tiled kernel, cell-list kernels
+    for algo in ("tiled1", "tiled2", "cells"):
+        sweep_case("cfg2 mono 256x512 B=4", 4, 67, 64, 256, 512, 1, "mono", algo=algo)
+        sweep_case("cfg3 stereo 256x512 B=4", 4, 67, 64, 256, 512, 1, "stereo", algo=algo)
+        sweep_case("model-real 64x128 B=4", 4, 67, 64, 64, 128, 1, "mono", algo=algo, steps=50)
+    sweep_case("cfg5 D=128 512x1024 V=4 B=2", 2, 67, 128, 512, 1024, 4, "mono", algo="cells", steps=5)
+    # packed-source entry (pdepth_pack_source_f32 once, pdepth_sweep_dpv_packed_f32 per step) and the pre-pass alone
+    b = synth.make_batch(2, 4, C=67, D=64, H=256, W=512, V=1, pose="mono")
+    d = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    dc = ops.d_candi_tensor(d["d_candi"], "cuda")
+    ps = ops.pack_source(d["src"], 64)
+    ms = timeit(lambda: ops.sweep_dpv(d["ref"], ps, d["K"], d["R"], d["t"], d["rays"], d["cxcy"], dc, 10.0))
+    line("cfg2 mono 256x512 B=4, packed-source entry", ms, 4 * 256 * 512 * (67 * 2 + 64 + 1) * 4, volumes_per_s=4 / ms * 1e3)
+    ms = timeit(lambda: ops.pack_source(d["src"], 64))
+    line("pack_source B=4 V=1 C=67 256x512 (read NCHW, write 17+2 float4 planes)", ms, 4 * 256 * 512 * 4 * (67 + 19 * 4))
     # DPV reduction alone at full resolution (decoder output, models.py:351 + default_trainer.py:233)
     for (B, D, H, W) in ((4, 64, 256, 512), (4, 64, 64, 128)):
         x = torch.randn(B, D, H, W, device="cuda")
+        y = torch.randn(B, D, H, W, device="cuda")
         dc = ops.d_candi_tensor(synth.powerf(5, 40, D, 1.0), "cuda")
+        tag = "B=%d D=%d %dx%d" % (B, D, H, W)
         ms = timeit(lambda: ops.dpv_reduce(x, dc), steps=50)
-        byt = 4 * H * W * (2 * D + 1) * B
-        print(json.dumps({"case": "dpv_reduce B=%d D=%d %dx%d" % (B, D, H, W), "ms": ms,
-                          "algorithmic_GBps": byt / ms / 1e6, "hbm_frac": byt / ms / 1e6 / 8000.0}), flush=True)
+        line("dpv_reduce " + tag, ms, 4 * H * W * (2 * D + 1) * B)
         ms = timeit(lambda: ops.dpv_expect(x, dc, BV_log=True), steps=50)
-        byt = 4 * H * W * (D + 1) * B
-        print(json.dumps({"case": "dpv_expect B=%d D=%d %dx%d" % (B, D, H, W), "ms": ms,
-                          "algorithmic_GBps": byt / ms / 1e6, "hbm_frac": byt / ms / 1e6 / 8000.0}), flush=True)
+        line("dpv_expect " + tag, ms, 4 * H * W * (D + 1) * B)
+        ms = timeit(lambda: ops.dpv_moments(x, dc, BV_log=True), steps=50)
+        line("dpv_moments " + tag, ms, 4 * H * W * (D + 2) * B)
+        ms = timeit(lambda: ops.dpv_reduce_ex(x, dc, want_logp=True, want_depth=True, want_var=True, want_quarter=True), steps=50)
+        line("dpv_reduce_ex logp+depth+variance+quarter " + tag, ms, 4 * H * W * (2 * D + 2) * B + 4 * (H // 4) * (W // 4) * D * B)
+        ms = timeit(lambda: ops.dpv_reduce_ex(x, dc, addend=y, want_logp=True, want_prob=True), steps=50)
+        line("dpv_reduce_ex feedback update (logits+addend -> logp, prob) " + tag, ms, 4 * H * W * 4 * D * B)
+        lp = torch.log_softmax(x, dim=1)
+        mk = (torch.rand(B, 1, H, W, device="cuda") > 0.6).float()
+        dm = (torch.rand(B, H, W, device="cuda") * 30 + 6) * mk[:, 0]
+        ms = timeit(lambda: ops.dpv_fuse(lp, dm, mk, dc, 0.3), steps=50)
+        line("dpv_fuse (fused + log) " + tag, ms, 4 * H * W * (3 * D + 2) * B)
+        intr = torch.tensor([[0.58 * W, 0, W / 2.0, 0, 0.58 * W, H / 2.0, 0, 0, 1]], device="cuda").repeat(B, 1).reshape(B, 3, 3)
+        ms = timeit(lambda: ops.ufield(lp, dc, intr, None, BV_log=True), steps=50)
+        line("ufield (expectation + band mask + column collapse) " + tag, ms, 4 * H * W * (2 * D + 2) * B,
+             note="two reads of the volume: the mask needs the depth map of the whole column first")
     # warp_feature, feedback mode: [B, V=2, 64, 64, 128]
     it = synth.make_batch(4, 4, C=64, D=64, H=64, W=128, V=2, pose="mono")
     d = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in it.items()}
     dc = ops.d_candi_tensor(d["d_candi"], "cuda")
     ms = timeit(lambda: ops.warp_feature(d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], dc), steps=50)
-    byt = 8 * 64 * 128 * 2 * 64 * 4
-    print(json.dumps({"case": "warp_feature B=4 V=2 D=64 64x128", "ms": ms, "algorithmic_GBps": byt / ms / 1e6}), flush=True)
+    line("warp_feature B=4 V=2 D=64 64x128", ms, 8 * 64 * 128 * 2 * 64 * 4)
+    ms = timeit(lambda: ops.sample_coords(d["K"], d["R"], d["t"], d["rays"], d["cxcy"], dc, 64, 128), steps=50)
+    line("sample_coords B=4 V=2 D=64 64x128", ms, 8 * 64 * 128 * 2 * 64 * 4 + 12 * 64 * 128 * 4)
+    # correlation op (PWC-Lite shapes: C=32..128 at 1/8..1/64 resolution; here B=4, C=64, 64x128, 9x9 displacements)
+    x1 = torch.randn(4, 64, 64, 128, device="cuda")
+    x2 = torch.randn(4, 64, 64, 128, device="cuda")
+    go = torch.randn(4, 81, 64, 128, device="cuda")
+    ms = timeit(lambda: pdepth_amd._native.correlation_forward(x1, x2, 4, 1, 4, 1, 1, 1), steps=50)
+    line("correlation forward B=4 C=64 64x128 r=4", ms, 4 * 64 * 128 * 4 * (2 * 64 + 81),
+         lds_tile_flops=2.0 * 81 * 64 * 64 * 128 * 4, tflops=2.0 * 81 * 64 * 64 * 128 * 4 / ms / 1e9)
+    ms = timeit(lambda: pdepth_amd._native.correlation_backward(x1, x2, go, 4, 1, 4, 1, 1, 1), steps=50)
+    line("correlation backward (both gradients) B=4 C=64 64x128 r=4", ms, 4 * 64 * 128 * 4 * (4 * 64 + 81),
+         tflops=4.0 * 81 * 64 * 64 * 128 * 4 / ms / 1e9)
+    from pdepth_amd.utils import inverse_warp as iw
+    img = torch.randn(4, 3, 256, 512, device="cuda")
+    dep = torch.rand(4, 256, 512, device="cuda") * 30 + 5
+    pose = torch.eye(4, device="cuda").repeat(4, 1, 1)
+    K = torch.tensor([[300.0, 0, 256], [0, 300.0, 128], [0, 0, 1]], device="cuda").repeat(4, 1, 1)
+    ms = timeit(lambda: iw.inverse_warp(img, dep, pose, K), steps=50)
+    line("inverse_warp B=4 C=3 256x512 (host wrapper included)", ms, 4 * 256 * 512 * 4 * (3 + 1 + 3) + 4 * 256 * 512)
 
 
 def model_cases():
