@@ -90,6 +90,25 @@ constexpr int BUF_BYTES = NTEX_MAX * 16;   // one window buffer of the direct gr
 #ifndef PDEPTH_BAND_TEX
 #define PDEPTH_BAND_TEX (PDEPTH_NSUB == 1 ? 256 : 448)
 #endif
+// Counter experiments only (tools/variants_tiled.sh; the results are WRONG with them): -DPDEPTH_CONF_TAPS / _BANDX /
+// _GRAM replace the per-pixel gather address of one class of LDS reads by the conflict-free lane * 16 (+ a KiB per read), so that the
+// difference in SQ_LDS_BANK_CONFLICT attributes the conflicts to that class.
+#define PDEPTH_CONF_SEL_TAPS 0
+#define PDEPTH_CONF_SEL_BANDX 0
+#define PDEPTH_CONF_SEL_GRAM 0
+#ifdef PDEPTH_CONF_TAPS
+#undef PDEPTH_CONF_SEL_TAPS
+#define PDEPTH_CONF_SEL_TAPS 1
+#endif
+#ifdef PDEPTH_CONF_BANDX
+#undef PDEPTH_CONF_SEL_BANDX
+#define PDEPTH_CONF_SEL_BANDX 1
+#endif
+#ifdef PDEPTH_CONF_GRAM
+#undef PDEPTH_CONF_SEL_GRAM
+#define PDEPTH_CONF_SEL_GRAM 1
+#endif
+#define PDEPTH_CONF_ADDR(WHICH, addr, salt) (PDEPTH_CONF_SEL_##WHICH ? ((int)(threadIdx.x & 63) * 16 + (salt) * 1024) : (addr))
 #ifndef PDEPTH_NX
 #define PDEPTH_NX (PDEPTH_NSUB == 1 ? 64 : 48)
 #endif
@@ -538,8 +557,8 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     }
 #define PDEPTH_LOAD(T, i_)                                                          \
     {                                                                               \
-        const lds_v4f q0 = (lds_v4f)(size_t)(unsigned)(off[i_] + CUR * NTEX_MAX * 16);        \
-        const lds_v4f q1 = (lds_v4f)(size_t)(unsigned)(off[i_] + WCB + CUR * NTEX_MAX * 16);  \
+        const lds_v4f q0 = (lds_v4f)(size_t)(unsigned)(PDEPTH_CONF_ADDR(TAPS, off[i_], (i_) & 3) + CUR * NTEX_MAX * 16);        \
+        const lds_v4f q1 = (lds_v4f)(size_t)(unsigned)(PDEPTH_CONF_ADDR(TAPS, off[i_], (i_) & 3) + WCB + CUR * NTEX_MAX * 16);  \
         T[0] = q0[0]; T[1] = q0[1]; T[2] = q1[0]; T[3] = q1[1];                     \
     }
                     // Software pipeline over the part's planes: the four taps of plane i+1 are in flight while
@@ -639,7 +658,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
 #pragma unroll
                 for (int m = 0; m < XPW; ++m) {
                     while (jc >= NC) { jc -= NC; ++jr; }
-                    xaddr[m] = jr < NR ? base + (jr * gWC + jc) * 16 : base;
+                    xaddr[m] = PDEPTH_CONF_ADDR(BANDX, jr < NR ? base + (jr * gWC + jc) * 16 : base, m);
                     xacc[m] = 0.0f;
                     jc += NPG;
                 }
@@ -710,7 +729,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
                 if (!any) { fw = fw * 0.0f; fe = fe * 0.0f; fn = fn * 0.0f; fs = fs * 0.0f; dx = 0; dy = 0; }
                 if ((unsigned)dx > (unsigned)(NC - 2) || (unsigned)dy > (unsigned)(NR - 2)) { viol = 1; dx = 0; dy = 0; }
                 const int slot = dy * NC + dx;
-                const int tex = ((bby0 + dy - gwy0) * gWC + (bbx0 + dx - gwx0)) * 16;
+                const int tex = PDEPTH_CONF_ADDR(GRAM, ((bby0 + dy - gwy0) * gWC + (bbx0 + dx - gwx0)) * 16, 0);
                 auto xat = [&](int j) { return *(lds_f)(size_t)(unsigned)(xb + j * 256); };
                 const float X00 = xat(slot), X01 = xat(slot + 1), X10 = xat(slot + NC), X11 = xat(slot + NC + 1);
                 const v4f G00 = *(lds_v4f)(size_t)(unsigned)(g4b + tex);

@@ -316,7 +316,7 @@ class BaseModel(nn.Module):
         # self.last_aux: by-products of the DPV passes (depth maps, next prev_output) for harness.eval_step; the
         # returned dict keeps exactly the reference's keys (models.py:656,678,699)
         self.last_aux = None
-        d_candi = model_input["d_candi"]
+        d_candi = model_input.get("d_candi")   # (.get: an unknown nmode must reach the reference's error below)
         if self.nmode == "default":
             half, raw, feats_all = self._features(model_input)
             cost_volumes = self._sweep(feats_all, model_input)
