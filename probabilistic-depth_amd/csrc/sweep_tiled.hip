@@ -93,6 +93,9 @@ constexpr int BUF_BYTES = NTEX_MAX * 16;   // one window buffer of the direct gr
 // Counter experiments only (tools/variants_tiled.sh; the results are WRONG with them): -DPDEPTH_CONF_TAPS / _BANDX /
 // _GRAM replace the per-pixel gather address of one class of LDS reads by the conflict-free lane * 16 (+ a KiB per read), so that the
 // difference in SQ_LDS_BANK_CONFLICT attributes the conflicts to that class.
+#ifndef PDEPTH_ABL_STOP
+#define PDEPTH_ABL_STOP 0
+#endif
 #define PDEPTH_CONF_SEL_TAPS 0
 #define PDEPTH_CONF_SEL_BANDX 0
 #define PDEPTH_CONF_SEL_GRAM 0
@@ -166,6 +169,10 @@ __device__ __forceinline__ void wait_dma_but(int n) {
 }
 // raw barrier: every LDS access of this wave has completed, but VMEM (the DMA of later chunks) stays in flight
 __device__ __forceinline__ void lds_barrier() {
+#ifdef PDEPTH_ABL_NOBAR   // timing experiment (results wrong): what do the per-chunk barriers of the staging loops cost?
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return;
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 __device__ __forceinline__ v4i make_rsrc(const void* base, int bytes) {
@@ -399,6 +406,10 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
             }
         }
         const int kend = ks;  // planes [0, kend) are evaluated directly
+#if PDEPTH_ABL_STOP == 1   // counter experiments (results wrong): leave the tile after the band decision, ...
+        if (ks + NC + NR + bbx0 + bby0 + gwx0 + gwy0 + gWC + gWR == 0x7ffffff0 && lane == 0) flag_subtile();  // (keeps the decision alive)
+        goto tile_done;
+#endif
 
         for (int k0 = 0; k0 < kend; k0 += SG) {
             // ---- geometry of this thread's KP planes (registers) ----------------------------
@@ -617,6 +628,9 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
             }
         }
 
+#if PDEPTH_ABL_STOP == 2   // ... after the direct groups, ...
+        goto tile_done;
+#endif
         // ---- band group: planes [ks, D) in correlation form --------------------------------------------
         if (ks < a.D) {  // block-uniform
             typedef const __attribute__((address_space(3))) v4f* lds_v4f;
@@ -751,6 +765,9 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
             if (wave_max_s(viol) != 0 && lane == 0) flag_subtile();  // the gather kernel redoes the sub-tile
         }
     }
+#if PDEPTH_ABL_STOP == 3   // ... or before the epilogue
+    goto tile_done;
+#endif
     __syncthreads();
     {
     // ---- epilogue from LDS: cost store, log-softmax over D, expectation ----------------------
