@@ -30,8 +30,11 @@ struct SweepArgs {
 
 // sweep_direct.hip
 hipError_t launch_sweep_direct(const SweepArgs& a, hipStream_t stream);
-hipError_t launch_sweep_direct_flagged(const SweepArgs& a, const int* tile_flags, int tiles_x, int tiles,
-                                       hipStream_t stream, int flag_value = 1);  // runs the tiles whose flag == flag_value
+// Workspace counter (an int of the 64 queue ints behind the tile flags) of the tiles handed to the gather kernel:
+// every writer of a gather flag increments it, the gather kernel's blocks leave at once while it is zero.
+constexpr int GATHER_COUNT_SLOT = 48;
+hipError_t launch_sweep_direct_flagged(const SweepArgs& a, const int* tile_flags, const int* gather_count, int tiles_x,
+                                       int tiles, hipStream_t stream, int flag_value = 1);  // runs the tiles whose flag == flag_value
 int sweep_direct_max_planes(int C);
 
 // sweep_tiled.hip

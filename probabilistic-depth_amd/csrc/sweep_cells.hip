@@ -575,7 +575,7 @@ __global__ __launch_bounds__(NT, CELLS_OCC) void sweep_cells_kernel(SweepArgs a,
         }          // views
 
         if (bail) {
-            if (tid == 0) *my_flag = 2;
+            if (tid == 0) { *my_flag = 2; atomicAdd(&queue[GATHER_COUNT_SLOT - 8], 1); }   // (queue = workspace counters + 8)
         } else {
             // ---- epilogue from registers: cost store, log-softmax over D, expectation --------------------
             const size_t obase = (size_t)b * a.D * HW + p;
@@ -700,7 +700,7 @@ hipError_t launch_sweep_cells(const SweepArgs& a, void* workspace, hipStream_t s
                        fast_ok ? (const int*)redo_list : (const int*)nullptr);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_sweep_direct_flagged(a, flags, tiles_x, tiles, stream, 2);
+    return launch_sweep_direct_flagged(a, flags, queue + GATHER_COUNT_SLOT, tiles_x, tiles, stream, 2);
 }
 
 }  // namespace pdepth

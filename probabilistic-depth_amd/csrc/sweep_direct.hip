@@ -21,7 +21,10 @@ namespace pdepth {
 //                         kernel flagged that tile (sweep_tiled.hip).
 template <int METRIC, int CCH, bool MULTI_CHUNK>
 __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int* __restrict__ tile_flags,
-                                                          int tiles_x, int tiles, int flag_value) {
+                                                          const int* __restrict__ gather_count, int tiles_x, int tiles,
+                                                          int flag_value) {
+    // the usual case -- no tile was handed over -- costs one scalar load per block
+    if (gather_count && *gather_count == 0) return;
     extern __shared__ float lds[];
     const int tid = threadIdx.x;
     const int HW = a.H * a.W;
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int
 }
 
 template <int METRIC>
-static hipError_t launch_metric(const SweepArgs& a, const int* tile_flags, int tiles_x, int tiles,
+static hipError_t launch_metric(const SweepArgs& a, const int* tile_flags, const int* gather_count, int tiles_x, int tiles,
                                 hipStream_t stream, int flag_value = 1) {
     const int HW = a.H * a.W;
     dim3 grid(tile_flags ? (tiles < 256 ? tiles : 256) : (HW + 63) / 64, a.B);
@@ -140,26 +143,26 @@ static hipError_t launch_metric(const SweepArgs& a, const int* tile_flags, int t
         auto kern = sweep_direct_kernel<METRIC, 68, false>;
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, a, tile_flags, tiles_x, tiles, flag_value);
+        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, a, tile_flags, gather_count, tiles_x, tiles, flag_value);
     } else {
         const size_t lds = (size_t)a.D * 64 * sizeof(float) * 2;
         auto kern = sweep_direct_kernel<METRIC, 32, true>;
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, a, tile_flags, tiles_x, tiles, flag_value);
+        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, a, tile_flags, gather_count, tiles_x, tiles, flag_value);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_sweep_direct(const SweepArgs& a, hipStream_t stream) {
-    return a.metric == 0 ? launch_metric<0>(a, nullptr, 0, 0, stream)
-                         : launch_metric<1>(a, nullptr, 0, 0, stream);
+    return a.metric == 0 ? launch_metric<0>(a, nullptr, nullptr, 0, 0, stream)
+                         : launch_metric<1>(a, nullptr, nullptr, 0, 0, stream);
 }
 
-hipError_t launch_sweep_direct_flagged(const SweepArgs& a, const int* tile_flags, int tiles_x, int tiles,
-                                       hipStream_t stream, int flag_value) {
-    return a.metric == 0 ? launch_metric<0>(a, tile_flags, tiles_x, tiles, stream, flag_value)
-                         : launch_metric<1>(a, tile_flags, tiles_x, tiles, stream, flag_value);
+hipError_t launch_sweep_direct_flagged(const SweepArgs& a, const int* tile_flags, const int* gather_count, int tiles_x,
+                                       int tiles, hipStream_t stream, int flag_value) {
+    return a.metric == 0 ? launch_metric<0>(a, tile_flags, gather_count, tiles_x, tiles, stream, flag_value)
+                         : launch_metric<1>(a, tile_flags, gather_count, tiles_x, tiles, stream, flag_value);
 }
 
 // Largest D the direct kernel can hold in LDS (two arrays in the chunked variant).

@@ -305,7 +305,10 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     auto flag_subtile = [&]() {
         const int tiles16_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
         const int tx16 = (tile % tiles_x) * NSUB + sub, ty = tile / tiles_x;
-        if (tx16 < tiles16_x) tile_flags[b * tiles16_x * tiles_y + ty * tiles16_x + tx16] = 1;
+        if (tx16 < tiles16_x) {
+            tile_flags[b * tiles16_x * tiles_y + ty * tiles16_x + tx16] = 1;
+            atomicAdd(&queue[GATHER_COUNT_SLOT], 1);
+        }
     };
 
     const float cx = a.cxcy[b * 2 + 0], cy = a.cxcy[b * 2 + 1];
@@ -978,7 +981,7 @@ hipError_t PDEPTH_CAT(launch_sweep_tiled_n, PDEPTH_NSUB)(const SweepArgs& a, voi
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_sweep_direct_flagged(a, flags, tiles16_x, tiles16_x * tiles_y, stream);
+    return launch_sweep_direct_flagged(a, flags, queue + GATHER_COUNT_SLOT, tiles16_x, tiles16_x * tiles_y, stream);
 }
 
 }  // namespace pdepth
