@@ -331,8 +331,9 @@ def correlation(x1, x2, max_displacement=4):
     return torch.cat(cv, 1)
 
 
-def inverse_warp(img, depth, pose_mat, intrinsics):
-    """Depth-driven inverse warp for a [B,4,4] or [B,3,4] pose -> (warped, valid).
+def inverse_warp(img, depth, pose_mat, intrinsics, mode="bilinear"):
+    """Depth-driven inverse warp for a [B,4,4] or [B,3,4] pose -> (warped, valid).  Plain torch ops: autograd through
+    this function is the oracle of the backward (losses/loss_blocks.py:116,151 call it under autograd).
 
     utils/inverse_warp.py:174-210: pixel2cam (:26-40), K @ pose (:200), cam2pixel (:43-69: Z clamped at 1e-3,
     normalisation with (w-1)/(h-1)), F.grid_sample with default align_corners, validity = |grid| <= 1 (:208).
@@ -347,5 +348,5 @@ def inverse_warp(img, depth, pose_mat, intrinsics):
     pc = torch.matmul(proj[:, :, :3], cam.reshape(b, 3, -1)) + proj[:, :, -1:]
     Z = pc[:, 2].clamp(min=1e-3)
     grid = torch.stack([2 * (pc[:, 0] / Z) / (w - 1) - 1, 2 * (pc[:, 1] / Z) / (h - 1) - 1], dim=2).reshape(b, h, w, 2)
-    out = F.grid_sample(img, grid, padding_mode="zeros", mode="bilinear", align_corners=False)
+    out = F.grid_sample(img, grid, padding_mode="zeros", mode=mode, align_corners=False)
     return out, grid.abs().max(dim=-1)[0] <= 1

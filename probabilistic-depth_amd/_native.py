@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "pdepth_abi_version", "pdepth_last_error", "pdepth_sweep_workspace_bytes",
     "pdepth_sweep_cost_f32", "pdepth_sweep_dpv_f32", "pdepth_dpv_reduce_f32",
     "pdepth_dpv_expect_f32", "pdepth_warp_feature_f32", "pdepth_sample_coords_f32",
-    "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32", "pdepth_inverse_warp_f32",
+    "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32", "pdepth_inverse_warp_f32", "pdepth_inverse_warp_backward_f32",
     "pdepth_dpv_moments_f32", "pdepth_correlation_backward_f32",
     "pdepth_pack_source_f32", "pdepth_sweep_dpv_packed_f32", "pdepth_dpv_reduce_ex_f32",
     "pdepth_ufield_workspace_bytes", "pdepth_ufield_f32",
@@ -133,7 +133,8 @@ def load():
                                         c_float, c_float, c_void_p, c_void_p, c_void_p]
     lib.pdepth_correlation_forward_f32.argtypes = [c_void_p, c_void_p] + [c_int32] * 10 + [c_void_p, c_void_p]
     lib.pdepth_correlation_backward_f32.argtypes = [c_void_p] * 3 + [c_int32] * 10 + [c_void_p] * 3
-    lib.pdepth_inverse_warp_f32.argtypes = [c_void_p] * 4 + [c_int32] * 4 + [c_void_p] * 3
+    lib.pdepth_inverse_warp_f32.argtypes = [c_void_p] * 4 + [c_int32] * 5 + [c_void_p] * 3
+    lib.pdepth_inverse_warp_backward_f32.argtypes = [c_void_p] * 5 + [c_int32] * 5 + [c_void_p] * 3
     for fn in ("pdepth_sweep_cost_f32", "pdepth_sweep_dpv_f32", "pdepth_dpv_reduce_f32",
                "pdepth_dpv_expect_f32", "pdepth_warp_feature_f32", "pdepth_sample_coords_f32",
                "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32", "pdepth_inverse_warp_f32",
@@ -541,7 +542,10 @@ def correlation_backward(x1, x2, grad_out, pad_size, kernel_size, max_displaceme
     return g1, g2
 
 
-def inverse_warp(img, depth, Kinv, proj):
+SAMPLE_MODES = {"bilinear": 0, "nearest": 1}
+
+
+def inverse_warp(img, depth, Kinv, proj, mode="bilinear"):
     """img [B,C,H,W], depth [B,H,W], Kinv [B,3,3], proj [B,3,4] -> (warped [B,C,H,W], valid bool [B,H,W])."""
     lib = load()
     _dev(img, "img")
@@ -553,6 +557,24 @@ def inverse_warp(img, depth, Kinv, proj):
     valid = torch.empty((B, H, W), dtype=torch.uint8, device=img.device)
     with torch.cuda.device(img.device):
         rc = lib.pdepth_inverse_warp_f32(_dev(img, "img"), _dev(depth, "depth"), _dev(Kinv, "Kinv"), _dev(proj, "proj"),
-                                         B, C, H, W, out.data_ptr(), valid.data_ptr(), _stream(img.device))
+                                         B, C, H, W, SAMPLE_MODES[mode], out.data_ptr(), valid.data_ptr(), _stream(img.device))
     _check(rc, lib)
     return out, valid.bool()
+
+
+def inverse_warp_backward(img, depth, Kinv, proj, grad_out, mode="bilinear", want_img=True, want_point=True):
+    """-> (grad_img [B,C,H,W] | None, grad_point [B,3,H,W] | None): pdepth_inverse_warp_backward_f32."""
+    lib = load()
+    img, depth, Kinv, proj, grad_out = (t.contiguous() for t in (img, depth, Kinv, proj, grad_out))
+    B, C, H, W = img.shape
+    if tuple(grad_out.shape) != (B, C, H, W):
+        raise RuntimeError("inverse_warp_backward: grad_out must have the shape of img")
+    g_img = torch.empty_like(img) if want_img else None
+    g_pt = torch.empty((B, 3, H, W), dtype=torch.float32, device=img.device) if want_point else None
+    with torch.cuda.device(img.device):
+        rc = lib.pdepth_inverse_warp_backward_f32(_dev(img, "img"), _dev(depth, "depth"), _dev(Kinv, "Kinv"), _dev(proj, "proj"),
+                                                  _dev(grad_out, "grad_out"), B, C, H, W, SAMPLE_MODES[mode],
+                                                  g_img.data_ptr() if want_img else None,
+                                                  g_pt.data_ptr() if want_point else None, _stream(img.device))
+    _check(rc, lib)
+    return g_img, g_pt

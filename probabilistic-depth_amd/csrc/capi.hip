@@ -312,11 +312,24 @@ int pdepth_correlation_backward_f32(const float* input1, const float* input2, co
 }
 
 int pdepth_inverse_warp_f32(const float* img, const float* depth, const float* Kinv, const float* proj, int32_t B,
-                            int32_t C, int32_t H, int32_t W, float* out, uint8_t* valid, void* stream) {
+                            int32_t C, int32_t H, int32_t W, int32_t mode, float* out, uint8_t* valid, void* stream) {
     if (!img || !depth || !Kinv || !proj || !out) return fail(PDEPTH_E_ARG, "pdepth_inverse_warp_f32: null pointer");
     if (B <= 0 || C <= 0 || H <= 1 || W <= 1) return fail(PDEPTH_E_ARG, "pdepth_inverse_warp_f32: bad dimension");
-    return launched(pdepth::launch_inverse_warp(img, depth, Kinv, proj, B, C, H, W, out, valid, (hipStream_t)stream),
+    if (mode != PDEPTH_SAMPLE_BILINEAR && mode != PDEPTH_SAMPLE_NEAREST) return fail(PDEPTH_E_ARG, "pdepth_inverse_warp_f32: unknown mode %d", mode);
+    return launched(pdepth::launch_inverse_warp(img, depth, Kinv, proj, B, C, H, W, mode, out, valid, (hipStream_t)stream),
                     "pdepth_inverse_warp_f32");
+}
+
+int pdepth_inverse_warp_backward_f32(const float* img, const float* depth, const float* Kinv, const float* proj,
+                                     const float* grad_out, int32_t B, int32_t C, int32_t H, int32_t W, int32_t mode,
+                                     float* grad_img, float* grad_point, void* stream) {
+    if (!img || !depth || !Kinv || !proj || !grad_out || (!grad_img && !grad_point))
+        return fail(PDEPTH_E_ARG, "pdepth_inverse_warp_backward_f32: null pointer");
+    if (B <= 0 || C <= 0 || H <= 1 || W <= 1) return fail(PDEPTH_E_ARG, "pdepth_inverse_warp_backward_f32: bad dimension");
+    if (mode != PDEPTH_SAMPLE_BILINEAR && mode != PDEPTH_SAMPLE_NEAREST)
+        return fail(PDEPTH_E_ARG, "pdepth_inverse_warp_backward_f32: unknown mode %d", mode);
+    return launched(pdepth::launch_inverse_warp_backward(img, depth, Kinv, proj, grad_out, B, C, H, W, mode, grad_img,
+                                                         grad_point, (hipStream_t)stream), "pdepth_inverse_warp_backward_f32");
 }
 
 }  // extern "C"

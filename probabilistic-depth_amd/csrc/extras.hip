@@ -336,10 +336,64 @@ hipError_t launch_correlation_backward(const float* x1, const float* x2, const f
 }
 
 // ---------------------------------------------------------------------------------------------------
-// inverse_warp forward (utils/inverse_warp.py:174-210): depth-map driven warp used by the training losses
-// (losses/loss_blocks.py:116,151).  pixel2cam (:26-40), cam2pixel (:43-69, Z clamped at 1e-3, coordinates
-// normalised with (w-1), (h-1)), then F.grid_sample with its default align_corners=False, zeros padding.
+// inverse_warp (utils/inverse_warp.py:174-210): depth-map driven warp used by the training losses
+// (losses/loss_blocks.py:116 bilinear, :151 'nearest').  pixel2cam (:26-40), cam2pixel (:43-69, Z clamped at 1e-3,
+// coordinates normalised with (w-1), (h-1)), then F.grid_sample with its default align_corners=False, zeros padding.
+// Forward: one kernel.  Backward: the same per-pixel chain re-evaluated, the image gradient scattered with atomics
+// (like ATen's grid_sampler backward) and the gradient with respect to the projected point (X, Y, Z) written per
+// pixel; the 3x3 / 3x4 algebra behind it (depth, pose, intrinsics) is a handful of small matmuls on the host side.
 // ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct WarpSample {
+    float X, Y, pz, Z;       // projected point, pz before the clamp
+    float ix, iy;            // un-normalised sample position
+    int x0, y0;              // top-left tap (clamped to [-2, size + 1])
+    float nw, ne, sw, se;    // bilinear weights
+    float w, e, n, s;
+    bool finite, xi0, xi1, yi0, yi1;
+    float xn, yn;
+};
+
+__device__ __forceinline__ WarpSample warp_sample(const float* __restrict__ ki, const float* __restrict__ pr, int x, int y,
+                                                   float d, int H, int W) {
+    WarpSample q;
+    const float fx = (float)x, fy = (float)y;
+    float cam[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        cam[i] = __builtin_fmaf(ki[i * 3 + 2], 1.0f, __builtin_fmaf(ki[i * 3 + 1], fy, ki[i * 3 + 0] * fx)) * d;
+    float pc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        pc[i] = __builtin_fmaf(pr[i * 4 + 2], cam[2], __builtin_fmaf(pr[i * 4 + 1], cam[1], pr[i * 4 + 0] * cam[0])) + pr[i * 4 + 3];
+    q.X = pc[0]; q.Y = pc[1]; q.pz = pc[2];
+    q.Z = fmaxf(pc[2], 1e-3f);
+    q.xn = 2.0f * (pc[0] / q.Z) / (float)(W - 1) - 1.0f;
+    q.yn = 2.0f * (pc[1] / q.Z) / (float)(H - 1) - 1.0f;
+    q.ix = __builtin_fmaf(q.xn + 1.0f, (float)W / 2.0f, -0.5f);
+    q.iy = __builtin_fmaf(q.yn + 1.0f, (float)H / 2.0f, -0.5f);
+    const float xf = floorf(q.ix), yf = floorf(q.iy);
+    q.w = q.ix - xf; q.e = 1.0f - q.w; q.n = q.iy - yf; q.s = 1.0f - q.n;
+    q.nw = q.s * q.e; q.ne = q.s * q.w; q.sw = q.n * q.e; q.se = q.n * q.w;
+    q.finite = (q.ix == q.ix) && (q.iy == q.iy);
+    q.x0 = (int)fminf(fmaxf(xf, -2.0f), (float)(W + 1)); q.y0 = (int)fminf(fmaxf(yf, -2.0f), (float)(H + 1));
+    q.xi0 = q.x0 >= 0 && q.x0 < W; q.xi1 = q.x0 + 1 >= 0 && q.x0 + 1 < W;
+    q.yi0 = q.y0 >= 0 && q.y0 < H; q.yi1 = q.y0 + 1 >= 0 && q.y0 + 1 < H;
+    return q;
+}
+
+// nearest tap of grid_sample(mode='nearest'): round half to even of the un-normalised position; -1 = outside / NaN
+__device__ __forceinline__ int nearest_tap(const WarpSample& q, int H, int W) {
+    if (!q.finite) return -1;
+    const float rx = rintf(q.ix), ry = rintf(q.iy);
+    if (!(rx >= 0.0f && rx < (float)W && ry >= 0.0f && ry < (float)H)) return -1;
+    return (int)ry * W + (int)rx;
+}
+
+}  // namespace
+
+template <int MODE>   // 0 bilinear, 1 nearest
 __global__ __launch_bounds__(256) void inverse_warp_kernel(const float* __restrict__ img,
                                                            const float* __restrict__ depth,
                                                            const float* __restrict__ Kinv,
@@ -350,46 +404,102 @@ __global__ __launch_bounds__(256) void inverse_warp_kernel(const float* __restri
     if (pix >= HW) return;
     const int b = blockIdx.y;
     const int y = pix / W, x = pix - y * W;
-    const float* ki = Kinv + b * 9;
-    const float* pr = proj + b * 12;
-    const float fx = (float)x, fy = (float)y, d = depth[(size_t)b * HW + pix];
-    float cam[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-        cam[i] = __builtin_fmaf(ki[i * 3 + 2], 1.0f, __builtin_fmaf(ki[i * 3 + 1], fy, ki[i * 3 + 0] * fx)) * d;
-    float pc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-        pc[i] = __builtin_fmaf(pr[i * 4 + 2], cam[2], __builtin_fmaf(pr[i * 4 + 1], cam[1], pr[i * 4 + 0] * cam[0])) + pr[i * 4 + 3];
-    const float Z = fmaxf(pc[2], 1e-3f);
-    const float xn = 2.0f * (pc[0] / Z) / (float)(W - 1) - 1.0f;
-    const float yn = 2.0f * (pc[1] / Z) / (float)(H - 1) - 1.0f;
-    if (valid) valid[(size_t)b * HW + pix] = (fmaxf(fabsf(xn), fabsf(yn)) <= 1.0f) ? 1 : 0;
-    const float ix = __builtin_fmaf(xn + 1.0f, (float)W / 2.0f, -0.5f);
-    const float iy = __builtin_fmaf(yn + 1.0f, (float)H / 2.0f, -0.5f);
-    const float xf = floorf(ix), yf = floorf(iy);
-    const float w = ix - xf, e = 1.0f - w, n = iy - yf, s = 1.0f - n;
-    const float nw = s * e, ne = s * w, sw = n * e, se = n * w;
-    const bool finite = (ix == ix) && (iy == iy);
-    const int x0 = (int)fminf(fmaxf(xf, -2.0f), (float)(W + 1)), y0 = (int)fminf(fmaxf(yf, -2.0f), (float)(H + 1));
-    const bool xi0 = x0 >= 0 && x0 < W, xi1 = x0 + 1 >= 0 && x0 + 1 < W;
-    const bool yi0 = y0 >= 0 && y0 < H, yi1 = y0 + 1 >= 0 && y0 + 1 < H;
-    const float* ib = img + (size_t)b * C * HW + (y0 * W + x0);
+    const WarpSample q = warp_sample(Kinv + b * 9, proj + b * 12, x, y, depth[(size_t)b * HW + pix], H, W);
+    if (valid) valid[(size_t)b * HW + pix] = (fmaxf(fabsf(q.xn), fabsf(q.yn)) <= 1.0f) ? 1 : 0;
     float* ob = out + (size_t)b * C * HW + pix;
+    if (MODE == 1) {
+        const int tap = nearest_tap(q, H, W);
+        for (int c = 0; c < C; ++c) ob[(size_t)c * HW] = tap >= 0 ? img[((size_t)b * C + c) * HW + tap] : 0.0f;
+        return;
+    }
+    const float* ib = img + (size_t)b * C * HW + (q.y0 * W + q.x0);
     for (int c = 0; c < C; ++c) {
         const float* p = ib + (size_t)c * HW;
-        const float v00 = (finite && xi0 && yi0) ? p[0] : 0.0f;
-        const float v01 = (finite && xi1 && yi0) ? p[1] : 0.0f;
-        const float v10 = (finite && xi0 && yi1) ? p[W] : 0.0f;
-        const float v11 = (finite && xi1 && yi1) ? p[W + 1] : 0.0f;
-        ob[(size_t)c * HW] = __builtin_fmaf(v11, se, __builtin_fmaf(v10, sw, __builtin_fmaf(v01, ne, v00 * nw)));
+        const float v00 = (q.finite && q.xi0 && q.yi0) ? p[0] : 0.0f;
+        const float v01 = (q.finite && q.xi1 && q.yi0) ? p[1] : 0.0f;
+        const float v10 = (q.finite && q.xi0 && q.yi1) ? p[W] : 0.0f;
+        const float v11 = (q.finite && q.xi1 && q.yi1) ? p[W + 1] : 0.0f;
+        ob[(size_t)c * HW] = __builtin_fmaf(v11, q.se, __builtin_fmaf(v10, q.sw, __builtin_fmaf(v01, q.ne, v00 * q.nw)));
+    }
+}
+
+// grad_img [B,C,H,W] (zeroed by the launcher, atomics; may be NULL), grad_pc [B,3,H,W] = dL/d(X, Y, Z) of the
+// projected point (zero in nearest mode, where the output does not depend on the position; may be NULL).
+template <int MODE>
+__global__ __launch_bounds__(256) void inverse_warp_bwd_kernel(const float* __restrict__ img,
+                                                               const float* __restrict__ depth,
+                                                               const float* __restrict__ Kinv,
+                                                               const float* __restrict__ proj,
+                                                               const float* __restrict__ go, int C, int H, int W,
+                                                               float* __restrict__ grad_img, float* __restrict__ grad_pc) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int HW = H * W;
+    if (pix >= HW) return;
+    const int b = blockIdx.y;
+    const int y = pix / W, x = pix - y * W;
+    const WarpSample q = warp_sample(Kinv + b * 9, proj + b * 12, x, y, depth[(size_t)b * HW + pix], H, W);
+    const float* gb = go + (size_t)b * C * HW + pix;
+    float gix = 0.0f, giy = 0.0f;
+    if (MODE == 1) {
+        const int tap = nearest_tap(q, H, W);
+        if (grad_img && tap >= 0)
+            for (int c = 0; c < C; ++c) atomicAdd(grad_img + ((size_t)b * C + c) * HW + tap, gb[(size_t)c * HW]);
+    } else {
+        const size_t base = (size_t)b * C * HW + (q.y0 * W + q.x0);
+        const bool t00 = q.finite && q.xi0 && q.yi0, t01 = q.finite && q.xi1 && q.yi0;
+        const bool t10 = q.finite && q.xi0 && q.yi1, t11 = q.finite && q.xi1 && q.yi1;
+        for (int c = 0; c < C; ++c) {
+            const float g = gb[(size_t)c * HW];
+            const float* p = img + base + (size_t)c * HW;
+            const float v00 = t00 ? p[0] : 0.0f, v01 = t01 ? p[1] : 0.0f, v10 = t10 ? p[W] : 0.0f, v11 = t11 ? p[W + 1] : 0.0f;
+            // d out / d ix = (v01 - v00) s + (v11 - v10) n,  d out / d iy = (v10 - v00) e + (v11 - v01) w
+            gix = __builtin_fmaf(g, __builtin_fmaf(v11 - v10, q.n, (v01 - v00) * q.s), gix);
+            giy = __builtin_fmaf(g, __builtin_fmaf(v11 - v01, q.w, (v10 - v00) * q.e), giy);
+            if (grad_img) {
+                float* gi = grad_img + base + (size_t)c * HW;
+                if (t00) atomicAdd(gi, g * q.nw);
+                if (t01) atomicAdd(gi + 1, g * q.ne);
+                if (t10) atomicAdd(gi + W, g * q.sw);
+                if (t11) atomicAdd(gi + W + 1, g * q.se);
+            }
+        }
+    }
+    if (grad_pc) {
+        // ix = ((xn + 1) W - 1) / 2, xn = 2 (X / Z) / (W - 1) - 1, Z = max(pz, 1e-3) (clamp passes the gradient for pz >= 1e-3)
+        float gX = 0.0f, gY = 0.0f, gZ = 0.0f;
+        if (MODE == 0 && q.finite) {
+            const float gxn = gix * ((float)W / 2.0f), gyn = giy * ((float)H / 2.0f);
+            gX = gxn * 2.0f / ((float)(W - 1) * q.Z);
+            gY = gyn * 2.0f / ((float)(H - 1) * q.Z);
+            if (q.pz >= 1e-3f) gZ = -(gX * q.X + gY * q.Y) / q.Z;
+        }
+        float* o = grad_pc + (size_t)b * 3 * HW + pix;
+        o[0] = gX; o[HW] = gY; o[2 * (size_t)HW] = gZ;
     }
 }
 
 hipError_t launch_inverse_warp(const float* img, const float* depth, const float* Kinv, const float* proj, int B,
-                               int C, int H, int W, float* out, unsigned char* valid, hipStream_t stream) {
+                               int C, int H, int W, int mode, float* out, unsigned char* valid, hipStream_t stream) {
     dim3 grid((H * W + 255) / 256, B);
-    hipLaunchKernelGGL(inverse_warp_kernel, grid, dim3(256), 0, stream, img, depth, Kinv, proj, C, H, W, out, valid);
+    if (mode == 0)
+        hipLaunchKernelGGL(inverse_warp_kernel<0>, grid, dim3(256), 0, stream, img, depth, Kinv, proj, C, H, W, out, valid);
+    else
+        hipLaunchKernelGGL(inverse_warp_kernel<1>, grid, dim3(256), 0, stream, img, depth, Kinv, proj, C, H, W, out, valid);
+    return hipGetLastError();
+}
+
+hipError_t launch_inverse_warp_backward(const float* img, const float* depth, const float* Kinv, const float* proj,
+                                        const float* grad_out, int B, int C, int H, int W, int mode, float* grad_img,
+                                        float* grad_pc, hipStream_t stream) {
+    if (grad_img) {
+        hipError_t e = hipMemsetAsync(grad_img, 0, (size_t)B * C * H * W * sizeof(float), stream);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid((H * W + 255) / 256, B);
+    if (mode == 0)
+        hipLaunchKernelGGL(inverse_warp_bwd_kernel<0>, grid, dim3(256), 0, stream, img, depth, Kinv, proj, grad_out, C, H, W, grad_img, grad_pc);
+    else
+        hipLaunchKernelGGL(inverse_warp_bwd_kernel<1>, grid, dim3(256), 0, stream, img, depth, Kinv, proj, grad_out, C, H, W, grad_img, grad_pc);
     return hipGetLastError();
 }
 

@@ -86,6 +86,9 @@ int correlation_max_radius();
 hipError_t launch_correlation_backward(const float* x1, const float* x2, const float* go, int B, int C, int H, int W,
                                        int radius, int stride2, float* g1, float* g2, hipStream_t stream);
 hipError_t launch_inverse_warp(const float* img, const float* depth, const float* Kinv, const float* proj, int B,
-                               int C, int H, int W, float* out, unsigned char* valid, hipStream_t stream);
+                               int C, int H, int W, int mode, float* out, unsigned char* valid, hipStream_t stream);
+hipError_t launch_inverse_warp_backward(const float* img, const float* depth, const float* Kinv, const float* proj,
+                                        const float* grad_out, int B, int C, int H, int W, int mode, float* grad_img,
+                                        float* grad_pc, hipStream_t stream);
 
 }  // namespace pdepth

@@ -1,11 +1,13 @@
-"""Drop-in for the reference's utils/inverse_warp.py::inverse_warp (forward only).
+"""Drop-in for the reference's utils/inverse_warp.py::inverse_warp, forward and backward.
 
 Same signature and return values as utils/inverse_warp.py:174-210.  The 3x3 / 3x4 camera algebra
 (intrinsics.inverse(), pose vector -> matrix :140-156 with euler2mat :72-108 / quat2mat :110-131,
-intrinsics @ pose :200) stays in torch on the device -- a few dozen flops per batch item -- and the per-pixel
-back-projection, projection and bilinear sampling run in one HIP kernel (pdepth_inverse_warp_f32).
-The reference uses this function only in its training losses (losses/loss_blocks.py:116,151); there is no
-backward here, so tensors that require grad raise.
+intrinsics @ pose :200) stays in torch on the device -- a few dozen flops per batch item, differentiable by torch's
+own autograd -- and the per-pixel back-projection, projection and sampling run in one HIP kernel
+(pdepth_inverse_warp_f32; 'bilinear' and 'nearest', zeros padding).  The reference uses this function in its training
+losses, under autograd (losses/loss_blocks.py:116,151): when an input requires grad the call goes through
+_InverseWarpFn, whose backward is pdepth_inverse_warp_backward_f32 (image gradient by atomic scatter, gradient of the
+projected point per pixel) followed by the small products that carry it to the depth map, the pose and the intrinsics.
 """
 import torch
 
@@ -41,16 +43,56 @@ def pose_vec2mat(vec, rotation_mode="euler"):
     return torch.cat([rot, vec[:, :3].unsqueeze(-1)], dim=2)
 
 
+class _InverseWarpFn(torch.autograd.Function):
+    """(img, depth, Kinv, proj) -> (warped, valid): the HIP kernels with the chain rule of pixel2cam / cam2pixel."""
+
+    @staticmethod
+    def forward(ctx, img, depth, Kinv, proj, mode):
+        out, valid = _native.inverse_warp(img, depth, Kinv, proj, mode)
+        ctx.save_for_backward(img, depth, Kinv, proj)
+        ctx.mode = mode
+        ctx.mark_non_differentiable(valid)
+        return out, valid
+
+    @staticmethod
+    def backward(ctx, g_out, _g_valid):
+        img, depth, Kinv, proj = ctx.saved_tensors
+        need_img = ctx.needs_input_grad[0]
+        need_pt = any(ctx.needs_input_grad[1:4]) and ctx.mode == "bilinear"
+        g_img = g_depth = g_Kinv = g_proj = None
+        if need_img or need_pt:
+            g_img, g_pc = _native.inverse_warp_backward(img, depth, Kinv, proj, g_out.float(), ctx.mode,
+                                                        want_img=need_img, want_point=need_pt)
+        if need_pt:
+            B, _, H, W = img.shape
+            ys, xs = torch.meshgrid(torch.arange(H, device=img.device, dtype=torch.float32),
+                                    torch.arange(W, device=img.device, dtype=torch.float32), indexing="ij")
+            pix = torch.stack([xs, ys, torch.ones_like(xs)]).reshape(1, 3, H * W)          # (x, y, 1) per pixel
+            g_pc = g_pc.reshape(B, 3, H * W)
+            d = depth.reshape(B, 1, H * W)
+            cam0 = torch.matmul(Kinv, pix)                                                 # pixel2cam before the depth
+            g_cam = torch.matmul(proj[:, :, :3].transpose(1, 2), g_pc)
+            if ctx.needs_input_grad[1]:
+                g_depth = (g_cam * cam0).sum(1).reshape(B, H, W)
+            if ctx.needs_input_grad[2]:
+                g_Kinv = torch.matmul(g_cam * d, pix.transpose(1, 2).expand(B, -1, -1))
+            if ctx.needs_input_grad[3]:
+                g_proj = torch.cat([torch.matmul(g_pc, (cam0 * d).transpose(1, 2)), g_pc.sum(2, keepdim=True)], dim=2)
+        elif ctx.mode == "nearest":   # the output does not depend on the sample position
+            g_depth = torch.zeros_like(depth) if ctx.needs_input_grad[1] else None
+            g_Kinv = torch.zeros_like(Kinv) if ctx.needs_input_grad[2] else None
+            g_proj = torch.zeros_like(proj) if ctx.needs_input_grad[3] else None
+        return g_img, g_depth, g_Kinv, g_proj, None
+
+
 def inverse_warp(img, depth, pose, intrinsics, mode="bilinear", rotation_mode="euler", padding_mode="zeros"):
     """Inverse warp a source image to the target image plane -> (projected_img [B,C,H,W], valid_points bool [B,H,W])."""
     if depth.dim() != 3:
         raise AssertionError("wrong size for depth, expected BxHxW, got  {}".format(list(depth.size())))
     if intrinsics.dim() != 3 or intrinsics.shape[1:] != (3, 3):
         raise AssertionError("wrong size for intrinsics, expected Bx3x3, got  {}".format(list(intrinsics.size())))
-    if mode != "bilinear" or padding_mode != "zeros":
-        raise NotImplementedError("inverse_warp: the HIP path implements mode='bilinear', padding_mode='zeros'")
-    if img.requires_grad or depth.requires_grad or pose.requires_grad:
-        raise RuntimeError("inverse_warp: backward is not implemented in the HIP path (forward/eval only)")
+    if mode not in ("bilinear", "nearest") or padding_mode != "zeros":
+        raise NotImplementedError("inverse_warp: the HIP path implements mode='bilinear' | 'nearest', padding_mode='zeros'")
     if pose.shape[1] == 6:
         pose_mat = pose_vec2mat(pose, rotation_mode)
     elif pose.shape[1] == 4 and pose.shape[2] == 4:
@@ -59,4 +101,7 @@ def inverse_warp(img, depth, pose, intrinsics, mode="bilinear", rotation_mode="e
         raise RuntimeError("inverse_warp: pose must be [B,6] or [B,4,4]")
     intrinsics = intrinsics.float()
     proj = torch.matmul(intrinsics, pose_mat.float())
-    return _native.inverse_warp(img.float(), depth.float(), intrinsics.inverse(), proj)
+    Kinv = intrinsics.inverse()
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (img, depth, Kinv, proj)):
+        return _InverseWarpFn.apply(img.float(), depth.float(), Kinv, proj, mode)
+    return _native.inverse_warp(img.float(), depth.float(), Kinv, proj, mode)

@@ -205,3 +205,73 @@ def test_hip_dpv_fuse_every_depth_count_path():
         np.testing.assert_allclose(logf.cpu().numpy(), want_log.numpy(), rtol=1e-5, atol=3e-5)
         only_log = ops.dpv_fuse(logp.to(dev), dmaps.to(dev), masks.to(dev), d, var=0.3, want_fused=False)
         assert only_log[0] is None and torch.equal(only_log[1], logf)
+
+
+def _g17_case(g, mode, rot, dev=None):
+    from pdepth_amd.utils import inverse_warp as iw
+    t = lambda k: torch.from_numpy(g[k]) if dev is None else torch.from_numpy(g[k]).to(dev)
+    img, depth, pose = t("img").requires_grad_(True), t("depth").requires_grad_(True), t("pose6").requires_grad_(True)
+    return iw, img, depth, pose, t("K"), t("grad_out")
+
+
+def test_oracle_inverse_warp_backward_matches_reference_fixture():
+    """Autograd through the oracle's restatement (+ the host's pose_vec2mat) vs autograd through the reference's
+    inverse_warp (fixture g17): gradients to the image, the depth map, the 6-DoF pose and the intrinsics."""
+    g = golden("g17_inverse_warp_backward.npz")
+    for mode in ("bilinear", "nearest"):
+        for rot in ("euler", "quat"):
+            iw, img, depth, pose, K, gout = _g17_case(g, mode, rot)
+            pm = iw.pose_vec2mat(pose, rot)
+            out, valid = O.inverse_warp(img, depth, pm, K, mode)
+            (out * gout).sum().backward()
+            tag = mode + "_" + rot
+            np.testing.assert_allclose(out.detach().numpy(), g[tag + "_out"], rtol=1e-4, atol=2e-4)
+            assert (valid.numpy() != g[tag + "_valid"]).mean() < 0.01
+            np.testing.assert_allclose(img.grad.numpy(), g[tag + "_gimg"], rtol=1e-4, atol=2e-4)
+            if mode == "bilinear":
+                gd, gp = g[tag + "_gdepth"], g[tag + "_gpose"]
+                assert np.abs(depth.grad.numpy() - gd).max() <= 2e-3 * np.abs(gd).max()
+                assert np.abs(pose.grad.numpy() - gp).max() <= 2e-3 * np.abs(gp).max()
+    depth, K = torch.from_numpy(g["depth"]).requires_grad_(True), torch.from_numpy(g["K"]).requires_grad_(True)
+    p44 = torch.from_numpy(g["pose44"]).requires_grad_(True)
+    out, _ = O.inverse_warp(torch.from_numpy(g["img"]), depth, p44, K)
+    (out * torch.from_numpy(g["grad_out"])).sum().backward()
+    for got, key in ((depth.grad, "p44_gdepth"), (p44.grad, "p44_gpose"), (K.grad, "p44_gK")):
+        assert np.abs(got.numpy() - g[key]).max() <= 2e-3 * np.abs(g[key]).max(), key
+
+
+@pytest.mark.gpu
+def test_hip_inverse_warp_backward():
+    """utils.inverse_warp under autograd (the way losses/loss_blocks.py:116,151 call the reference's) against the
+    gradients autograd computes through the reference (fixture g17): image (atomic scatter), depth, pose, intrinsics."""
+    g = golden("g17_inverse_warp_backward.npz")
+    dev = torch.device("cuda")
+    for mode in ("bilinear", "nearest"):
+        for rot in ("euler", "quat"):
+            iw, img, depth, pose, K, gout = _g17_case(g, mode, rot, dev)
+            out, valid = iw.inverse_warp(img, depth, pose, K, mode, rot)
+            assert out.requires_grad and not valid.requires_grad and valid.dtype == torch.bool
+            (out * gout).sum().backward()
+            tag = mode + "_" + rot
+            np.testing.assert_allclose(out.detach().cpu().numpy(), g[tag + "_out"], rtol=1e-4, atol=2e-4, err_msg=tag)
+            assert (valid.cpu().numpy() != g[tag + "_valid"]).mean() < 0.01
+            np.testing.assert_allclose(img.grad.cpu().numpy(), g[tag + "_gimg"], rtol=1e-4, atol=3e-4, err_msg=tag)
+            gd, gp = g[tag + "_gdepth"], g[tag + "_gpose"]
+            if mode == "bilinear":
+                assert np.abs(depth.grad.cpu().numpy() - gd).max() <= 2e-3 * np.abs(gd).max(), tag
+                assert np.abs(pose.grad.cpu().numpy() - gp).max() <= 2e-3 * np.abs(gp).max(), tag
+            else:   # the reference's autograd yields exact zeros through mode='nearest'
+                assert float(depth.grad.abs().max()) == 0.0 and float(pose.grad.abs().max()) == 0.0
+    # a 4x4 pose, gradients to the intrinsics as well; the image does not require grad here
+    depth = torch.from_numpy(g["depth"]).to(dev).requires_grad_(True)
+    K = torch.from_numpy(g["K"]).to(dev).requires_grad_(True)
+    p44 = torch.from_numpy(g["pose44"]).to(dev).requires_grad_(True)
+    out, _ = iw.inverse_warp(torch.from_numpy(g["img"]).to(dev), depth, p44, K)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["p44_out"], rtol=1e-4, atol=2e-4)
+    (out * torch.from_numpy(g["grad_out"]).to(dev)).sum().backward()
+    for got, key in ((depth.grad, "p44_gdepth"), (p44.grad, "p44_gpose"), (K.grad, "p44_gK")):
+        assert np.abs(got.cpu().numpy() - g[key]).max() <= 2e-3 * np.abs(g[key]).max(), key
+    # without grad the plain kernel path is taken and gives the same forward
+    with torch.no_grad():
+        o2, _ = iw.inverse_warp(torch.from_numpy(g["img"]).to(dev), depth, p44, K)
+    assert torch.equal(o2, out.detach())
