@@ -15,7 +15,7 @@ def stats(pose, H=256, W=512, D=64, seed=2000, tw=32, th=4, B=4):
     for b in range(B):
         it = synth.make_item(seed + b, C=4, D=D, H=H, W=W, V=1, pose=pose)
         ix, iy = positions(it, 0)                       # [D, H, W]
-        for (k0, k1) in ((16, 64), (0, 64), (0, 16), (0, 8), (8, 16), (0, 4), (4, 8), (8, 12), (12, 16), (16, 32), (32, 64)):
+        for (k0, k1) in ((16, 64), (12, 64), (8, 64), (4, 64), (0, 64), (24, 64), (32, 64), (0, 16), (0, 8), (8, 16), (0, 4), (4, 8), (8, 12), (12, 16), (16, 32)):
             if k1 > D: continue
             xa = np.floor(np.minimum(ix[k0], ix[k1 - 1]) - 1e-3); xb = np.floor(np.maximum(ix[k0], ix[k1 - 1]) + 1e-3) + 1
             ya = np.floor(np.minimum(iy[k0], iy[k1 - 1]) - 1e-3); yb = np.floor(np.maximum(iy[k0], iy[k1 - 1]) + 1e-3) + 1
