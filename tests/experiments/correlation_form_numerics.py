@@ -3,7 +3,7 @@
 cost = w^T G w - 2 w.X + |r|^2  with G = Gram terms of the source cell, X = <ref pixel, source texel>.
 Run in the build container: python tests/experiments/correlation_form_numerics.py  (results quoted in DESIGN.md 3).
 """
-import sys; sys.path.insert(0,'/root/repo')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import pdepth_amd
 from pdepth_amd import synth
