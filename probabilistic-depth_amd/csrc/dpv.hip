@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256) void dpv_reduce_ex_vec4_kernel(const float* __
         const int k = g + 4 * i;
         if (k < D) {
             const float4 lp = make_float4(v[i].x - ls.x, v[i].y - ls.y, v[i].z - ls.z, v[i].w - ls.w);
-            v[i] = lp;
             const float4 p = make_float4(expf(lp.x), expf(lp.y), expf(lp.z), expf(lp.w));
+            v[i] = p;   // (kept for the variance sweep)
             if (live) {
                 if (logp) store_nt(logp + off + (size_t)k * HW, lp);
                 if (ex.prob) store_nt(ex.prob + off + (size_t)k * HW, p);
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256) void dpv_reduce_ex_vec4_kernel(const float* __
             if (k < D) {
                 const float dk = dc[k];
                 const float4 dd = make_float4(dk - e.x, dk - e.y, dk - e.z, dk - e.w);
-                var.x += (dd.x * dd.x) * expf(v[i].x); var.y += (dd.y * dd.y) * expf(v[i].y);
-                var.z += (dd.z * dd.z) * expf(v[i].z); var.w += (dd.w * dd.w) * expf(v[i].w);
+                var.x += (dd.x * dd.x) * v[i].x; var.y += (dd.y * dd.y) * v[i].y;
+                var.z += (dd.z * dd.z) * v[i].z; var.w += (dd.w * dd.w) * v[i].w;
             }
         }
 #pragma unroll
