@@ -52,6 +52,8 @@
 // ~3e-7 (direct) and ~5e-7 (band) of the largest cost of the volume, i.e. an ulp or two of the fp32 cost.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "geometry.hpp"
 #include "kernels.hpp"
 
@@ -206,18 +208,21 @@ __device__ __forceinline__ T cold_arg(size_t offset) {
 #define PDEPTH_VARIANT PDEPTH_CAT(tiled_n, PDEPTH_NSUB)
 namespace PDEPTH_VARIANT {
 
-template <int METRIC>
+// SPEC: the evaluation configuration -- D = 64 planes, C = 67 channels, one source view -- as compile-time constants
+// (loop bounds, the chunk count, the LDS carve-up and the view loop fold; the shape of the image stays a run-time value).
+template <int METRIC, bool SPEC>
 __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a, const float4* __restrict__ packed,
                                                               int* __restrict__ tile_flags, int* __restrict__ queue,
                                                               int tiles_x, int ntile) {
+    const int aD = SPEC ? 64 : a.D, aC = SPEC ? 67 : a.C, aV = SPEC ? 1 : a.V;
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
     float4* win = lds4;                                   // [NBUF][NTEX_MAX]
     float* reft = reinterpret_cast<float*>(lds4 + NBUF * NTEX_MAX);  // [NBUF][NSUB][4 channels][64 pixels]
     float* costs_all = reft + NBUF * NSUB * 256;          // [NSUB][D][64]
-    float* red_all = costs_all + (size_t)NSUB * a.D * 64; // [NSUB][NPG][64]
+    float* red_all = costs_all + (size_t)NSUB * aD * 64; // [NSUB][NPG][64]
     float* dcl = red_all + NW * 64;                       // [D] depth candidates (read wave-uniformly, per plane)
-    float* dlo = dcl + a.D;                               // [D/16 + 1] min of d_candi[16 j .. D)
-    float* dhi = dlo + (a.D / 16 + 1);                    // [D/16 + 1] max of d_candi[16 j .. D)
+    float* dlo = dcl + aD;                               // [D/16 + 1] min of d_candi[16 j .. D)
+    float* dhi = dlo + (aD / 16 + 1);                    // [D/16 + 1] max of d_candi[16 j .. D)
     __shared__ int s_bbox[2][NW][4];   // per-wave bounding boxes of window_of(), double buffered by call parity
     __shared__ int s_dec[2][NW][8];    // per-wave band-decision values (NSUB > 1: the sub-tiles see different pixels)
     __shared__ int s_item[2];          // work item of this block: current / prefetched next
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform
     const int sub = wave / NPG;      // sub-tile of this wave
     const int pgl = wave % NPG;      // plane group of this wave within its sub-tile
-    float* costs = costs_all + (size_t)sub * a.D * 64;    // [D][64] of this sub-tile
+    float* costs = costs_all + (size_t)sub * aD * 64;    // [D][64] of this sub-tile
     float* red = red_all + sub * NPG * 64;                // [NPG][64] of this sub-tile
     const int lane = tid & 63;       // pixel of the tile
     const int lx = lane & 15, ly = lane >> 4;
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     const int nitems = band_tiles * a.B;
     const bool colmajor = rr == 0 && qq % tiles_x == 0;  // the band is a whole number of tile rows
     const int HW = a.H * a.W;
-    const int nchunk = (a.C + 3) / 4;
+    const int nchunk = (aC + 3) / 4;
     const float half_w = (float)a.W / 2.0f, half_h = (float)a.H / 2.0f;
     // cost / sigma with the divide chain of geometry.hpp (bit-identical to the IEEE divide for finite operands in
     // range); non-finite costs take the real divide so that inf / NaN come out exactly as before
@@ -252,14 +257,14 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
         if (!(fabsf(v) < 1.0e30f)) q = v / sigma;
         return q;
     };
-    for (int k = tid; k < a.D; k += NT) dcl[k] = a.d_candi[k];
+    for (int k = tid; k < aD; k += NT) dcl[k] = a.d_candi[k];
     __syncthreads();
     {   // suffix min / max of the depth candidates per 16 planes: one wave, 16 lanes per segment
-        const int nseg = a.D / 16 + 1;
+        const int nseg = aD / 16 + 1;
         if (tid < 64) {
             for (int s0 = 0; s0 < nseg; s0 += 4) {
                 const int seg = s0 + (tid >> 4), k = seg * 16 + (tid & 15);
-                float lo = (seg < nseg && k < a.D) ? dcl[k] : INFINITY, hi = (seg < nseg && k < a.D) ? dcl[k] : -INFINITY;
+                float lo = (seg < nseg && k < aD) ? dcl[k] : INFINITY, hi = (seg < nseg && k < aD) ? dcl[k] : -INFINITY;
 #pragma unroll
                 for (int sh = 8; sh >= 1; sh >>= 1) { lo = fminf(lo, __shfl_xor(lo, sh)); hi = fmaxf(hi, __shfl_xor(hi, sh)); }
                 if ((tid & 15) == 0 && seg < nseg) { red_all[seg] = lo; red_all[64 + seg] = hi; }  // (free scratch here)
@@ -317,16 +322,16 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     const float r1 = a.rays[((size_t)b * 3 + 1) * HW + p];
     const float r2 = a.rays[((size_t)b * 3 + 2) * HW + p];
     const float* refb = a.ref + (size_t)b * a.ref_bstride;
-    const v4i ref_rsrc = make_rsrc(refb, a.C * HW * 4);
+    const v4i ref_rsrc = make_rsrc(refb, aC * HW * 4);
 
-    for (int v = 0; v < a.V; ++v) {
+    for (int v = 0; v < aV; ++v) {
         ViewXform xf;
-        make_view_xform(PDEPTH_COLD_ARG(const float*, K) + b * 9, PDEPTH_COLD_ARG(const float*, R) + ((size_t)b * a.V + v) * 9,
-                        PDEPTH_COLD_ARG(const float*, t) + ((size_t)b * a.V + v) * 3, a.blas_mode, xf);
+        make_view_xform(PDEPTH_COLD_ARG(const float*, K) + b * 9, PDEPTH_COLD_ARG(const float*, R) + ((size_t)b * aV + v) * 9,
+                        PDEPTH_COLD_ARG(const float*, t) + ((size_t)b * aV + v) * 3, a.blas_mode, xf);
         float t2a, t2b, t2c;
         ray_term2(xf, r0, r1, r2, t2a, t2b, t2c);
         // [C/4 + 2][H][W] float4 texels: the channel groups, then the two Gram planes of the band mode
-        const float4* srcv = packed + ((size_t)b * a.V + v) * (nchunk + 2) * HW;
+        const float4* srcv = packed + ((size_t)b * aV + v) * (nchunk + 2) * HW;
         const v4i src_rsrc = make_rsrc(srcv, (nchunk + 2) * HW * 16);
 
         // ---- band decision -------------------------------------------------------------------------
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
         // centre is crossed -- checked), and every footprint is verified against it in the combine step; a
         // violation hands the tile to the gather kernel.  ks = first multiple of 16 whose box has at most
         // NX_MAX texels for every pixel of the tile; planes [0, ks) are evaluated directly.  L1 has no such form.
-        int ks = a.D;             // block-uniform: first plane of the band group (D: none)
+        int ks = aD;             // block-uniform: first plane of the band group (D: none)
         int bbx0 = 0, bby0 = 0;   // per pixel: top-left texel of its box
         int NC = 0, NR = 0;       // block-uniform box size
         int gwx0 = 0, gwy0 = 0, gWC = 0, gWR = 0;  // staged window of the band group
@@ -399,12 +404,12 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
             };
             // Candidates in the order of their likelihood: [16, D) first (the usual answer); [0, D) only if the box of
             // [16, D) leaves room (it contains it); later starts only if [16, D) does not fit.
-            const int k1 = a.D > 16 ? 16 : 0;
+            const int k1 = aD > 16 ? 16 : 0;
             if (trial(k1)) {
                 commit(k1);
                 if (k1 != 0 && NC * NR * 2 <= NX_MAX && trial(0)) commit(0);
             } else {
-                for (int kc = k1 + 16; kc < a.D; kc += 16)
+                for (int kc = k1 + 16; kc < aD; kc += 16)
                     if (trial(kc)) { commit(kc); break; }
             }
         }
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
                         dma_b128(src_rsrc, win_lds + (bufi * NTEX_MAX + sl * NT) * 16, so[sl], soff);
                 const int c = ch * 4 + pgl;
                 // channels beyond C: out of range => zeros (the packed source is zero padded as well)
-                dma_b32(ref_rsrc, ref_lds + bufi * (NSUB * 1024), c < a.C ? ro : 0x7fffffff, c < a.C ? c * HW * 4 : 0);
+                dma_b32(ref_rsrc, ref_lds + bufi * (NSUB * 1024), c < aC ? ro : 0x7fffffff, c < aC ? c * HW * 4 : 0);
             };
             // Iteration ch: wait until this wave's DMA of chunk ch has landed, barrier (=> every wave's part of
             // chunk ch is in LDS and every wave is done reading chunk ch-1), re-fill the buffer of chunk ch-1
@@ -635,7 +640,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
         goto tile_done;
 #endif
         // ---- band group: planes [ks, D) in correlation form --------------------------------------------
-        if (ks < a.D) {  // block-uniform
+        if (ks < aD) {  // block-uniform
             typedef const __attribute__((address_space(3))) v4f* lds_v4f;
             typedef const __attribute__((address_space(3))) float* lds_f;
             typedef __attribute__((address_space(3))) float* lds_fw;
@@ -660,7 +665,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
                         dma_b128(src_rsrc, win_lds0 + q * BAND_STAGE_BYTES + hlf * BAND_CHUNK_BYTES + wave * 1024,
                                  (feat || st == gstage) ? so : 0x7fffffff, pl * HW * 16);
                     const int c = pl * 4 + pgl;
-                    const bool rok = feat && c < a.C;
+                    const bool rok = feat && c < aC;
                     dma_b32(ref_rsrc, win_lds0 + BAND_REF_OFF + ((2 * st + hlf) % (2 * BR)) * BAND_REF_CHUNK + sub * 1024 + pgl * 256,
                             rok ? ro : 0x7fffffff, rok ? c * HW * 4 : 0);
                 }
@@ -732,7 +737,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
             // combine: wave w takes planes ks + w, ks + w + 4, ...; Gram planes (N, H, V, D1) and (D2, -, -, -)
             const int g4b = win_lds0, g1b = g4b + BAND_CHUNK_BYTES;
             int viol = 0;
-            for (int k = ks + pgl; k < a.D; k += NPG) {
+            for (int k = ks + pgl; k < aD; k += NPG) {
                 float ix, iy;
                 plane_sample_pos_fast(xf, t2a, t2b, t2c, dcl[k], cx, cy, rcx, rcy, half_w, half_h, ix, iy);
                 // footprint as in make_footprint(); "any tap inside the image" <=> x0 in [-1, W-1] and y0 in [-1, H-1]
@@ -778,17 +783,17 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     float* const cost_out = PDEPTH_COLD_ARG(float*, cost_out);
     float* const logp_out = PDEPTH_COLD_ARG(float*, logp_out);
     float* const depth_out = PDEPTH_COLD_ARG(float*, depth_out);
-    float* cout = (cost_out && live) ? cost_out + (size_t)b * a.D * HW + p : nullptr;
+    float* cout = (cost_out && live) ? cost_out + (size_t)b * aD * HW + p : nullptr;
     if (cout)
-        for (int k = pgl; k < a.D; k += NPG) cout[(size_t)k * HW] = costs[k * 64 + lane];
+        for (int k = pgl; k < aD; k += NPG) cout[(size_t)k * HW] = costs[k * 64 + lane];
     if (logp_out || depth_out) {
         // Each wave reduces its planes locally (max, then sum of exp relative to its own max); ONE exchange of
         // (max, sum) per wave through the idle reference buffers, combined by rescaling -- one barrier instead of
         // two exchange rounds with two barriers each.
         float mw = -INFINITY;
-        for (int k = pgl; k < a.D; k += NPG) mw = fmaxf(mw, costs[k * 64 + lane]);
+        for (int k = pgl; k < aD; k += NPG) mw = fmaxf(mw, costs[k * 64 + lane]);
         float sw = 0.0f;
-        for (int k = pgl; k < a.D; k += NPG) sw = sw + expf(costs[k * 64 + lane] - mw);
+        for (int k = pgl; k < aD; k += NPG) sw = sw + expf(costs[k * 64 + lane] - mw);
         float* redm = reft + sub * 512;        // [NPG][64] of this sub-tile
         float* reds = reft + sub * 512 + 256;  // [NPG][64]
         redm[pgl * 64 + lane] = mw;
@@ -802,8 +807,8 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
                         (reds[128 + lane] * expf(m2 - m) + reds[192 + lane] * expf(m3 - m));
         const float ls = logf(s);
         float e = 0.0f;
-        float* o = (logp_out && live) ? logp_out + (size_t)b * a.D * HW + p : nullptr;
-        for (int k = pgl; k < a.D; k += NPG) {
+        float* o = (logp_out && live) ? logp_out + (size_t)b * aD * HW + p : nullptr;
+        for (int k = pgl; k < aD; k += NPG) {
             const float lp = (costs[k * 64 + lane] - m) - ls;
             if (o) o[(size_t)k * HW] = lp;
             e = e + dcl[k] * expf(lp);
@@ -943,6 +948,12 @@ int sweep_device_cus() {
 #endif
 
 // Launches the pre-pass, this variant's tiled kernel, then the gather kernel on the tiles it flagged.
+// PDEPTH_NO_SPEC=1 (read once): always the general instantiation (A/B timing of the compile-time specialisation)
+static bool getenv_once_no_spec() {
+    static const bool v = [] { const char* e = getenv("PDEPTH_NO_SPEC"); return e && e[0] == '1'; }();
+    return v;
+}
+
 hipError_t PDEPTH_CAT(launch_sweep_tiled_n, PDEPTH_NSUB)(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready) {
     const int tiles16_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;  // the gather kernel's (and the flags') tiles
     const int tiles_x = (a.W + TW * NSUB - 1) / (TW * NSUB);                  // this kernel's work items per row
@@ -964,15 +975,22 @@ hipError_t PDEPTH_CAT(launch_sweep_tiled_n, PDEPTH_NSUB)(const SweepArgs& a, voi
     dim3 grid(nblk);
     // (the dynamic-LDS attribute is per kernel, sticky and the same on every device: set it whenever more than the
     //  default is needed -- no cached state, and a failure is reported instead of surfacing as a launch error)
-    if (a.metric == 0) {
-        auto kern = PDEPTH_VARIANT::sweep_tiled_kernel<0>;
+    if (a.metric == 0 && a.D == 64 && a.C == 67 && a.V == 1 && !getenv_once_no_spec()) {
+        auto kern = PDEPTH_VARIANT::sweep_tiled_kernel<0, true>;
+        if (lds > 64 * 1024) {
+            e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles);
+    } else if (a.metric == 0) {
+        auto kern = PDEPTH_VARIANT::sweep_tiled_kernel<0, false>;
         if (lds > 64 * 1024) {
             e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles);
     } else {
-        auto kern = PDEPTH_VARIANT::sweep_tiled_kernel<1>;
+        auto kern = PDEPTH_VARIANT::sweep_tiled_kernel<1, false>;
         if (lds > 64 * 1024) {
             e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
