@@ -316,18 +316,20 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
         }
     };
 
-    const float cx = a.cxcy[b * 2 + 0], cy = a.cxcy[b * 2 + 1];
+    const float* const cxcy_ = PDEPTH_COLD_ARG(const float*, cxcy);   // (per-tile arguments are re-read from the kernarg
+    const float* const rays_ = PDEPTH_COLD_ARG(const float*, rays);   //  segment instead of living in SGPRs across the tile)
+    const float cx = cxcy_[b * 2 + 0], cy = cxcy_[b * 2 + 1];
     const float rcx = refined_rcp(cx), rcy = refined_rcp(cy);
-    const float r0 = a.rays[((size_t)b * 3 + 0) * HW + p];
-    const float r1 = a.rays[((size_t)b * 3 + 1) * HW + p];
-    const float r2 = a.rays[((size_t)b * 3 + 2) * HW + p];
-    const float* refb = a.ref + (size_t)b * a.ref_bstride;
+    const float r0 = rays_[((size_t)b * 3 + 0) * HW + p];
+    const float r1 = rays_[((size_t)b * 3 + 1) * HW + p];
+    const float r2 = rays_[((size_t)b * 3 + 2) * HW + p];
+    const float* refb = PDEPTH_COLD_ARG(const float*, ref) + (size_t)b * PDEPTH_COLD_ARG(long long, ref_bstride);
     const v4i ref_rsrc = make_rsrc(refb, aC * HW * 4);
 
     for (int v = 0; v < aV; ++v) {
         ViewXform xf;
         make_view_xform(PDEPTH_COLD_ARG(const float*, K) + b * 9, PDEPTH_COLD_ARG(const float*, R) + ((size_t)b * aV + v) * 9,
-                        PDEPTH_COLD_ARG(const float*, t) + ((size_t)b * aV + v) * 3, a.blas_mode, xf);
+                        PDEPTH_COLD_ARG(const float*, t) + ((size_t)b * aV + v) * 3, PDEPTH_COLD_ARG(int, blas_mode), xf);
         float t2a, t2b, t2c;
         ray_term2(xf, r0, r1, r2, t2a, t2b, t2c);
         // [C/4 + 2][H][W] float4 texels: the channel groups, then the two Gram planes of the band mode
