@@ -98,6 +98,12 @@ constexpr int BUF_BYTES = NTEX_MAX * 16;   // one window buffer of the direct gr
 #ifndef PDEPTH_ABL_STOP
 #define PDEPTH_ABL_STOP 0
 #endif
+#ifndef PDEPTH_TRY8    // band decision: also try the band group [8, D)
+#define PDEPTH_TRY8 0
+#endif
+#ifndef PDEPTH_SHEAR   // band boxes follow the epipolar line row by row (1) or are bounding rectangles (0)
+#define PDEPTH_SHEAR 1
+#endif
 #define PDEPTH_CONF_SEL_TAPS 0
 #define PDEPTH_CONF_SEL_BANDX 0
 #define PDEPTH_CONF_SEL_GRAM 0
@@ -221,8 +227,8 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     float* costs_all = reft + NBUF * NSUB * 256;          // [NSUB][D][64]
     float* red_all = costs_all + (size_t)NSUB * aD * 64; // [NSUB][NPG][64]
     float* dcl = red_all + NW * 64;                       // [D] depth candidates (read wave-uniformly, per plane)
-    float* dlo = dcl + aD;                               // [D/16 + 1] min of d_candi[16 j .. D)
-    float* dhi = dlo + (aD / 16 + 1);                    // [D/16 + 1] max of d_candi[16 j .. D)
+    float* dlo = dcl + aD;                               // [D/8 + 1] min of d_candi[8 j .. D)
+    float* dhi = dlo + (aD / 8 + 1);                     // [D/8 + 1] max of d_candi[8 j .. D)
     __shared__ int s_bbox[2][NW][4];   // per-wave bounding boxes of window_of(), double buffered by call parity
     __shared__ int s_dec[2][NW][8];    // per-wave band-decision values (NSUB > 1: the sub-tiles see different pixels)
     __shared__ int s_item[2];          // work item of this block: current / prefetched next
@@ -259,15 +265,15 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     };
     for (int k = tid; k < aD; k += NT) dcl[k] = a.d_candi[k];
     __syncthreads();
-    {   // suffix min / max of the depth candidates per 16 planes: one wave, 16 lanes per segment
-        const int nseg = aD / 16 + 1;
+    {   // suffix min / max of the depth candidates per 8 planes: one wave, 8 lanes per segment
+        const int nseg = aD / 8 + 1;
         if (tid < 64) {
-            for (int s0 = 0; s0 < nseg; s0 += 4) {
-                const int seg = s0 + (tid >> 4), k = seg * 16 + (tid & 15);
+            for (int s0 = 0; s0 < nseg; s0 += 8) {
+                const int seg = s0 + (tid >> 3), k = seg * 8 + (tid & 7);
                 float lo = (seg < nseg && k < aD) ? dcl[k] : INFINITY, hi = (seg < nseg && k < aD) ? dcl[k] : -INFINITY;
 #pragma unroll
-                for (int sh = 8; sh >= 1; sh >>= 1) { lo = fminf(lo, __shfl_xor(lo, sh)); hi = fmaxf(hi, __shfl_xor(hi, sh)); }
-                if ((tid & 15) == 0 && seg < nseg) { red_all[seg] = lo; red_all[64 + seg] = hi; }  // (free scratch here)
+                for (int sh = 4; sh >= 1; sh >>= 1) { lo = fminf(lo, __shfl_xor(lo, sh)); hi = fmaxf(hi, __shfl_xor(hi, sh)); }
+                if ((tid & 7) == 0 && seg < nseg) { red_all[seg] = lo; red_all[64 + seg] = hi; }  // (free scratch here)
             }
         }
         __syncthreads();
@@ -351,34 +357,69 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
         int ks = aD;             // block-uniform: first plane of the band group (D: none)
         int bbx0 = 0, bby0 = 0;   // per pixel: top-left texel of its box
         int NC = 0, NR = 0;       // block-uniform box size
+        int bsh0 = 0, bsh1 = 0;   // per pixel: column offset of box row r (4 bits each, rows 0..7 / 8..15): the box is SHEARED
         int gwx0 = 0, gwy0 = 0, gWC = 0, gWR = 0;  // staged window of the band group
         if (METRIC == 0) {
-            int t_x0 = 0, t_y0 = 0, t_nc = 0, t_nr = 0, t_wx0 = 0, t_wy0 = 0, t_wc = 0, t_wr = 0;
+            int t_x0 = 0, t_y0 = 0, t_nc = 0, t_nr = 0, t_wx0 = 0, t_wy0 = 0, t_wc = 0, t_wr = 0, t_sh0 = 0, t_sh1 = 0;
             // one candidate: does the band group [kc, D) fit?  (block-uniform result; contains a barrier for NSUB > 1)
             auto trial = [&](int kc) -> bool {
-                const float dl = dlo[kc >> 4], dh = dhi[kc >> 4];
+                const float dl = dlo[kc >> 3], dh = dhi[kc >> 3];
                 float ixl, iyl, ixh, iyh;
                 plane_sample_pos_fast(xf, t2a, t2b, t2c, dl, cx, cy, rcx, rcy, half_w, half_h, ixl, iyl);
                 plane_sample_pos_fast(xf, t2a, t2b, t2c, dh, cx, cy, rcx, rcy, half_w, half_h, ixh, iyh);
                 const float denl = (xf.kt[2] + t2c * dl) + 1e-10f, denh = (xf.kt[2] + t2c * dh) + 1e-10f;
                 const float big = fmaxf(fmaxf(fabsf(ixl), fabsf(iyl)), fmaxf(fabsf(ixh), fabsf(iyh)));
-                const bool ok = denl * denh > 0.0f && big < 1.0e6f;  // false for NaN as well
+                bool ok = denl * denh > 0.0f && big < 1.0e6f;  // false for NaN as well
                 const int x0 = (int)floorf(fminf(ixl, ixh) - 1e-3f), x1 = (int)floorf(fmaxf(ixl, ixh) + 1e-3f) + 1;
                 const int y0 = (int)floorf(fminf(iyl, iyh) - 1e-3f), y1 = (int)floorf(fmaxf(iyl, iyh) + 1e-3f) + 1;
+#if PDEPTH_SHEAR
+                // Sheared box: the samples lie on the straight segment between the two end positions, so texel row
+                // y0 + r is touched only by the part of the segment with iy in [y0 + r - 1, y0 + r + 1]; its
+                // columns start at x0 + shift[r] and the box is NR rows of NC columns, NC = the widest row of any
+                // pixel -- for a diagonal epipolar line far fewer texels than the bounding rectangle.
+                int shl = 0, shh = 0, ncs = 0, xsm = x0;
+                {
+                    const float dxs = ixh - ixl, dys = iyh - iyl;
+                    const bool horiz = !(fabsf(dys) > 1e-4f);
+                    const float inv = horiz ? 0.0f : __builtin_amdgcn_rcpf(dys);
+                    const int nrw = wave_max_s(ok ? y1 - y0 + 1 : 0);
+                    bool shok = true;
+                    for (int r = 0; r < 16 && r < nrw; ++r) {
+                        const float rm = (float)(y0 + r - 1);
+                        const float ta = (rm - iyl) * inv, tb = ((rm + 2.0f) - iyl) * inv;
+                        const float lo = horiz ? 0.0f : fminf(fmaxf(fminf(ta, tb), 0.0f), 1.0f);
+                        const float hi = horiz ? 1.0f : fminf(fmaxf(fmaxf(ta, tb), 0.0f), 1.0f);
+                        const float xa = __builtin_fmaf(lo, dxs, ixl), xb = __builtin_fmaf(hi, dxs, ixl);
+                        const int cmin = max((int)floorf(fminf(xa, xb) - 1e-3f), x0);
+                        const int cmax = min((int)floorf(fmaxf(xa, xb) + 1e-3f) + 1, x1);
+                        const bool rowv = ok && y0 + r <= y1;
+                        const int sh = rowv ? cmin - x0 : 0;
+                        ncs = max(ncs, rowv ? cmax - cmin + 1 : 0);
+                        shok = shok && sh <= 15;
+                        if (r < 8) shl |= (sh & 15) << (4 * r); else shh |= (sh & 15) << (4 * (r - 8));
+                        xsm = max(xsm, rowv ? cmin : x0);
+                    }
+                    ok = ok && shok && nrw <= 16;
+                }
+                const int bw = ncs, bxs = xsm;    // width of the pixel's box, its rightmost row start
+#else
+                const int shl = 0, shh = 0;
+                const int bw = x1 - x0 + 1, bxs = x0;
+#endif
                 int nc, nr, wx0_, wy0_, wc_, wr_;
                 if (NSUB == 1) {  // every wave sees the same 64 pixels: no exchange needed
                     if (__builtin_amdgcn_ballot_w64(ok) != ~0ull) return false;  // some pixel crosses the pole / leaves the range
-                    nc = wave_max_s(x1 - x0 + 1); nr = wave_max_s(y1 - y0 + 1);
+                    nc = wave_max_s(bw); nr = wave_max_s(y1 - y0 + 1);
                     if (nc * nr > NX_MAX) return false;
                     wx0_ = wave_min_s(x0); wy0_ = wave_min_s(y0);
-                    wc_ = wave_max_s(x0) + nc - wx0_; wr_ = wave_max_s(y0) + nr - wy0_;
+                    wc_ = wave_max_s(bxs) + nc - wx0_; wr_ = wave_max_s(y0) + nr - wy0_;
                 } else {          // combine the sub-tiles through LDS (one barrier per trial, double buffered)
                     int (*sd)[8] = s_dec[dec_parity];
                     dec_parity ^= 1;
                     const int okw = __builtin_amdgcn_ballot_w64(ok) == ~0ull ? 1 : 0;
-                    const int v1 = wave_max_s(ok ? x1 - x0 + 1 : 0), v2 = wave_max_s(ok ? y1 - y0 + 1 : 0);
+                    const int v1 = wave_max_s(ok ? bw : 0), v2 = wave_max_s(ok ? y1 - y0 + 1 : 0);
                     const int v3 = wave_min_s(ok ? x0 : 0), v4 = wave_min_s(ok ? y0 : 0);
-                    const int v5 = wave_max_s(ok ? x0 : 0), v6 = wave_max_s(ok ? y0 : 0);
+                    const int v5 = wave_max_s(ok ? bxs : 0), v6 = wave_max_s(ok ? y0 : 0);
                     if (lane == 0) {
                         sd[wave][0] = okw; sd[wave][1] = v1; sd[wave][2] = v2; sd[wave][3] = v3; sd[wave][4] = v4;
                         sd[wave][5] = v5; sd[wave][6] = v6;
@@ -398,10 +439,11 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
                 }
                 if (wc_ * wr_ > BAND_TEX) return false;
                 t_x0 = x0; t_y0 = y0; t_nc = nc; t_nr = nr; t_wx0 = wx0_; t_wy0 = wy0_; t_wc = wc_; t_wr = wr_;
+                t_sh0 = shl; t_sh1 = shh;
                 return true;
             };
             auto commit = [&](int kc) {
-                ks = kc; bbx0 = t_x0; bby0 = t_y0; NC = t_nc; NR = t_nr;
+                ks = kc; bbx0 = t_x0; bby0 = t_y0; NC = t_nc; NR = t_nr; bsh0 = t_sh0; bsh1 = t_sh1;
                 gwx0 = t_wx0; gwy0 = t_wy0; gWC = t_wc; gWR = t_wr;
             };
             // Candidates in the order of their likelihood: [16, D) first (the usual answer); [0, D) only if the box of
@@ -409,7 +451,15 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
             const int k1 = aD > 16 ? 16 : 0;
             if (trial(k1)) {
                 commit(k1);
+#if PDEPTH_TRY8
+                // [8, D): half a direct group less, when the box of [16, D) leaves a third of the slots free
+                if (k1 != 0 && NC * NR * 3 <= NX_MAX * 2 && trial(8)) {
+                    commit(8);
+                    if (NC * NR * 3 <= NX_MAX * 2 && trial(0)) commit(0);
+                }
+#else
                 if (k1 != 0 && NC * NR * 2 <= NX_MAX && trial(0)) commit(0);
+#endif
             } else {
                 for (int kc = k1 + 16; kc < aD; kc += 16)
                     if (trial(kc)) { commit(kc); break; }
@@ -675,6 +725,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
             const int ndma = has_win ? 4 : 2;  // DMA instructions of this wave per stage
             // wave w accumulates the box texels j = w, w+4, w+8, ... (row-major in the NC x NR box)
             const int base = win_lds0 + ((bby0 - gwy0) * gWC + (bbx0 - gwx0)) * 16;  // this pixel's box, ring slot 0, chunk 0
+            auto row_shift = [&](int r) { return ((r < 8 ? bsh0 : bsh1) >> ((r & 7) * 4)) & 15; };  // column offset of box row r
             int xaddr[XPW];
             float xacc[XPW];
             {
@@ -682,7 +733,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
 #pragma unroll
                 for (int m = 0; m < XPW; ++m) {
                     while (jc >= NC) { jc -= NC; ++jr; }
-                    xaddr[m] = PDEPTH_CONF_ADDR(BANDX, jr < NR ? base + (jr * gWC + jc) * 16 : base, m);
+                    xaddr[m] = PDEPTH_CONF_ADDR(BANDX, jr < NR ? base + (jr * gWC + jc + row_shift(jr)) * 16 : base, m);
                     xacc[m] = 0.0f;
                     jc += NPG;
                 }
@@ -750,12 +801,19 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
                 int dx = fx0 - bbx0, dy = fy0 - bby0;
                 const bool any = live && ix == ix && iy == iy && (unsigned)(fx0 + 1) < (unsigned)(a.W + 1) &&
                                  (unsigned)(fy0 + 1) < (unsigned)(a.H + 1);
-                if (!any) { fw = fw * 0.0f; fe = fe * 0.0f; fn = fn * 0.0f; fs = fs * 0.0f; dx = 0; dy = 0; }
-                if ((unsigned)dx > (unsigned)(NC - 2) || (unsigned)dy > (unsigned)(NR - 2)) { viol = 1; dx = 0; dy = 0; }
-                const int slot = dy * NC + dx;
+                if (!any) { fw = fw * 0.0f; fe = fe * 0.0f; fn = fn * 0.0f; fs = fs * 0.0f; dy = 0; }
+                if ((unsigned)dy > (unsigned)(NR - 2)) { viol = 1; dy = 0; }
+                // the two rows of the footprint start at their own column of the sheared box
+                const unsigned shw = (unsigned)((((unsigned long long)(unsigned)bsh1 << 32) | (unsigned)bsh0) >> (dy * 4));  // one 64-bit shift
+                const int sh_t = (int)(shw & 15u), sh_b = (int)((shw >> 4) & 15u);
+                if (!any) dx = sh_t;
+                int dt = dx - sh_t, db = dx - sh_b;
+                if (!any) db = 0;
+                if ((unsigned)dt > (unsigned)(NC - 2) || (unsigned)db > (unsigned)(NC - 2)) { viol = 1; dx = sh_t; dt = 0; db = 0; }
+                const int slot = dy * NC + dt, slot_b = (dy + 1) * NC + db;
                 const int tex = PDEPTH_CONF_ADDR(GRAM, ((bby0 + dy - gwy0) * gWC + (bbx0 + dx - gwx0)) * 16, 0);
                 auto xat = [&](int j) { return *(lds_f)(size_t)(unsigned)(xb + j * 256); };
-                const float X00 = xat(slot), X01 = xat(slot + 1), X10 = xat(slot + NC), X11 = xat(slot + NC + 1);
+                const float X00 = xat(slot), X01 = xat(slot + 1), X10 = xat(slot_b), X11 = xat(slot_b + 1);
                 const v4f G00 = *(lds_v4f)(size_t)(unsigned)(g4b + tex);
                 const v4f G01 = *(lds_v4f)(size_t)(unsigned)(g4b + tex + 16);
                 const v4f G10 = *(lds_v4f)(size_t)(unsigned)(g4b + tex + gWC * 16);
@@ -889,7 +947,7 @@ __global__ __launch_bounds__(256) void pack_c4_kernel(const float* __restrict__ 
 
 static size_t tiled_lds_bytes(int D) {
     return (size_t)(NBUF * NTEX_MAX + NBUF * NSUB * 64) * sizeof(float4) + (size_t)NSUB * (D + NPG) * 64 * sizeof(float) +
-           (size_t)(D + 2 * (D / 16 + 1)) * sizeof(float);
+           (size_t)(D + 2 * (D / 8 + 1)) * sizeof(float);
 }
 
 // Largest D whose cost tile fits LDS next to the window (2 blocks per CU).
