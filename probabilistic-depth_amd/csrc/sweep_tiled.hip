@@ -98,6 +98,9 @@ constexpr int BUF_BYTES = NTEX_MAX * 16;   // one window buffer of the direct gr
 #ifndef PDEPTH_ABL_STOP
 #define PDEPTH_ABL_STOP 0
 #endif
+#ifndef PDEPTH_ABL_NOWAIT
+#define PDEPTH_ABL_NOWAIT 0
+#endif
 #ifndef PDEPTH_TRY8    // band decision: also try the band group [8, D)
 #define PDEPTH_TRY8 0
 #endif
@@ -614,7 +617,9 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
             lds_barrier();  // every reader of the previous part / super group is done with the buffers
             stage(0, 0);
             for (int ch = 0; ch < nchunk; ++ch) {
+#if !(PDEPTH_ABL_NOWAIT & 1)   // timing experiment (results wrong): direct groups do not wait for their DMA
                 wait_dma();
+#endif
                 lds_barrier();
                 if (ch + 1 < nchunk) stage((ch + 1) & 1, ch + 1);
                 {
@@ -742,7 +747,9 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
             lds_barrier();  // every reader of the previous group is done with the buffers
             for (int st = 0; st < BR - 1 && st < nstage; ++st) stage(st);
             for (int st = 0; st < nstage; ++st) {
+#if !(PDEPTH_ABL_NOWAIT & 2)   // ... the band group does not
                 wait_dma_but(ndma * min(BR - 2, nstage - 1 - st));  // stage st has landed, younger ones stay in flight
+#endif
                 lds_barrier();
                 if (st + BR - 1 < nstage) stage(st + BR - 1);  // into the slot of stage st-1
                 if (st < gstage) {
