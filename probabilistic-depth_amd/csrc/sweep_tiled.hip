@@ -104,8 +104,11 @@ constexpr int BUF_BYTES = NTEX_MAX * 16;   // one window buffer of the direct gr
 #ifndef PDEPTH_TRY8    // band decision: also try the band group [8, D)
 #define PDEPTH_TRY8 0
 #endif
-#ifndef PDEPTH_SHEAR   // band boxes follow the epipolar line row by row (1) or are bounding rectangles (0)
-#define PDEPTH_SHEAR 1
+// Band boxes follow the epipolar line row by row (1) or are bounding rectangles (0).  Only where the X slots are scarce:
+// the two-tile build has 48 per pixel, and the rectangle of planes [16, D) exceeds them in 17 % of the tiles of the
+// benchmark pose (=> twice the direct work); with 64 slots (one-tile build) the rectangle fits and the shear only costs.
+#ifndef PDEPTH_SHEAR
+#define PDEPTH_SHEAR (PDEPTH_NSUB == 2)
 #endif
 #define PDEPTH_CONF_SEL_TAPS 0
 #define PDEPTH_CONF_SEL_BANDX 0
@@ -387,7 +390,9 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
                     const float inv = horiz ? 0.0f : __builtin_amdgcn_rcpf(dys);
                     const int nrw = wave_max_s(ok ? y1 - y0 + 1 : 0);
                     bool shok = true;
-                    for (int r = 0; r < 16 && r < nrw; ++r) {
+                    const bool flat = __builtin_amdgcn_ballot_w64(ok && !horiz) == 0ull;   // every segment horizontal: plain rectangles
+                    if (flat) { ncs = x1 - x0 + 1; }
+                    for (int r = 0; r < 16 && r < nrw && !flat; ++r) {
                         const float rm = (float)(y0 + r - 1);
                         const float ta = (rm - iyl) * inv, tb = ((rm + 2.0f) - iyl) * inv;
                         const float lo = horiz ? 0.0f : fminf(fmaxf(fminf(ta, tb), 0.0f), 1.0f);
@@ -797,6 +802,8 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
             // combine: wave w takes planes ks + w, ks + w + 4, ...; Gram planes (N, H, V, D1) and (D2, -, -, -)
             const int g4b = win_lds0, g1b = g4b + BAND_CHUNK_BYTES;
             int viol = 0;
+            // (wave-uniform: rectified stereo and the image axes of a forward motion have plain rectangles and skip the shifts)
+            const bool sheared = PDEPTH_SHEAR && __builtin_amdgcn_ballot_w64((bsh0 | bsh1) != 0) != 0ull;
             for (int k = ks + pgl; k < aD; k += NPG) {
                 float ix, iy;
                 plane_sample_pos_fast(xf, t2a, t2b, t2c, dcl[k], cx, cy, rcx, rcy, half_w, half_h, ix, iy);
@@ -811,12 +818,19 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
                 if (!any) { fw = fw * 0.0f; fe = fe * 0.0f; fn = fn * 0.0f; fs = fs * 0.0f; dy = 0; }
                 if ((unsigned)dy > (unsigned)(NR - 2)) { viol = 1; dy = 0; }
                 // the two rows of the footprint start at their own column of the sheared box
-                const unsigned shw = (unsigned)((((unsigned long long)(unsigned)bsh1 << 32) | (unsigned)bsh0) >> (dy * 4));  // one 64-bit shift
-                const int sh_t = (int)(shw & 15u), sh_b = (int)((shw >> 4) & 15u);
-                if (!any) dx = sh_t;
-                int dt = dx - sh_t, db = dx - sh_b;
-                if (!any) db = 0;
-                if ((unsigned)dt > (unsigned)(NC - 2) || (unsigned)db > (unsigned)(NC - 2)) { viol = 1; dx = sh_t; dt = 0; db = 0; }
+                int dt, db;
+                if (sheared) {
+                    const unsigned shw = (unsigned)((((unsigned long long)(unsigned)bsh1 << 32) | (unsigned)bsh0) >> (dy * 4));  // one 64-bit shift
+                    const int sh_t = (int)(shw & 15u), sh_b = (int)((shw >> 4) & 15u);
+                    if (!any) dx = sh_t;
+                    dt = dx - sh_t; db = dx - sh_b;
+                    if (!any) db = 0;
+                    if ((unsigned)dt > (unsigned)(NC - 2) || (unsigned)db > (unsigned)(NC - 2)) { viol = 1; dx = sh_t; dt = 0; db = 0; }
+                } else {
+                    if (!any) dx = 0;
+                    if ((unsigned)dx > (unsigned)(NC - 2)) { viol = 1; dx = 0; }
+                    dt = dx; db = dx;
+                }
                 const int slot = dy * NC + dt, slot_b = (dy + 1) * NC + db;
                 const int tex = PDEPTH_CONF_ADDR(GRAM, ((bby0 + dy - gwy0) * gWC + (bbx0 + dx - gwx0)) * 16, 0);
                 auto xat = [&](int j) { return *(lds_f)(size_t)(unsigned)(xb + j * 256); };
