@@ -101,6 +101,12 @@ constexpr int BUF_BYTES = NTEX_MAX * 16;   // one window buffer of the direct gr
 #ifndef PDEPTH_ABL_NOWAIT
 #define PDEPTH_ABL_NOWAIT 0
 #endif
+#ifndef PDEPTH_STEAL   // blocks whose XCD band is exhausted take items of the other bands ...
+#define PDEPTH_STEAL 1
+#endif
+#ifndef PDEPTH_STEAL_ROUNDS   // ... that have more than this many rounds of their own XCD's blocks left
+#define PDEPTH_STEAL_ROUNDS 2
+#endif
 #ifndef PDEPTH_TRY8    // band decision: also try the band group [8, D)
 #define PDEPTH_TRY8 0
 #endif
@@ -253,10 +259,12 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     // workgroups are dealt round-robin over the 8 XCDs, so blocks i and i+8 share an L2.  Every XCD owns one
     // contiguous band of tiles (its own queue counter): neighbouring tiles stage overlapping source windows,
     // which then hit that XCD's L2 instead of going out to the Infinity Cache.
+    // A block whose own band is exhausted takes items of the other XCDs' bands (round robin from its own): the bands
+    // are strips of the image and do not cost the same -- in a forward motion the strips at the top and bottom see the
+    // largest disparities -- and the last item of a block would otherwise leave its CU idle for up to an item's time.
     const int xcd = blockIdx.x & 7, qq = ntile >> 3, rr = ntile & 7;
-    const int band_first = xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq;
-    const int band_tiles = qq + (xcd < rr ? 1 : 0);
-    const int nitems = band_tiles * a.B;
+    auto band_first_of = [&](int x) { return x < rr ? x * (qq + 1) : rr * (qq + 1) + (x - rr) * qq; };
+    auto band_tiles_of = [&](int x) { return qq + (x < rr ? 1 : 0); };
     const bool colmajor = rr == 0 && qq % tiles_x == 0;  // the band is a whole number of tile rows
     const int HW = a.H * a.W;
     const int nchunk = (aC + 3) / 4;
@@ -292,15 +300,17 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     }
     const int win_lds0 = (int)lds_addr_of(win);
     // work item -> batch item, tile, this lane's pixel
-    auto map_item = [&](int it, int& b_, int& tile_, bool& live_, int& p_) {
+    auto map_item = [&](int item_, int& b_, int& tile_, bool& live_, int& p_) {
+        const int qx = item_ >> 24, it = item_ & 0xffffff;   // queue (XCD band) the item came from, index in it
+        const int band_tiles = band_tiles_of(qx);
         b_ = it / band_tiles;
         const int ti = it - b_ * band_tiles;
-        tile_ = band_first + ti;
+        tile_ = band_first_of(qx) + ti;
         if (colmajor) {
             // walk the band column by column, so that the blocks in flight on one XCD share a narrow strip of
             // source columns (working set ~1 MB instead of the full image width)
             const int band_rows = qq / tiles_x;
-            tile_ = (xcd * band_rows + ti % band_rows) * tiles_x + ti / band_rows;
+            tile_ = (qx * band_rows + ti % band_rows) * tiles_x + ti / band_rows;
         }
         const int x = (tile_ % tiles_x) * (TW * NSUB) + sub * TW + lx, y = (tile_ / tiles_x) * TH + ly;
         live_ = x < a.W && y < a.H;
@@ -309,13 +319,38 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     // (when the grid already covers every item -- small problems -- block i simply takes item i of its XCD:
     //  no atomics on the critical path of a launch that is latency bound anyway)
     const bool queued = (int)gridDim.x < 8 * ((ntile + 7) / 8) * a.B;  // else: one block per item of every XCD band
+    // Next item of this block.  The atomic on the block's own queue is ISSUED at the top of a tile and its result is only
+    // looked at at the end of the tile (the latency rides under the tile's first DMA wait instead of holding wave 0,
+    // and with it the block's first barrier, for a round trip to L2).  Only when the own band is exhausted -- at the
+    // end of a launch -- the other bands are polled, and only those that have more items left than their own XCD
+    // runs blocks: the last round of a band is quicker on its own XCD (warm L2) than spread over the others.
+    const int n_own = band_tiles_of(xcd) * a.B;
+    auto steal = [&]() -> int {   // (one thread) index | queue << 24, or -1 when every band is exhausted
+#if PDEPTH_STEAL
+#pragma unroll 1
+        for (int j = 1; j < 8; ++j) {
+            const int x = (xcd + j) & 7, n = band_tiles_of(x) * a.B;
+            if (n - *(volatile int*)&queue[x] <= PDEPTH_STEAL_ROUNDS * (int)(gridDim.x >> 3)) continue;
+            const int it = atomicAdd(&queue[x], 1);
+            if (it < n) return it | (x << 24);
+        }
+#endif
+        return -1;
+    };
+    int nxt_own = n_own;   // (thread 0) result of the atomic issued at the top of the tile
+    bool own_done = false; // (thread 0) the own band is exhausted
     if (queued) {
-        if (tid == 0) s_item[0] = atomicAdd(&queue[xcd], 1);
+        if (tid == 0) {
+            const int it = atomicAdd(&queue[xcd], 1);
+            own_done = it >= n_own;
+            s_item[0] = own_done ? steal() : (it | (xcd << 24));
+        }
         __syncthreads();
     }
-    int item = queued ? s_item[0] : (int)(blockIdx.x >> 3), item_par = 0;
-    while (item < nitems) {
-    if (tid == 0) s_item[item_par ^ 1] = queued ? atomicAdd(&queue[xcd], 1) : nitems;  // next item; published by any later barrier
+    int item = __builtin_amdgcn_readfirstlane(queued ? s_item[0] : ((int)(blockIdx.x >> 3) < n_own ? (int)(blockIdx.x >> 3) | (xcd << 24) : -1));
+    int item_par = 0;
+    while (item >= 0) {
+    if (tid == 0 && queued && !own_done) nxt_own = atomicAdd(&queue[xcd], 1);
     int b, tile, p; bool live;
     map_item(item, b, tile, live, p);
     // the gather kernel's flags are per 16x4 tile: this wave's sub-tile (if it lies in the image at all)
@@ -905,9 +940,17 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     }
     }
 tile_done:
+    if (tid == 0) {   // publish the next item (the barrier below makes it visible)
+        int nx = -1;
+        if (queued) {
+            if (!own_done && nxt_own < n_own) nx = nxt_own | (xcd << 24);
+            else { own_done = true; nx = steal(); }
+        }
+        s_item[item_par ^ 1] = nx;
+    }
     __syncthreads();  // the tile's LDS state is dead, s_item of the next round is visible
     item_par ^= 1;
-    item = s_item[item_par];
+    item = __builtin_amdgcn_readfirstlane(s_item[item_par]);   // (block-uniform)
     }  // work items
 }
 
