@@ -232,7 +232,16 @@ __global__ __launch_bounds__(fast::NT, 2) void sweep_cells_fast_kernel(SweepArgs
                 incl = incl + (CELLS_DPP_I(incl, QP_SHR2) & (r >= 2 ? -1 : 0));
                 const int excl = incl - cnt;
                 const int total = CELLS_DPP_I(incl, QP_B3);   // texels per role of this pixel
-                const int tmax = max(max(total & 31, (total >> 5) & 31), max((total >> 10) & 31, (total >> 15) & 31));
+                // The 5-bit fields hold a lane's own counts (at most JS = 16) but not every quad total (up to 64, e.g. depth
+                // candidates in no particular order: every plane a new cell): the totals that decide whether the tile
+                // fits are summed in 16-bit fields, and a tile that does not fit never looks at the packed ones.
+                int tmax;
+                {
+                    int w01 = (cnt & 31) | (((cnt >> 5) & 31) << 16), w23 = ((cnt >> 10) & 31) | (((cnt >> 15) & 31) << 16);
+                    w01 += CELLS_DPP_I(w01, QP_XOR1); w23 += CELLS_DPP_I(w23, QP_XOR1);
+                    w01 += CELLS_DPP_I(w01, QP_XOR2); w23 += CELLS_DPP_I(w23, QP_XOR2);
+                    tmax = max(max(w01 & 0xffff, w01 >> 16), max(w23 & 0xffff, w23 >> 16));
+                }
                 const int mytot = (total >> (5 * r)) & 31;    // texels of this lane's role
 
                 // ---- block-wide: window of all cells; does everything fit one pass? --------------------------

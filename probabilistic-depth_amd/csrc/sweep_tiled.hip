@@ -453,7 +453,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
                 if (NSUB == 1) {  // every wave sees the same 64 pixels: no exchange needed
                     if (__builtin_amdgcn_ballot_w64(ok) != ~0ull) return false;  // some pixel crosses the pole / leaves the range
                     nc = wave_max_s(bw); nr = wave_max_s(y1 - y0 + 1);
-                    if (nc * nr > NX_MAX) return false;
+                    if (nc > NX_MAX || nr > NX_MAX || nc * nr > NX_MAX) return false;   // (each factor first: the product of two huge boxes wraps)
                     wx0_ = wave_min_s(x0); wy0_ = wave_min_s(y0);
                     wc_ = wave_max_s(bxs) + nc - wx0_; wr_ = wave_max_s(y0) + nr - wy0_;
                 } else {          // combine the sub-tiles through LDS (one barrier per trial, double buffered)
@@ -477,10 +477,10 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
                         wx0_ = min(wx0_, sd[w2][3]); wy0_ = min(wy0_, sd[w2][4]);
                         xmax = max(xmax, sd[w2][5]); ymax = max(ymax, sd[w2][6]);
                     }
-                    if (!allok || nc * nr > NX_MAX) return false;
+                    if (!allok || nc > NX_MAX || nr > NX_MAX || nc * nr > NX_MAX) return false;
                     wc_ = xmax + nc - wx0_; wr_ = ymax + nr - wy0_;
                 }
-                if (wc_ * wr_ > BAND_TEX) return false;
+                if (wc_ > BAND_TEX || wr_ > BAND_TEX || wc_ * wr_ > BAND_TEX) return false;
                 t_x0 = x0; t_y0 = y0; t_nc = nc; t_nr = nr; t_wx0 = wx0_; t_wy0 = wy0_; t_wc = wc_; t_wr = wr_;
                 t_sh0 = shl; t_sh1 = shh;
                 return true;

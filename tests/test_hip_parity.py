@@ -414,3 +414,30 @@ def test_every_sweep_implementation_on_small_ragged_shapes(dev, variant):
             ddiff = np.abs(da.cpu().numpy() - dd.cpu().numpy())[fin].max()
             assert ddiff < 1.5e-4 * max(1.0, float(np.max(b["d_candi"])) / 40.0), f"variant {variant} case {case}: depth differs by {ddiff:.2e}"
 
+
+
+def test_soak_regressions(dev):
+    """Two inputs a longer soak run (tools/soak.py, seed 31) found after the fuzz tests above had passed for two rounds.
+    (1) A source view 26 m off to the side: the band decision's box of a tile was 30 042 x 84 665 texels, the product
+        wrapped in 32 bits and passed the "at most NX_MAX slots" test.  (2) Depth candidates in no particular order:
+        every plane opens a new cell, the fast cell-list kernel's per-quad slot totals overflowed their 5-bit fields before
+        the "does it fit" test looked at them."""
+    def agree(b, algo):
+        d = to_dev(b, dev)
+        args = (d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 8.0)
+        ca = ops.sweep_cost(*args, algo=algo).cpu().numpy()
+        cd = ops.sweep_cost(*args, algo="direct").cpu().numpy()
+        assert np.array_equal(np.isnan(ca), np.isnan(cd)), algo
+        fin = np.isfinite(cd)
+        err = float(np.abs(ca - cd)[fin].max()) / max(1.0, float(np.abs(cd[fin]).max()))
+        assert err < 2e-6, f"{algo}: {err:.3e}"
+    b = synth.make_batch(5480, 1, C=22, D=83, H=195, W=286, V=3, pose="mono", cx_off=1.999560470167534, cy_off=-0.5343920453361704)
+    b["t"][0, 0] = torch.tensor([18.91592254, 18.98302991, -11.80695313])
+    for algo in ("auto", "tiled1", "cells"):
+        agree(b, algo)
+    rng = np.random.default_rng(1301)
+    for D in (64, 128):
+        b = synth.make_batch(6301, 1, C=33, D=D, H=150, W=302, V=1, pose="stereo")
+        b["d_candi"] = rng.uniform(0.5, 60.0, size=D)
+        for algo in ("cells", "auto", "tiled2" if D == 64 else "tiled1"):
+            agree(b, algo)
