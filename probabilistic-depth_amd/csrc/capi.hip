@@ -41,7 +41,7 @@ int check_desc(const pdepth_sweep_desc* d, const pdepth_camera* cam, const char*
 pdepth::SweepArgs make_args(const pdepth_sweep_desc* d, const pdepth_camera* cam, const float* ref,
                             const float* src, const float* d_candi) {
     pdepth::SweepArgs a{};
-    a.ref = ref; a.src = src;
+    a.ref = ref; a.src = src; a.packed_src = nullptr;
     a.K = cam->K; a.R = cam->R; a.t = cam->t; a.rays = cam->rays; a.cxcy = cam->cxcy;
     a.d_candi = d_candi;
     a.B = d->B; a.V = d->V; a.C = d->C; a.D = d->D; a.H = d->H; a.W = d->W;

@@ -26,6 +26,10 @@ struct SweepArgs {
     int fast_div;      // 1: shared-reciprocal divide chain (geometry.hpp), 0: compiler's IEEE divides
     float sigma;
     long long ref_bstride, src_bstride, src_vstride;
+    // the source views in the sweep kernels' staging layout ([B*V][C/4 + 2][H][W] float4, sweep_tiled.hip), set by the
+    // launchers of the tiled / cell-list paths: the gather kernel reads it for the tiles handed to it when src == nullptr
+    // (packed-source entry: the caller no longer has the NCHW source)
+    const void* packed_src;
 };
 
 // sweep_direct.hip

@@ -700,7 +700,9 @@ hipError_t launch_sweep_cells(const SweepArgs& a, void* workspace, hipStream_t s
                        fast_ok ? (const int*)redo_list : (const int*)nullptr);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_sweep_direct_flagged(a, flags, queue + GATHER_COUNT_SLOT, tiles_x, tiles, stream, 2);
+    SweepArgs ag = a;
+    ag.packed_src = packed;   // (the gather kernel's source when the caller passed a packed source only)
+    return launch_sweep_direct_flagged(ag, flags, queue + GATHER_COUNT_SLOT, tiles_x, tiles, stream, 2);
 }
 
 }  // namespace pdepth

@@ -19,7 +19,9 @@ namespace pdepth {
 // tile_flags == nullptr : block i owns pixels [64 i, 64 i + 64) of the flattened image.
 // tile_flags != nullptr : block i owns the 16 wide x 4 tall tile i and runs only if the tiled
 //                         kernel flagged that tile (sweep_tiled.hip).
-template <int METRIC, int CCH, bool MULTI_CHUNK>
+// PACKED: the taps come from the packed copy of the source (channel c of texel p = component c & 3 of float4 plane c >> 2)
+// instead of the NCHW tensor; same values, same arithmetic.
+template <int METRIC, int CCH, bool MULTI_CHUNK, bool PACKED = false>
 __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int* __restrict__ tile_flags,
                                                           const int* __restrict__ gather_count, int tiles_x, int tiles,
                                                           int flag_value) {
@@ -65,7 +67,9 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int
                         a.t + ((size_t)b * a.V + v) * 3, a.blas_mode, xf);
         float t2a, t2b, t2c;
         ray_term2(xf, r0, r1, r2, t2a, t2b, t2c);
-        const float* srcv = a.src + (size_t)b * a.src_bstride + (size_t)v * a.src_vstride;
+        const float* srcv = PACKED ? reinterpret_cast<const float*>(static_cast<const float4*>(a.packed_src) +
+                                                                    ((size_t)b * a.V + v) * ((a.C + 3) / 4 + 2) * HW)
+                                   : a.src + (size_t)b * a.src_bstride + (size_t)v * a.src_vstride;
 
         if (MULTI_CHUNK)
             for (int k = 0; k < a.D; ++k) acc[k * 64 + tid] = 0.0f;
@@ -80,16 +84,18 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int
                 float ix, iy;
                 plane_sample_pos(xf, t2a, t2b, t2c, a.d_candi[k], cx, cy, half_w, half_h, ix, iy);
                 const Footprint f = make_footprint(ix, iy, a.W, a.H);
-                const float* s00 = srcv + (size_t)c0 * HW + (f.y0 * a.W + f.x0);
+                const float* s00 = PACKED ? srcv + (size_t)(f.y0 * a.W + f.x0) * 4 : srcv + (size_t)c0 * HW + (f.y0 * a.W + f.x0);
+                constexpr int TS = PACKED ? 4 : 1;   // floats between horizontally adjacent texels
                 float part = 0.0f;
 #pragma unroll
                 for (int cc = 0; cc < CCH; ++cc) {
                     if (c0 + cc < a.C) {  // wave-uniform
-                        const float* s = s00 + (size_t)cc * HW;
+                        const int c = c0 + cc;
+                        const float* s = PACKED ? s00 + (size_t)(c >> 2) * HW * 4 + (c & 3) : s00 + (size_t)cc * HW;
                         const float vnw = (f.mask & 1u) ? s[0] : 0.0f;
-                        const float vne = (f.mask & 2u) ? s[1] : 0.0f;
-                        const float vsw = (f.mask & 4u) ? s[a.W] : 0.0f;
-                        const float vse = (f.mask & 8u) ? s[a.W + 1] : 0.0f;
+                        const float vne = (f.mask & 2u) ? s[TS] : 0.0f;
+                        const float vsw = (f.mask & 4u) ? s[a.W * TS] : 0.0f;
+                        const float vse = (f.mask & 8u) ? s[(a.W + 1) * TS] : 0.0f;
                         float val = vnw * f.nw;
                         val = __builtin_fmaf(vne, f.ne, val);
                         val = __builtin_fmaf(vsw, f.sw, val);
@@ -138,20 +144,23 @@ static hipError_t launch_metric(const SweepArgs& a, const int* tile_flags, const
                                 hipStream_t stream, int flag_value = 1) {
     const int HW = a.H * a.W;
     dim3 grid(tile_flags ? (tiles < 256 ? tiles : 256) : (HW + 63) / 64, a.B);
+    // no NCHW source (packed-source entry): the taps come from the packed copy
+    const bool packed = a.src == nullptr;
+    if (packed && a.packed_src == nullptr) return hipErrorInvalidValue;
+    auto go = [&](auto kern, size_t lds) -> hipError_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, a, tile_flags, gather_count, tiles_x, tiles, flag_value);
+        return hipGetLastError();
+    };
     if (a.C <= 68) {
         const size_t lds = (size_t)a.D * 64 * sizeof(float);
-        auto kern = sweep_direct_kernel<METRIC, 68, false>;
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, a, tile_flags, gather_count, tiles_x, tiles, flag_value);
-    } else {
-        const size_t lds = (size_t)a.D * 64 * sizeof(float) * 2;
-        auto kern = sweep_direct_kernel<METRIC, 32, true>;
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, a, tile_flags, gather_count, tiles_x, tiles, flag_value);
+        return packed ? go(sweep_direct_kernel<METRIC, 68, false, true>, lds) : go(sweep_direct_kernel<METRIC, 68, false, false>, lds);
     }
-    return hipGetLastError();
+    const size_t lds = (size_t)a.D * 64 * sizeof(float) * 2;
+    return packed ? go(sweep_direct_kernel<METRIC, 32, true, true>, lds) : go(sweep_direct_kernel<METRIC, 32, true, false>, lds);
 }
 
 hipError_t launch_sweep_direct(const SweepArgs& a, hipStream_t stream) {

@@ -1126,7 +1126,9 @@ hipError_t PDEPTH_CAT(launch_sweep_tiled_n, PDEPTH_NSUB)(const SweepArgs& a, voi
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_sweep_direct_flagged(a, flags, queue + GATHER_COUNT_SLOT, tiles16_x, tiles16_x * tiles_y, stream);
+    SweepArgs ag = a;
+    ag.packed_src = packed;   // (the gather kernel's source when the caller passed a packed source only)
+    return launch_sweep_direct_flagged(ag, flags, queue + GATHER_COUNT_SLOT, tiles16_x, tiles16_x * tiles_y, stream);
 }
 
 }  // namespace pdepth

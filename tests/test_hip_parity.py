@@ -441,3 +441,31 @@ def test_soak_regressions(dev):
         b["d_candi"] = rng.uniform(0.5, 60.0, size=D)
         for algo in ("cells", "auto", "tiled2" if D == 64 else "tiled1"):
             agree(b, algo)
+
+
+def test_packed_entry_with_gather_fallback(dev):
+    """pdepth_sweep_dpv_packed_f32 has no NCHW source to give to the gather kernel: tiles handed over (wide baseline,
+    huge translation) are evaluated from the packed copy -- same taps, same arithmetic, so the outputs are those of the
+    plain entry bit for bit.  (Found by the soak run as a GPU fault: the gather kernel dereferenced the NULL source.)"""
+    rng = np.random.default_rng(77)
+    fb_total = 0
+    for pose, C, D, H, W, V, unsorted in (("wide", 19, 96, 180, 400, 2, False), ("stereo", 33, 64, 150, 302, 1, True),
+                                          ("wide", 70, 40, 120, 260, 1, True)):
+        b = synth.make_batch(8800 + C, 2, C=C, D=D, H=H, W=W, V=V, pose=pose)
+        if unsorted:
+            b["d_candi"] = rng.uniform(0.5, 60.0, size=D)
+        d = to_dev(b, dev)
+        args = (d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 9.0)
+        for metric in ("L2", "L1"):
+            try:
+                ps = ops.pack_source(d["src"], D)
+                cp, lp, dp = ops.sweep_dpv(d["ref"], ps, *args, feat_dist=metric, want_cost=True)
+            except RuntimeError as e:   # shapes the packed entry declines (e.g. L1 with C > 68)
+                assert "packed" in str(e), str(e)
+                continue
+            fb_total += pdepth_amd._native.fallback_tiles(2, H, W)
+            ca, la, da = ops.sweep_dpv(d["ref"], d["src"], *args, feat_dist=metric, want_cost=True)
+            assert torch.equal(cp.nan_to_num(nan=-7.0), ca.nan_to_num(nan=-7.0)), (pose, metric)
+            assert torch.equal(dp.nan_to_num(nan=-7.0), da.nan_to_num(nan=-7.0)), (pose, metric)
+            assert torch.equal(lp.nan_to_num(nan=-7.0), la.nan_to_num(nan=-7.0)), (pose, metric)
+    assert fb_total > 0, "these cases are meant to exercise the gather fallback"

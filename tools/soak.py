@@ -20,7 +20,8 @@ import pdepth_amd
 from pdepth_amd import ops, synth, _native
 dev=torch.device('cuda')
 rng=np.random.default_rng(int(sys.argv[1]) if len(sys.argv)>1 else 1)
-worst=0; n=0; fb=0
+worst=0; worst_d=0; n=0; fb=0
+DPV=bool(os.environ.get('SOAK_DPV'))   # also compare the fused log-DPV / depth outputs and the packed-source entry
 only=set(int(x) for x in sys.argv[3].split(',')) if len(sys.argv)>3 else None   # replay: only these case numbers (the RNG is advanced through the others)
 force=sys.argv[4] if len(sys.argv)>4 else None   # replay: force this implementation
 for case in range(int(sys.argv[2]) if len(sys.argv)>2 else 200):
@@ -47,7 +48,26 @@ for case in range(int(sys.argv[2]) if len(sys.argv)>2 else 200):
     metric='L1' if case%7==3 else 'L2'
     if algo=='cells' and (metric=='L1' or D>128): algo='tiled1'
     if algo=='tiled2' and D>64: algo='tiled1'
+    if case%4==3 and metric=='L2' and not force: algo='auto'
     if force: algo=force
+    if DPV:   # the fused outputs too: log-DPV and expected depth of the implementation against the gather kernel's, and the packed entry
+        args=(d['ref'],d['src'],d['K'],d['R'],d['t'],d['rays'],d['cxcy'],d['d_candi'],8.0)
+        ca_,la,da=ops.sweep_dpv(*args,feat_dist=metric,algo=algo,want_cost=True)
+        cd_,ld,dd=ops.sweep_dpv(*args,feat_dist=metric,algo='direct',want_cost=True)
+        fd=torch.isfinite(dd)&torch.isfinite(da)
+        if bool((torch.isfinite(dd)!=torch.isfinite(da)).any()): print('case',case,algo,'depth finiteness differs',pose,H,W,C,D,V,B,k,metric)
+        elif bool(fd.any()):
+            dmax=float(np.max(np.abs(b['d_candi']))); de=float((da-dd)[fd].abs().max())
+            worst_d=max(worst_d,de/max(1.0,dmax/40.0))
+            if de>3e-4*max(1.0,dmax/40.0): print('case',case,'variant',algo,pose,H,W,C,D,V,B,k,metric,'depth differs by',de,'max candidate',dmax)
+        if case%5==0 and algo in ('auto','tiled1','tiled2') and metric=='L2' and C<=68:
+            try:
+                ps=ops.pack_source(d['src'],D)
+                cp,lp,dp=ops.sweep_dpv(d['ref'],ps,*args[2:],feat_dist=metric,algo='auto',want_cost=True)
+                ca2,la2,da2=ops.sweep_dpv(*args,feat_dist=metric,algo='auto',want_cost=True)
+                if not (torch.equal(cp.nan_to_num(),ca2.nan_to_num()) and torch.equal(dp.nan_to_num(),da2.nan_to_num())): print('case',case,'packed entry differs from the plain entry',pose,H,W,C,D,V,B,k)
+            except RuntimeError as e:
+                if 'packed' not in str(e): raise
     ca=ops.sweep_cost(d['ref'],d['src'],d['K'],d['R'],d['t'],d['rays'],d['cxcy'],d['d_candi'],8.0,feat_dist=metric,algo=algo).cpu().numpy(); fb+=_native.fallback_tiles(B,H,W)
     cd=ops.sweep_cost(d['ref'],d['src'],d['K'],d['R'],d['t'],d['rays'],d['cxcy'],d['d_candi'],8.0,feat_dist=metric,algo='direct').cpu().numpy()
     if not np.array_equal(np.isnan(ca),np.isnan(cd)): print('NaN pattern differs',case,pose,H,W,C,D,V,B,k,metric); continue
@@ -66,4 +86,4 @@ for case in range(int(sys.argv[2]) if len(sys.argv)>2 else 200):
                     sub=bad[0,:,ty*4:ty*4+4,tx*16:tx*16+16]
                     print('   tile',ty,tx,'bad per plane',sub.reshape(sub.shape[0],-1).sum(1).tolist())
     n+=1
-print('cases',n,'worst',worst,'fallback tiles',fb)
+print('cases',n,'worst',worst,'fallback tiles',fb,('worst depth difference (scaled) %.3e'%worst_d) if DPV else '')
