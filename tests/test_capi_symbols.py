@@ -49,6 +49,45 @@ def test_argument_validation_without_gpu():
     assert rc == 1 and b"blas_mode" in lib.pdepth_last_error()
 
 
+def test_argument_validation_of_the_round2_entries_without_gpu():
+    lib = _native.load()
+    cam = _native.Camera(1, 1, 1, 1, 1)
+    desc = _native.SweepDesc(1, 1, 4, 8, 8, 16, 0, 0, 0, 1.0, 4 * 8 * 16, 4 * 8 * 16, 4 * 8 * 16)
+    lib.pdepth_sweep_workspace_bytes.restype = ctypes.c_size_t
+    need = lib.pdepth_sweep_workspace_bytes(ctypes.byref(desc))
+    assert need > 0
+    # workspace too small / missing / misaligned
+    assert lib.pdepth_pack_source_f32(ctypes.byref(desc), 1, 256, need - 1, None) == 3 and b"workspace" in lib.pdepth_last_error()
+    assert lib.pdepth_pack_source_f32(ctypes.byref(desc), 1, None, need, None) == 3
+    assert lib.pdepth_pack_source_f32(ctypes.byref(desc), 1, 257, need, None) == 3 and b"aligned" in lib.pdepth_last_error()
+    rc = lib.pdepth_sweep_dpv_packed_f32(ctypes.byref(desc), ctypes.byref(cam), 1, 1, None, 1, 1, 256, need - 1, None)
+    assert rc == 3
+    # the gather kernel has no packed form of its own
+    direct = _native.SweepDesc(1, 1, 4, 8, 8, 16, 0, _native.ALGO_DIRECT, 0, 1.0, 512, 512, 512)
+    assert lib.pdepth_pack_source_f32(ctypes.byref(direct), 1, 256, need, None) == 1 and b"packed source" in lib.pdepth_last_error()
+    rc = lib.pdepth_sweep_dpv_packed_f32(ctypes.byref(direct), ctypes.byref(cam), 1, 1, None, 1, 1, 256, need, None)
+    assert rc == 1 and b"packed source" in lib.pdepth_last_error()
+    # cell-list kernels: L2 only
+    cells_l1 = _native.SweepDesc(1, 1, 4, 8, 8, 16, 1, _native.ALGO_CELLS, 0, 1.0, 512, 512, 512)
+    rc = lib.pdepth_sweep_dpv_f32(ctypes.byref(cells_l1), ctypes.byref(cam), 1, 1, 1, None, 1, 1, 256, need, None)
+    assert rc == 1 and b"ALGO_CELLS" in lib.pdepth_last_error()
+    # extended reduction
+    assert lib.pdepth_dpv_reduce_ex_f32(1, None, 1, 1, 4, 4, 4, None, None, None, None, None, None) == 1 and b"no output" in lib.pdepth_last_error()
+    assert lib.pdepth_dpv_reduce_ex_f32(1, None, 1, 1, 4, 2, 4, 1, None, None, None, 1, None) == 1 and b"quarter" in lib.pdepth_last_error()
+    assert lib.pdepth_dpv_reduce_ex_f32(16, None, 1, 1, 4, 4, 4, 1, 16, None, None, None, None) == 1 and b"alias" in lib.pdepth_last_error()
+    # inverse warp: sampling mode
+    rc = lib.pdepth_inverse_warp_f32(1, 1, 1, 1, 1, 3, 4, 4, 7, 1, None, None)
+    assert rc == 1 and b"unknown mode" in lib.pdepth_last_error()
+    rc = lib.pdepth_inverse_warp_backward_f32(1, 1, 1, 1, 1, 1, 3, 4, 4, 0, None, None, None)
+    assert rc == 1 and b"null pointer" in lib.pdepth_last_error()
+    # uncertainty field: workspace
+    lib.pdepth_ufield_workspace_bytes.restype = ctypes.c_size_t
+    un = lib.pdepth_ufield_workspace_bytes(1, 8, 16)
+    args = [1, 1, 1, None, 1, 4, 8, 16, 1, ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(1), ctypes.c_float(0), 0, ctypes.c_float(0), 1, 1]
+    assert lib.pdepth_ufield_f32(*args, 256, un - 1, None) == 3
+    assert lib.pdepth_ufield_f32(*args, None, un, None) == 3
+
+
 def test_host_blas_probe_is_decisive():
     """The probe must reproduce torch's CPU matmul exactly with one of the two documented modes."""
     import numpy as np
