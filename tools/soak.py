@@ -21,6 +21,7 @@ from pdepth_amd import ops, synth, _native
 dev=torch.device('cuda')
 rng=np.random.default_rng(int(sys.argv[1]) if len(sys.argv)>1 else 1)
 worst=0; worst_d=0; n=0; fb=0
+SPEC=bool(os.environ.get('SOAK_SPEC'))   # the evaluation configuration's channel / plane / view counts at random image sizes and poses
 DPV=bool(os.environ.get('SOAK_DPV'))   # also compare the fused log-DPV / depth outputs and the packed-source entry
 only=set(int(x) for x in sys.argv[3].split(',')) if len(sys.argv)>3 else None   # replay: only these case numbers (the RNG is advanced through the others)
 force=sys.argv[4] if len(sys.argv)>4 else None   # replay: force this implementation
@@ -28,6 +29,7 @@ for case in range(int(sys.argv[2]) if len(sys.argv)>2 else 200):
     algo=('tiled1','tiled2','cells')[case%3]
     H,W=int(rng.integers(2,200)),int(rng.integers(2,400)); C,D,V=int(rng.integers(1,72)),int(rng.integers(1,161)),int(rng.integers(1,4))
     B=int(rng.integers(1,3))
+    if SPEC: C,D,V=67,64,1; H,W=int(rng.integers(40,300)),int(rng.integers(100,560))   # the specialised instantiation (two-tile build from 96 k pixels)
     pose=('mono','stereo','wide','identity')[int(rng.integers(0,4))]
     cxo,cyo=float(rng.uniform(-3,3)),float(rng.uniform(-2,2))
     k=int(rng.integers(0,6))
