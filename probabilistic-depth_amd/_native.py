@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpdepth_hip.so")
 
 METRIC_L2, METRIC_L1 = 0, 1
-ALGO_AUTO, ALGO_DIRECT, ALGO_TILED_1, ALGO_TILED_2, ALGO_CELLS = 0, 1, 2, 3, 4
+ALGO_AUTO, ALGO_DIRECT, ALGO_TILED_1, ALGO_TILED_2, ALGO_CELLS, ALGO_MFMA = 0, 1, 2, 3, 4, 5
 BLAS_FMA, BLAS_SEPARATE = 0, 1
 
 # every symbol include/pdepth.h declares (tests check the library exports all of them)

@@ -55,11 +55,12 @@ pdepth::SweepArgs make_args(const pdepth_sweep_desc* d, const pdepth_camera* cam
 // (sweep_tiled.hip, default: the fastest on every BASELINE configuration but the 64x128 model-real one) or, with
 // PDEPTH_SWEEP_IMPL=cells, the cell-list kernels (sweep_cells_fast.hip + sweep_cells.hip), which make no geometric
 // assumption at all and serve as an independent second implementation in the parity suite.
-enum { IMPL_TILED = 0, IMPL_CELLS = 1 };
+enum { IMPL_DEFAULT = 0, IMPL_CELLS = 1, IMPL_TILED = 2, IMPL_MFMA = 3 };
 int sweep_impl() {
     static const int impl = [] {
         const char* f = getenv("PDEPTH_SWEEP_IMPL");
-        return (f && f[0] == 'c') ? IMPL_CELLS : IMPL_TILED;
+        if (!f) return (int)IMPL_DEFAULT;
+        return f[0] == 'c' ? (int)IMPL_CELLS : f[0] == 't' ? (int)IMPL_TILED : f[0] == 'm' ? (int)IMPL_MFMA : (int)IMPL_DEFAULT;
     }();
     return impl;
 }
@@ -92,10 +93,15 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
     if (!cost && !logp && !depth) return fail(PDEPTH_E_ARG, "%s: no output requested", who);
     if (d->metric != PDEPTH_METRIC_L2 && d->metric != PDEPTH_METRIC_L1)
         return fail(PDEPTH_E_ARG, "%s: undefined metric for feature distance (%d)", who, d->metric);
-    if (d->algo < PDEPTH_ALGO_AUTO || d->algo > PDEPTH_ALGO_CELLS)
+    if (d->algo < PDEPTH_ALGO_AUTO || d->algo > PDEPTH_ALGO_MFMA)
         return fail(PDEPTH_E_ARG, "%s: unknown algo %d", who, d->algo);
     if (d->algo == PDEPTH_ALGO_CELLS && (d->metric != PDEPTH_METRIC_L2 || d->D > pdepth::sweep_cells_max_planes()))
         return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_CELLS needs the L2 metric and D <= %d", who, pdepth::sweep_cells_max_planes());
+    if (d->algo == PDEPTH_ALGO_MFMA) {
+        const pdepth::SweepArgs probe = make_args(d, cam, ref, src, d_candi);
+        if (!pdepth::sweep_mfma_supports(probe))
+            return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_MFMA needs the L2 metric, D <= 128 and ceil(C/4) in {2, 16, 17, 18}", who);
+    }
     if (d->algo == PDEPTH_ALGO_TILED_2 && d->D > 64)
         return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_TILED_2 needs D <= 64", who);
     if (d->algo >= PDEPTH_ALGO_TILED_1 && !uses_packed_source(d))
@@ -120,6 +126,8 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
             return launched(pdepth::launch_sweep_tiled_n1(a, workspace, (hipStream_t)stream, packed_ready), who);
         if (d->algo == PDEPTH_ALGO_TILED_2)
             return launched(pdepth::launch_sweep_tiled_n2(a, workspace, (hipStream_t)stream, packed_ready), who);
+        if (d->algo == PDEPTH_ALGO_MFMA || (d->algo == PDEPTH_ALGO_AUTO && sweep_impl() == IMPL_MFMA && pdepth::sweep_mfma_supports(a)))
+            return launched(pdepth::launch_sweep_mfma(a, workspace, (hipStream_t)stream, packed_ready), who);
         // (L1 has no correlation form: always the tiled kernel)
         if (d->algo == PDEPTH_ALGO_CELLS || (d->metric == PDEPTH_METRIC_L2 && d->D <= pdepth::sweep_cells_max_planes() &&
                                              sweep_impl() == IMPL_CELLS))

@@ -51,6 +51,13 @@ hipError_t launch_sweep_tiled_n2(const SweepArgs& a, void* workspace, hipStream_
 hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t stream);          // pre-pass of both (also clears flags + queues)
 hipError_t clear_sweep_flags(const SweepArgs& a, void* workspace, hipStream_t stream);
 int sweep_device_cus();
+// workspace head shared by the packed-source kernels: tile flags (+ the 64 queue / counter ints behind them)
+size_t sweep_ws_flag_only_bytes(int B, int H, int W);
+size_t sweep_ws_flag_bytes(int B, int H, int W);
+
+// sweep_mfma.hip (L2 only; same workspace as the tiled kernel): the channel contraction on the matrix pipe
+bool sweep_mfma_supports(const SweepArgs& a);
+hipError_t launch_sweep_mfma(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false);
 
 // sweep_cells.hip (L2 only; same workspace as the tiled kernel)
 int sweep_cells_max_planes();

@@ -1,0 +1,458 @@
+// Plane sweep with the channel contraction on the matrix pipe (L2 metric): the default path of pdepth_sweep_{cost,dpv}_f32
+// for the feature widths it is instantiated for.
+//
+// Every plane is evaluated in the correlation form of the L2 distance (the band mode of sweep_tiled.hip, here for all
+// planes):
+//       sum_c (sum_t w_t s_t[c] - r[c])^2 = w^T G w - 2 sum_t w_t X_t + |r|^2,        X_t = <r, s_t>,
+// with G (Gram terms of neighbouring source texels) from the pre-pass (pack_c4_kernel, sweep_tiled.hip).  What is left
+// of the channel loop is X: one dot product per (pixel, source texel the pixel's planes touch).  For 16 neighbouring
+// reference pixels those texels overlap almost completely -- the epipolar segments of neighbours are translates of each
+// other -- so X for 16 pixels x 16 consecutive texels of a source row is a 16x16xC matrix product, and the fp32 matrix
+// instruction (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation, the vector unit's peak rate on a pipe of
+// its own) computes it from two registers per lane and 4 channels, with no LDS traffic per multiply.  About half of the
+// products are for (pixel, texel) pairs no plane samples; they cost matrix-pipe time only, which the kernel has to spare.
+//
+//   work item = one 16x4 tile of reference pixels of one batch item, ONE WAVE per item and per workgroup: no barriers
+//               between waves, nothing shared but the caches.  The wave takes the tile's four pixel rows one after the other;
+//   lanes     = in the vector phases lane (px = lane & 15, pg = lane >> 4) owns pixel px and planes k = 4 j + pg
+//               (interleaved, so any range of j keeps all lanes busy); in the matrix phase lane (n, kq) feeds texel /
+//               pixel n and channel slice kq;
+//   geometry  = bit-faithful sample positions (geometry.hpp), once per (pixel, plane, view), kept in registers;
+//   row table = for the planes of a pass: per source row the run [lo, hi] of texels any of the 16 pixels touches
+//               (LDS min/max, each lane folding its consecutive planes of equal row first), cut into blocks of 16 texels;
+//               a pass = a range of j whose runs need at most MAXB blocks: all 64 planes where that fits, otherwise the
+//               range is halved (near planes, whose segments are long, end up in passes of their own);
+//   X         = per block: texel features by buffer_load_dwordx4 from the packed source (lane (n, kq) loads 4 channels of
+//               texel n: out-of-image texels are fetched out of range and arrive as zeros = padding_mode 'zeros'),
+//               reference features of the 16 pixels held in registers for the whole pixel row, ceil(C/4) MFMAs with two
+//               blocks' accumulators interleaved; result X[texel][pixel] to LDS (16 pixels x 16 MAXB slots), the Gram
+//               records of the block's texels next to it;
+//   combine   = per (pixel, plane): 4 X values, the Gram terms of the cell and the bilinear weights, cost accumulated
+//               over views in registers;
+//   epilogue  = cost store, log-softmax over D and E[d] from registers (4 lanes per pixel, two xor-shuffles).
+//
+// A tile whose geometry does not fit (a single j -- 4 planes -- needing more than MAXB blocks or 64 source rows: extreme
+// poses) is flagged and redone by the gather kernel of sweep_direct.hip, like the tiles the other kernels hand over.
+// Agreement with the gather kernel (reference op order): an ulp or two of the largest cost of the volume, as the band mode.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+#include "geometry.hpp"
+#include "kernels.hpp"
+
+namespace pdepth {
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int MAXB = 16;               // blocks of 16 texels per pass
+constexpr int XSTRIDE = MAXB * 16 + 4; // floats per pixel of the X buffer (stride/4 odd: conflict-free b128 stores)
+constexpr int MAXROWS = 64;            // source rows per pass (one lane per row)
+constexpr int OOB = 0x7fffffff;        // buffer offset beyond every descriptor: the load returns 0
+
+__device__ __forceinline__ int opaque_v(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
+__device__ __forceinline__ float opaque_f(float x) { asm volatile("" : "+v"(x)); return x; }
+
+#define MFMA_DPP_STEP(OP, ctrl) v = OP(v, __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false))
+__device__ __forceinline__ int wave_min_i(int v) {
+    MFMA_DPP_STEP(min, 0xB1); MFMA_DPP_STEP(min, 0x4E); MFMA_DPP_STEP(min, 0x141); MFMA_DPP_STEP(min, 0x140);
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+    MFMA_DPP_STEP(max, 0xB1); MFMA_DPP_STEP(max, 0x4E); MFMA_DPP_STEP(max, 0x141); MFMA_DPP_STEP(max, 0x140);
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+#undef MFMA_DPP_STEP
+
+// Footprint of a sample position as make_footprint() (geometry.hpp) computes it, packed: (y0 << 16) | (x0 & 0xffff) of the
+// top-left texel, or NO_CELL when no tap lies inside the image (NaN positions included); fw, fn = the fractions.
+constexpr int NO_CELL = INT_MIN;
+__device__ __forceinline__ int cell_of(float ix, float iy, int W, int H, float& fw, float& fn) {
+    const float xfl = floorf(ix), yfl = floorf(iy);
+    fw = ix - xfl;
+    fn = iy - yfl;
+    const int x0 = (int)fminf(fmaxf(xfl, -2.0f), (float)(W + 1));
+    const int y0 = (int)fminf(fmaxf(yfl, -2.0f), (float)(H + 1));
+    const bool any = ix == ix && iy == iy && (unsigned)(x0 + 1) < (unsigned)(W + 1) && (unsigned)(y0 + 1) < (unsigned)(H + 1);
+    return any ? (y0 << 16) | (x0 & 0xffff) : NO_CELL;
+}
+__device__ __forceinline__ int cell_x(int xy) { return (int)(short)(xy & 0xffff); }
+__device__ __forceinline__ int cell_y(int xy) { return xy >> 16; }
+
+// NPL = packed feature planes of a source view (ceil(C / 4)); NHALF = ceil(D / 64).
+template <int NPL, int NHALF>
+__global__ __launch_bounds__(64, 2) void sweep_mfma_kernel(SweepArgs a, const float4* __restrict__ packed,
+                                                            int* __restrict__ tile_flags, int* __restrict__ queue, int tiles_x,
+                                                            int ntile) {
+    constexpr int NCH = NPL / 4, NTL = NPL % 4;   // chunks of 16 channels (4 MFMAs per 16-byte load), left-over planes of 4
+    __shared__ __attribute__((aligned(16))) float Xs[16 * XSTRIDE];   // X[pixel][slot]
+    __shared__ __attribute__((aligned(16))) float G4s[MAXB * 16 * 4]; // Gram record (N, H, V, D1) per slot
+    __shared__ float G1s[MAXB * 16];                                  // Gram D2 per slot
+    __shared__ int cmin[MAXROWS], cmax[MAXROWS];                      // per cell row: min / max x0
+    __shared__ int rowoff[MAXROWS];                                   // per texel row: slot = x + rowoff
+    __shared__ int blk[MAXB + 4];                                     // per block: (y << 16) | (x & 0xffff) of its first texel
+    __shared__ float dcl[64 * NHALF];
+
+    const int lane = threadIdx.x;
+    const int D = a.D, H = a.H, W = a.W, V = a.V, C = a.C;
+
+    // XCD-aware item order (workgroups are dealt round-robin over the 8 XCDs): every XCD owns one contiguous band of
+    // tiles, walked column by column where the band is a whole number of tile rows -- neighbouring tiles read
+    // overlapping source texels, which then hit that XCD's L2.
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, qq = ntile >> 3, rr8 = ntile & 7;
+    const int band_tiles = qq + (xcd < rr8 ? 1 : 0);
+    const int band_first = xcd < rr8 ? xcd * (qq + 1) : rr8 * (qq + 1) + (xcd - rr8) * qq;
+    if (idx >= band_tiles * a.B) return;
+    const int b = idx / band_tiles, ti = idx - b * band_tiles;
+    int tile = band_first + ti;
+    if (rr8 == 0 && qq % tiles_x == 0) {
+        const int band_rows = qq / tiles_x;
+        tile = (xcd * band_rows + ti % band_rows) * tiles_x + ti / band_rows;
+    }
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+
+    for (int k = lane; k < 64 * NHALF; k += 64) dcl[k] = a.d_candi[min(k, D - 1)];
+    __syncthreads();
+
+    const float cx = a.cxcy[b * 2 + 0], cy = a.cxcy[b * 2 + 1];
+    const float rcx = refined_rcp(cx), rcy = refined_rcp(cy);
+    const float half_w = (float)W / 2.0f, half_h = (float)H / 2.0f;
+    const float sigma = a.sigma, rsigma = refined_rcp(a.sigma);
+    // v / sigma through the divide chain of geometry.hpp (bit-identical to the IEEE divide for finite operands in range);
+    // inf / NaN (non-finite features) propagate through the plain product
+    auto div_sigma = [&](float v) { return fabsf(v) < 1.0e30f ? div_core(v, sigma, rsigma) : v * rsigma; };
+    bool failed = false;   // wave-uniform
+
+    for (int s = 0; s < 4 && !failed; ++s) {
+        const int y = ty * 4 + s;
+        if (y >= H) break;
+        // (opaque per pixel row: the optimiser otherwise hoists every lane- and HW-derived invariant of the row's phases --
+        //  masks, LDS addresses, scalar offsets -- to the top of the kernel and spills them)
+        const int n = opaque_v(lane & 15), kq = opaque_v(lane >> 4), HW = opaque_s(H * W);
+        const int x = tx * 16 + n;
+        const bool xlive = x < W;
+        const int p = y * W + min(x, W - 1);
+        const float r0 = a.rays[((size_t)b * 3 + 0) * HW + p];
+        const float r1 = a.rays[((size_t)b * 3 + 1) * HW + p];
+        const float r2 = a.rays[((size_t)b * 3 + 2) * HW + p];
+        // reference features of pixel n, channel slice kq: the B operands of every MFMA of this pixel row
+        float Rr[NPL];
+        {
+            // (buffer loads: 32-bit offsets, the channel as the scalar offset; channels beyond C are fetched out of range = 0)
+            const __amdgpu_buffer_rsrc_t rref =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(a.ref + (size_t)b * a.ref_bstride), 0, C * HW * 4, 0x00020000);
+#pragma unroll
+            for (int g = 0; g < NCH; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    Rr[4 * g + i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rref, 16 * g + 4 * kq + i < C ? (4 * kq * HW + p) * 4 : OOB, (16 * g + i) * HW * 4, 0));
+#pragma unroll
+            for (int tp = 0; tp < NTL; ++tp)
+                Rr[4 * NCH + tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rref, 4 * (4 * NCH + tp) + kq < C ? (kq * HW + p) * 4 : OOB, 4 * (4 * NCH + tp) * HW * 4, 0));
+        }
+        float rr = 0.0f;   // |r|^2 of the pixel
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) rr = __builtin_fmaf(Rr[i], Rr[i], rr);
+        rr = rr + __shfl_xor(rr, 16);
+        rr = rr + __shfl_xor(rr, 32);
+
+        float cost[NHALF * 16];
+#pragma unroll
+        for (int i = 0; i < NHALF * 16; ++i) cost[i] = 0.0f;
+
+        for (int v = 0; v < V && !failed; ++v) {
+            ViewXform xf;
+            make_view_xform(a.K + b * 9, a.R + ((size_t)b * V + v) * 9, a.t + ((size_t)b * V + v) * 3, a.blas_mode, xf);
+            float t2a, t2b, t2c;
+            ray_term2(xf, r0, r1, r2, t2a, t2b, t2c);
+            const float4* srcv = packed + ((size_t)b * V + v) * (NPL + 2) * HW;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)srcv, 0, (NPL + 2) * HW * 16, 0x00020000);
+
+#pragma unroll
+            for (int h = 0; h < NHALF; ++h) {
+                if (failed) break;
+                // ---- sample positions of this lane's 16 planes (NaN: plane beyond D or pixel beyond the image) ----------
+                int xy[16];
+                float fw[16], fn[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int k = 64 * h + 4 * j + kq;
+                    float ix, iy;
+                    plane_sample_pos_fast(xf, t2a, t2b, t2c, dcl[k], cx, cy, rcx, rcy, half_w, half_h, ix, iy);
+                    xy[j] = cell_of(ix, iy, W, H, fw[j], fn[j]);
+                    if (k >= D || !xlive) xy[j] = NO_CELL;
+                    __builtin_amdgcn_sched_barrier(0);   // (one plane at a time: the scheduler otherwise interleaves all 16 chains)
+                }
+
+                int j0 = 0, len = 16;   // current pass: j in [j0, j0 + len)
+                while (j0 < 16) {
+                    const int j1 = j0 + len;
+                    // (pinned per pass and per phase: nothing derived from the cells is carried from one phase into the next)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) xy[j] = opaque_v(xy[j]);
+                    // ---- row table -----------------------------------------------------------------------------
+                    int lmin = INT_MAX, lmax = INT_MIN;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        if (j >= j0 && j < j1 && xy[j] != NO_CELL) { lmin = min(lmin, cell_y(xy[j])); lmax = max(lmax, cell_y(xy[j])); }
+                    }
+                    const int ybase = wave_min_i(lmin), ytop = wave_max_i(lmax);
+                    int nb = 0;
+                    bool fits = true;
+                    if (ybase <= ytop) {
+                        const int ncell = ytop - ybase + 1;
+                        if (ncell + 1 > MAXROWS) {
+                            fits = false;
+                        } else {
+                            cmin[lane] = INT_MAX;
+                            cmax[lane] = INT_MIN;
+                            __syncthreads();
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) xy[j] = opaque_v(xy[j]);
+                            int run = -1, rmin = 0, rmax = 0;
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) {
+                                if (j >= j0 && j < j1 && xy[j] != NO_CELL) {
+                                    const int r = cell_y(xy[j]) - ybase, cxx = cell_x(xy[j]);
+                                    if (r != run) {
+                                        if (run >= 0) { atomicMin(&cmin[run], rmin); atomicMax(&cmax[run], rmax); }
+                                        run = r; rmin = cxx; rmax = cxx;
+                                    } else {
+                                        rmin = min(rmin, cxx); rmax = max(rmax, cxx);
+                                    }
+                                }
+                            }
+                            if (run >= 0) { atomicMin(&cmin[run], rmin); atomicMax(&cmax[run], rmax); }
+                            __syncthreads();
+                            // lane = texel row: cells of rows lane - 1 and lane touch it
+                            int lo = INT_MAX, hi = INT_MIN;
+                            if (lane < ncell) { lo = cmin[lane]; hi = cmax[lane]; }
+                            if (lane >= 1 && lane <= ncell) { lo = min(lo, cmin[lane - 1]); hi = max(hi, cmax[lane - 1]); }
+                            const int nblk = lo <= hi ? (hi - lo + 2 + 15) >> 4 : 0;   // texels lo .. hi + 1
+                            int incl = nblk;
+#pragma unroll
+                            for (int o = 1; o < 64; o <<= 1) {
+                                const int t = __shfl_up(incl, o);
+                                if (lane >= o) incl += t;
+                            }
+                            nb = __builtin_amdgcn_readlane(incl, 63);
+                            fits = nb <= MAXB;
+                            if (fits) {
+                                const int fb = incl - nblk;
+                                rowoff[lane] = 16 * fb - lo;
+                                for (int i = 0; i < nblk; ++i) blk[fb + i] = ((ybase + lane) << 16) | ((lo + 16 * i) & 0xffff);
+                                __syncthreads();
+                            }
+                        }
+                    }
+                    if (!fits) {
+                        if (len == 1) { failed = true; break; }
+                        len >>= 1;
+                        continue;
+                    }
+
+                    // ---- X = <r, s> for the blocks of the pass, on the matrix pipe -----------------------------------
+                    auto load_block = [&](int bi, v4f(&S)[NCH > 0 ? NCH : 1], float(&T)[NTL > 0 ? NTL : 1], v4f& g) {
+                        const int be = blk[bi];
+                        const int yy = be >> 16, xx = (int)(short)(be & 0xffff) + n;
+                        const bool ok = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
+                        const int t16 = (yy * W + xx) * 16;
+                        const int vo = ok ? t16 + kq * HW * 16 : OOB;
+#pragma unroll
+                        for (int gi = 0; gi < NCH; ++gi)
+                            S[gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, gi * 4 * HW * 16, 0));
+                        const int vt = ok ? t16 + kq * 4 : OOB;
+#pragma unroll
+                        for (int tp = 0; tp < NTL; ++tp)
+                            T[tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vt, (4 * NCH + tp) * HW * 16, 0));
+                        // lanes kq = 0: Gram record (N, H, V, D1) of texel n; kq = 1: (D2, 0, 0, 0)
+                        const int vg = (ok && kq < 2) ? t16 + kq * HW * 16 : OOB;
+                        g = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vg, NPL * HW * 16, 0));
+                    };
+                    auto store_block = [&](int bi, const v4f& acc, const v4f& g) {
+                        *reinterpret_cast<v4f*>(&Xs[n * XSTRIDE + 16 * bi + 4 * kq]) = acc;
+                        if (kq == 0) *reinterpret_cast<v4f*>(&G4s[(16 * bi + n) * 4]) = g;
+                        if (kq == 1) G1s[16 * bi + n] = g.x;
+                    };
+                    // one block = ceil(C/4) MFMAs in two alternating accumulator chains (a dependent f32 MFMA waits 40 cycles, an
+                    // independent one issues after 32)
+                    auto compute_block = [&](int bi, v4f(&S)[NCH > 0 ? NCH : 1], float(&T)[NTL > 0 ? NTL : 1], v4f& g) {
+                        v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int gi = 0; gi < NCH; ++gi) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(S[gi][0], Rr[4 * gi + 0], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(S[gi][1], Rr[4 * gi + 1], acc1, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(S[gi][2], Rr[4 * gi + 2], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(S[gi][3], Rr[4 * gi + 3], acc1, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int tp = 0; tp < NTL; ++tp) {
+                            if (tp & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(T[tp], Rr[4 * NCH + tp], acc1, 0, 0, 0);
+                            else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(T[tp], Rr[4 * NCH + tp], acc0, 0, 0, 0);
+                        }
+                        store_block(bi, acc0 + acc1, g);
+                    };
+                    if (nb > 0) {
+                        if (lane < 4) blk[nb + lane] = (int)0xfffe0000;   // empty blocks behind the list: loads beyond it fetch nothing
+                        __syncthreads();
+                        v4f SA[NCH > 0 ? NCH : 1], SB[NCH > 0 ? NCH : 1], SC[NCH > 0 ? NCH : 1];
+                        float TA[NTL > 0 ? NTL : 1], TB[NTL > 0 ? NTL : 1], TC[NTL > 0 ? NTL : 1];
+                        v4f gA, gB, gC;
+                        load_block(0, SA, TA, gA);
+                        load_block(1, SB, TB, gB);
+                        for (int bi = 0; bi < nb; bi += 3) {   // two blocks in flight behind the one being multiplied
+                            load_block(bi + 2, SC, TC, gC);
+                            compute_block(bi, SA, TA, gA);
+                            if (bi + 1 < nb) {
+                                load_block(bi + 3, SA, TA, gA);
+                                compute_block(bi + 1, SB, TB, gB);
+                            }
+                            if (bi + 2 < nb) {
+                                load_block(bi + 4, SB, TB, gB);
+                                compute_block(bi + 2, SC, TC, gC);
+                            }
+                        }
+                        __syncthreads();
+                    }
+
+                    // ---- combine: cost of this lane's planes of the pass ---------------------------------------------
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { xy[j] = opaque_v(xy[j]); fw[j] = opaque_f(fw[j]); fn[j] = opaque_f(fn[j]); }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        if (j >= j0 && j < j1) {
+                            float q = rr;
+                            if (xy[j] != NO_CELL) {
+                                const int r = cell_y(xy[j]) - ybase, cxx = cell_x(xy[j]);
+                                const int st = cxx + rowoff[r], sb = cxx + rowoff[r + 1];
+                                const float* xr = &Xs[n * XSTRIDE];
+                                const float X00 = xr[st], X01 = xr[st + 1], X10 = xr[sb], X11 = xr[sb + 1];
+                                const v4f G00 = *reinterpret_cast<const v4f*>(&G4s[st * 4]);
+                                const float G01x = G4s[(st + 1) * 4], G01z = G4s[(st + 1) * 4 + 2];
+                                const float G10x = G4s[sb * 4], G10y = G4s[sb * 4 + 1];
+                                const float G11x = G4s[(sb + 1) * 4];
+                                const float D2 = G1s[st];
+                                const float fe = 1.0f - fw[j], fs = 1.0f - fn[j];
+                                // |sum_t w_t s_t|^2, separable in the x weights (e, w) and the y weights (s, n) -- the
+                                // expression of sweep_tiled.hip's band combine, term for term
+                                const float ee = fe * fe, ww = fw[j] * fw[j], ew = fe * fw[j];
+                                const float A = ee * G00.x + ww * G01x + 2.0f * ew * G00.y;
+                                const float B = ee * G10x + ww * G11x + 2.0f * ew * G10y;
+                                const float Cq = ee * G00.z + ww * G01z + ew * (G00.w + D2);
+                                const float Q = (fs * fs) * A + (fn[j] * fn[j]) * B + 2.0f * (fs * fn[j]) * Cq;
+                                const float XW = (fs * fe) * X00 + (fs * fw[j]) * X01 + (fn[j] * fe) * X10 + (fn[j] * fw[j]) * X11;
+                                q = (Q - 2.0f * XW) + rr;
+                            }
+                            cost[h * 16 + j] = cost[h * 16 + j] + div_sigma(q);
+                        }
+                        if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two planes' LDS reads in flight at a time
+                    }
+                    __syncthreads();   // the tables and X of this pass are dead
+                    j0 = j1;
+                    len = min(j0 & -j0, 16 - j0);
+                }
+            }
+        }
+        if (failed) break;
+
+        // ---- epilogue: cost store, log-softmax over D, expectation ------------------------------------------------
+        // (buffer stores: one 32-bit lane offset, the plane as the scalar offset -- 64-bit per-plane pointers would be
+        //  hoisted out of the row loop and spilled)
+        const int ovoff = xlive ? (kq * HW + p) * 4 : OOB;
+        auto plane_soff = [&](int i) { return (64 * (i / 16) + 4 * (i % 16)) * HW * 4; };   // plane 64 h + 4 j (+ kq: lane offset)
+        if (a.cost_out) {
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.cost_out + (size_t)b * D * HW), 0, D * HW * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NHALF * 16; ++i)   // (planes beyond D lie beyond the descriptor: dropped)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cost[i]), rc, ovoff, plane_soff(i), 0);
+        }
+        if (a.logp_out || a.depth_out) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < NHALF * 16; ++i) {
+                const int k = 64 * (i / 16) + 4 * (i % 16) + kq;
+                if (k < D) mx = fmaxf(mx, cost[i]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            // p_k = e_k / s with e_k = exp(c_k - max): one exp per plane; log p_k = (c_k - max) - log s
+            float ssum = 0.0f, esum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NHALF * 16; ++i) {
+                const int k = 64 * (i / 16) + 4 * (i % 16) + kq;
+                const float ek = k < D ? exp_nonpos(cost[i] - mx) : 0.0f;
+                ssum = ssum + ek;
+                esum = __builtin_fmaf(dcl[k], ek, esum);
+            }
+            ssum = ssum + __shfl_xor(ssum, 16);
+            ssum = ssum + __shfl_xor(ssum, 32);
+            esum = esum + __shfl_xor(esum, 16);
+            esum = esum + __shfl_xor(esum, 32);
+            const float ls = logf(ssum);
+            if (a.logp_out) {
+                const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(a.logp_out + (size_t)b * D * HW), 0, D * HW * 4, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < NHALF * 16; ++i)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (cost[i] - mx) - ls), rl, ovoff, plane_soff(i), 0);
+            }
+            if (a.depth_out && xlive && kq == 0) a.depth_out[(size_t)b * HW + p] = esum / ssum;
+        }
+    }
+    if (failed && lane == 0) {   // the gather kernel redoes the tile
+        const int tiles_y = (H + 3) / 4;
+        tile_flags[b * tiles_x * tiles_y + ty * tiles_x + tx] = 1;
+        atomicAdd(&queue[GATHER_COUNT_SLOT], 1);
+    }
+}
+
+template <int NPL>
+hipError_t launch_npl(const SweepArgs& a, const float4* packed, int* flags, int* queue, int tiles_x, int tiles, hipStream_t stream) {
+    const long long nblk = 8ll * ((tiles + 7) / 8) * a.B;
+    if (a.D <= 64)
+        hipLaunchKernelGGL((sweep_mfma_kernel<NPL, 1>), dim3((unsigned)nblk), dim3(64), 0, stream, a, packed, flags, queue, tiles_x, tiles);
+    else
+        hipLaunchKernelGGL((sweep_mfma_kernel<NPL, 2>), dim3((unsigned)nblk), dim3(64), 0, stream, a, packed, flags, queue, tiles_x, tiles);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// shapes the matrix-pipe kernel is instantiated for: L2, D <= 128, ceil(C/4) in the list below
+bool sweep_mfma_supports(const SweepArgs& a) {
+    const int npl = (a.C + 3) / 4;
+    const long long hw = (long long)a.H * a.W;
+    return a.metric == 0 && a.D <= 128 && (npl == 17 || npl == 16 || npl == 2 || npl == 18) && a.W <= 32760 && a.H <= 32760 &&
+           hw * a.D * 4 < (1ll << 31) && hw * a.C * 4 < (1ll << 31) && hw * (npl + 2) * 16 < (1ll << 31);
+}
+
+// Launches the pre-pass (unless the workspace is already packed), the matrix-pipe kernel, then the gather kernel on the
+// tiles it flagged.  Workspace layout as the tiled kernel's.
+hipError_t launch_sweep_mfma(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready) {
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 3) / 4, tiles = tiles_x * tiles_y;
+    int* flags = reinterpret_cast<int*>(workspace);
+    float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + sweep_ws_flag_bytes(a.B, a.H, a.W));
+    int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + sweep_ws_flag_only_bytes(a.B, a.H, a.W));
+    hipError_t e = packed_ready ? clear_sweep_flags(a, workspace, stream) : launch_pack_c4(a, workspace, stream);
+    if (e != hipSuccess) return e;
+    switch ((a.C + 3) / 4) {
+        case 17: e = launch_npl<17>(a, packed, flags, queue, tiles_x, tiles, stream); break;
+        case 16: e = launch_npl<16>(a, packed, flags, queue, tiles_x, tiles, stream); break;
+        case 18: e = launch_npl<18>(a, packed, flags, queue, tiles_x, tiles, stream); break;
+        case 2: e = launch_npl<2>(a, packed, flags, queue, tiles_x, tiles, stream); break;
+        default: return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
+    SweepArgs ag = a;
+    ag.packed_src = packed;
+    return launch_sweep_direct_flagged(ag, flags, queue + GATHER_COUNT_SLOT, tiles_x, tiles, stream);
+}
+
+}  // namespace pdepth

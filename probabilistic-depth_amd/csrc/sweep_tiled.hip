@@ -1031,6 +1031,8 @@ static size_t flag_only_bytes(int B, int H, int W) {
 }
 static size_t flag_bytes(int B, int H, int W) { return flag_only_bytes(B, H, W) + 256; }
 #if PDEPTH_NSUB == 1
+size_t sweep_ws_flag_only_bytes(int B, int H, int W) { return flag_only_bytes(B, H, W); }
+size_t sweep_ws_flag_bytes(int B, int H, int W) { return flag_bytes(B, H, W); }
 size_t sweep_tiled_workspace_bytes(int B, int V, int C, int H, int W) {
     // flags + queue counters, packed source, then the list of tiles the fast cell-list kernel leaves to the generic one
     return flag_bytes(B, H, W) + (size_t)B * V * ((C + 3) / 4 + 2) * H * W * sizeof(float4) + flag_only_bytes(B, H, W);
