@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--planes", type=int, default=64)
     ap.add_argument("--views", type=int, default=1)
     ap.add_argument("--pose", default="mono", choices=["mono", "stereo"])
-    ap.add_argument("--algo", default="auto", choices=["auto", "direct", "tiled1", "tiled2", "cells"])
+    ap.add_argument("--algo", default="auto", choices=["auto", "direct", "tiled1", "tiled2", "cells", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 

@@ -48,7 +48,16 @@ namespace {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-constexpr int MAXB = 16;               // blocks of 16 texels per pass
+#ifndef MFMA_MAXB
+#define MFMA_MAXB 14
+#endif
+#ifndef MFMA_WG_PER_CU
+#define MFMA_WG_PER_CU 2
+#endif
+#ifndef MFMA_ABL_STOP   // timing experiments (results wrong): 1 = skip everything after the sample positions, 2 = after the row
+#define MFMA_ABL_STOP 0 // table, 3 = after X, 4 = after the combine (no epilogue)
+#endif
+constexpr int MAXB = MFMA_MAXB;        // blocks of 16 texels per pass (LDS: 4 waves x 19.9 KB, two workgroups per CU)
 constexpr int XSTRIDE = MAXB * 16 + 4; // floats per pixel of the X buffer (stride/4 odd: conflict-free b128 stores)
 constexpr int MAXROWS = 64;            // source rows per pass (one lane per row)
 constexpr int OOB = 0x7fffffff;        // buffer offset beyond every descriptor: the load returns 0
@@ -56,6 +65,35 @@ constexpr int OOB = 0x7fffffff;        // buffer offset beyond every descriptor:
 __device__ __forceinline__ int opaque_v(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
 __device__ __forceinline__ float opaque_f(float x) { asm volatile("" : "+v"(x)); return x; }
+
+// Diagnostic build only (-DMFMA_STAMPS, tools/dbg/mfma_stamps.py): cycles per phase and event counts, summed over waves,
+// in the spare ints behind the queue counters.  No stamp exists in the product build.
+#ifdef MFMA_STAMPS
+#define MSTAMP(idx) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); stamp_acc[idx] += now_ - stamp_t; stamp_t = now_; }
+#define MCOUNT(idx, v) { stamp_acc[idx] += (unsigned long long)(v); }
+#elif defined(MFMA_MARKS)   // phase markers in the ISA listing (tools/dbg/isa_phases.py): comments only
+#define MSTAMP(idx) asm volatile("; MARK " #idx);
+#define MCOUNT(idx, v)
+#else
+#define MSTAMP(idx)
+#define MCOUNT(idx, v)
+#endif
+
+// The waves of a workgroup share nothing: what a wave writes to its LDS region only its own lanes read.  LDS operations of
+// one wave complete in order, so "every earlier LDS operation of this wave is done" is all the synchronisation there is
+// (no s_barrier, and unlike __syncthreads() no wait for the global loads in flight).
+#define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside the rows of 16 (DPP row_shr), then the row totals
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
 
 #define MFMA_DPP_STEP(OP, ctrl) v = OP(v, __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false))
 __device__ __forceinline__ int wave_min_i(int v) {
@@ -85,79 +123,183 @@ __device__ __forceinline__ int cell_of(float ix, float iy, int W, int H, float& 
 __device__ __forceinline__ int cell_x(int xy) { return (int)(short)(xy & 0xffff); }
 __device__ __forceinline__ int cell_y(int xy) { return xy >> 16; }
 
+// LDS of one wave
+struct __attribute__((aligned(16))) WaveLds {
+    float Xs[16 * XSTRIDE];     // X[pixel][slot]
+    float G4s[MAXB * 16 * 4];   // Gram record (N, H, V, D1) per slot
+    float G1s[MAXB * 16];       // Gram D2 per slot
+    int cmin[MAXROWS], cmax[MAXROWS];   // per cell row: min / max x0
+    int rowoff[MAXROWS];        // per texel row: slot = x + rowoff
+    int blk[MAXB + 4];          // per block: (y << 16) | (x & 0xffff) of its first texel
+};
+
 // NPL = packed feature planes of a source view (ceil(C / 4)); NHALF = ceil(D / 64).
 template <int NPL, int NHALF>
-__global__ __launch_bounds__(64, 2) void sweep_mfma_kernel(SweepArgs a, const float4* __restrict__ packed,
-                                                            int* __restrict__ tile_flags, int* __restrict__ queue, int tiles_x,
-                                                            int ntile) {
+__global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const float4* __restrict__ packed,
+                                                             int* __restrict__ tile_flags, int* __restrict__ queue, int tiles_x,
+                                                             int ntile) {
     constexpr int NCH = NPL / 4, NTL = NPL % 4;   // chunks of 16 channels (4 MFMAs per 16-byte load), left-over planes of 4
-    __shared__ __attribute__((aligned(16))) float Xs[16 * XSTRIDE];   // X[pixel][slot]
-    __shared__ __attribute__((aligned(16))) float G4s[MAXB * 16 * 4]; // Gram record (N, H, V, D1) per slot
-    __shared__ float G1s[MAXB * 16];                                  // Gram D2 per slot
-    __shared__ int cmin[MAXROWS], cmax[MAXROWS];                      // per cell row: min / max x0
-    __shared__ int rowoff[MAXROWS];                                   // per texel row: slot = x + rowoff
-    __shared__ int blk[MAXB + 4];                                     // per block: (y << 16) | (x & 0xffff) of its first texel
+    __shared__ WaveLds wlds[4];
     __shared__ float dcl[64 * NHALF];
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WaveLds& L = wlds[wave];
+    float* const Xs = L.Xs; float* const G4s = L.G4s; float* const G1s = L.G1s;
+    int* const cmin = L.cmin; int* const cmax = L.cmax; int* const rowoff = L.rowoff; int* const blk = L.blk;
     const int D = a.D, H = a.H, W = a.W, V = a.V, C = a.C;
 
-    // XCD-aware item order (workgroups are dealt round-robin over the 8 XCDs): every XCD owns one contiguous band of
-    // tiles, walked column by column where the band is a whole number of tile rows -- neighbouring tiles read
-    // overlapping source texels, which then hit that XCD's L2.
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, qq = ntile >> 3, rr8 = ntile & 7;
-    const int band_tiles = qq + (xcd < rr8 ? 1 : 0);
-    const int band_first = xcd < rr8 ? xcd * (qq + 1) : rr8 * (qq + 1) + (xcd - rr8) * qq;
-    if (idx >= band_tiles * a.B) return;
-    const int b = idx / band_tiles, ti = idx - b * band_tiles;
-    int tile = band_first + ti;
-    if (rr8 == 0 && qq % tiles_x == 0) {
-        const int band_rows = qq / tiles_x;
-        tile = (xcd * band_rows + ti % band_rows) * tiles_x + ti / band_rows;
-    }
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    for (int k = threadIdx.x; k < 64 * NHALF; k += 256) dcl[k] = a.d_candi[min(k, D - 1)];
+    __syncthreads();   // (the only barrier of the kernel: from here on the four waves go their own way)
 
-    for (int k = lane; k < 64 * NHALF; k += 64) dcl[k] = a.d_candi[min(k, D - 1)];
-    __syncthreads();
-
-    const float cx = a.cxcy[b * 2 + 0], cy = a.cxcy[b * 2 + 1];
-    const float rcx = refined_rcp(cx), rcy = refined_rcp(cy);
     const float half_w = (float)W / 2.0f, half_h = (float)H / 2.0f;
     const float sigma = a.sigma, rsigma = refined_rcp(a.sigma);
     // v / sigma through the divide chain of geometry.hpp (bit-identical to the IEEE divide for finite operands in range);
     // inf / NaN (non-finite features) propagate through the plain product
     auto div_sigma = [&](float v) { return fabsf(v) < 1.0e30f ? div_core(v, sigma, rsigma) : v * rsigma; };
-    bool failed = false;   // wave-uniform
+#ifdef MFMA_STAMPS
+    unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t = __builtin_amdgcn_s_memrealtime();
+#endif
 
-    for (int s = 0; s < 4 && !failed; ++s) {
-        const int y = ty * 4 + s;
-        if (y >= H) break;
-        // (opaque per pixel row: the optimiser otherwise hoists every lane- and HW-derived invariant of the row's phases --
-        //  masks, LDS addresses, scalar offsets -- to the top of the kernel and spills them)
-        const int n = opaque_v(lane & 15), kq = opaque_v(lane >> 4), HW = opaque_s(H * W);
-        const int x = tx * 16 + n;
-        const bool xlive = x < W;
-        const int p = y * W + min(x, W - 1);
-        const float r0 = a.rays[((size_t)b * 3 + 0) * HW + p];
-        const float r1 = a.rays[((size_t)b * 3 + 1) * HW + p];
-        const float r2 = a.rays[((size_t)b * 3 + 2) * HW + p];
-        // reference features of pixel n, channel slice kq: the B operands of every MFMA of this pixel row
-        float Rr[NPL];
-        {
-            // (buffer loads: 32-bit offsets, the channel as the scalar offset; channels beyond C are fetched out of range = 0)
-            const __amdgpu_buffer_rsrc_t rref =
-                __builtin_amdgcn_make_buffer_rsrc((void*)(a.ref + (size_t)b * a.ref_bstride), 0, C * HW * 4, 0x00020000);
-#pragma unroll
-            for (int g = 0; g < NCH; ++g)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    Rr[4 * g + i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rref, 16 * g + 4 * kq + i < C ? (4 * kq * HW + p) * 4 : OOB, (16 * g + i) * HW * 4, 0));
-#pragma unroll
-            for (int tp = 0; tp < NTL; ++tp)
-                Rr[4 * NCH + tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                    rref, 4 * (4 * NCH + tp) + kq < C ? (kq * HW + p) * 4 : OOB, 4 * (4 * NCH + tp) * HW * 4, 0));
+    // Shape of a tile's four pixel sub-blocks (16 pixels each, one per wave): 16x1 (pixel rows) where the epipolar lines of
+    // view 0 run along the source rows (rectified stereo: a row's 16 pixels share two source rows), else 8x2 (the texels of
+    // two half rows overlap more than those of one full row: 30 % fewer blocks on a forward motion).  One decision per
+    // batch item, from four probe pixels: does the sample move by more than half a source row between the first and the
+    // last plane?  (Any choice is correct; this one is within 1 % of the best choice per tile on both benchmark poses.)
+    __shared__ unsigned char s_wide[256];
+    for (int bb = threadIdx.x; bb < min(a.B, 256); bb += 256) {
+        ViewXform xf;
+        make_view_xform(a.K + bb * 9, a.R + (size_t)bb * V * 9, a.t + (size_t)bb * V * 3, a.blas_mode, xf);
+        const float cx = a.cxcy[bb * 2 + 0], cy = a.cxcy[bb * 2 + 1];
+        const float rcx = refined_rcp(cx), rcy = refined_rcp(cy);
+        bool steep = false;
+        for (int pr = 0; pr < 4; ++pr) {
+            const int px = (pr & 1) ? (7 * W) / 8 : W / 8, py = (pr & 2) ? (7 * H) / 8 : H / 8, pc = py * W + px;
+            const size_t HW0 = (size_t)H * W;
+            float t2a, t2b, t2c, ix0, iy0, ix1, iy1;
+            ray_term2(xf, a.rays[((size_t)bb * 3 + 0) * HW0 + pc], a.rays[((size_t)bb * 3 + 1) * HW0 + pc],
+                      a.rays[((size_t)bb * 3 + 2) * HW0 + pc], t2a, t2b, t2c);
+            plane_sample_pos_fast(xf, t2a, t2b, t2c, dcl[0], cx, cy, rcx, rcy, half_w, half_h, ix0, iy0);
+            plane_sample_pos_fast(xf, t2a, t2b, t2c, dcl[D - 1], cx, cy, rcx, rcy, half_w, half_h, ix1, iy1);
+            steep = steep || fabsf(iy1 - iy0) > 0.5f;
         }
+        s_wide[bb] = steep ? 0 : 1;
+    }
+
+    // Persistent workgroups: the grid fills the chip once (two workgroups per CU) and every workgroup pulls tiles -- (batch
+    // item, 16x4 tile) -- from the queue of its XCD; wave w takes the tile's sub-block w, so the four waves, which read
+    // mostly the same source texels, run side by side on one CU and find each other's lines in its L1.  XCD-aware
+    // (workgroups are dealt round-robin over the 8 XCDs): every XCD owns one contiguous band of tiles, walked column by
+    // column where the band is a whole number of tile rows, so that overlapping source texels hit that XCD's L2.  A
+    // workgroup whose own queue is exhausted takes tiles of the other queues: the bands do not cost the same (on a forward
+    // motion those at the top and bottom of the image see the longest epipolar segments).
+    __shared__ int s_item[3];
+    const int xcd = blockIdx.x & 7, qq = ntile >> 3, rr8 = ntile & 7;
+    auto band_tiles_of = [&](int q) { return qq + (q < rr8 ? 1 : 0); };
+    auto band_first_of = [&](int q) { return q < rr8 ? q * (qq + 1) : rr8 * (qq + 1) + (q - rr8) * qq; };
+    const bool colmajor = rr8 == 0 && qq % tiles_x == 0;
+    // Queue protocol (thread 0): the atomic on the workgroup's OWN queue is issued at the top of a tile and its result is
+    // looked at when the tile is done -- a round trip to L2 that nothing waits for.  Only when the own band is exhausted (the
+    // end of a launch) the other queues are polled, synchronously.
+    const int n_own = band_tiles_of(xcd) * a.B;
+    bool own_done = false;
+    auto steal = [&]() -> int {   // (queue << 28) | index in the queue, or -1: every queue is exhausted
+        for (int j = 1; j < 8; ++j) {
+            const int q = (xcd + j) & 7, nq = band_tiles_of(q) * a.B;
+            if (*(volatile int*)&queue[q] >= nq) continue;
+            const int got = atomicAdd(&queue[q], 1);
+            if (got < nq) return (q << 28) | got;
+        }
+        return -1;
+    };
+    auto resolve = [&](int got) -> int {   // result of the own-queue atomic -> item
+        if (!own_done && got < n_own) return (xcd << 28) | got;
+        own_done = true;
+        return steal();
+    };
+    // item -> batch item, tile
+    auto decode = [&](int item, int& b_, int& tx_, int& ty_) {
+        const int q_ = item >> 28, iq = item & 0x0fffffff, band_tiles = band_tiles_of(q_);
+        b_ = iq / band_tiles;
+        const int ti = iq - b_ * band_tiles;
+        int tile = band_first_of(q_) + ti;
+        if (colmajor) {
+            const int band_rows = qq / tiles_x;
+            tile = (q_ * band_rows + ti % band_rows) * tiles_x + ti / band_rows;
+        }
+        tx_ = tile % tiles_x; ty_ = tile / tiles_x;
+    };
+    // this wave's pixel of a tile (sub-block = wave) and the loads that do not depend on anything computed: the pixel's ray
+    // and its reference features -- lane (n, kq): pixel n, channel slice kq, the B operands of every MFMA of the sub-block.
+    // They are issued one tile ahead, so that their latency (first touch: HBM) lies under the previous tile's work.
+    auto pixel_of = [&](int b_, int tx_, int ty_, int n_, int& x_, int& y_) {
+        const bool wide_ = b_ < 256 ? s_wide[b_] != 0 : false;
+        x_ = wide_ ? tx_ * 16 + n_ : tx_ * 16 + 8 * (wave & 1) + (n_ & 7);
+        y_ = wide_ ? ty_ * 4 + wave : ty_ * 4 + 2 * (wave >> 1) + (n_ >> 3);
+    };
+    auto load_pixel = [&](int item, float(&Rr_)[NPL], float(&ray_)[3]) {
+        int b_, tx_, ty_, x_, y_;
+        decode(item, b_, tx_, ty_);
+        const int n_ = opaque_v(lane & 15), kq_ = opaque_v(lane >> 4), HW_ = opaque_s(H * W);
+        pixel_of(b_, tx_, ty_, n_, x_, y_);
+        const int p_ = min(y_, H - 1) * W + min(x_, W - 1);
+        // (buffer loads: 32-bit offsets, the channel as the scalar offset; channels beyond C are fetched out of range = 0)
+        const __amdgpu_buffer_rsrc_t rray = __builtin_amdgcn_make_buffer_rsrc((void*)(a.rays + (size_t)b_ * 3 * HW_), 0, 3 * HW_ * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ray_[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rray, p_ * 4, i * HW_ * 4, 0));
+        const __amdgpu_buffer_rsrc_t rref =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(a.ref + (size_t)b_ * a.ref_bstride), 0, C * HW_ * 4, 0x00020000);
+#pragma unroll
+        for (int g = 0; g < NCH; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                Rr_[4 * g + i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rref, 16 * g + 4 * kq_ + i < C ? (4 * kq_ * HW_ + p_) * 4 : OOB, (16 * g + i) * HW_ * 4, 0));
+#pragma unroll
+        for (int tp = 0; tp < NTL; ++tp)
+            Rr_[4 * NCH + tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                rref, 4 * (4 * NCH + tp) + kq_ < C ? (kq_ * HW_ + p_) * 4 : OOB, 4 * (4 * NCH + tp) * HW_ * 4, 0));
+    };
+
+    // s_item: a ring of three -- the tile being worked on, the next one (its pixel loads are in flight), and the one
+    // thread 0 is fetching from the queue meanwhile
+    if (threadIdx.x == 0) {
+        s_item[0] = resolve(atomicAdd(&queue[xcd], 1));
+        s_item[1] = s_item[0] < 0 ? -1 : resolve(own_done ? 0 : atomicAdd(&queue[xcd], 1));
+    }
+    __syncthreads();
+    int slot = 0;
+    float Rr[NPL], ray[3];
+    {
+        const int it0 = __builtin_amdgcn_readfirstlane(s_item[0]);
+        if (it0 >= 0) load_pixel(it0, Rr, ray);
+    }
+    for (;;) {
+    const int item = __builtin_amdgcn_readfirstlane(s_item[slot]);
+    if (item < 0) break;
+    const int item_next = __builtin_amdgcn_readfirstlane(s_item[slot == 2 ? 0 : slot + 1]);
+    int got_own = 0;
+    if (threadIdx.x == 0 && item_next >= 0 && !own_done) got_own = atomicAdd(&queue[xcd], 1);   // (issued now, looked at when the tile is done)
+    float Rn[NPL], rayn[3];
+    if (item_next >= 0) load_pixel(item_next, Rn, rayn);
+    const int sub = wave;
+    int b, tx, ty;
+    decode(item, b, tx, ty);
+    const float cx = a.cxcy[b * 2 + 0], cy = a.cxcy[b * 2 + 1];
+    const float rcx = refined_rcp(cx), rcy = refined_rcp(cy);
+    bool failed = false;   // wave-uniform
+    const bool wide = b < 256 ? s_wide[b] != 0 : false;
+
+    if ((wide ? ty * 4 + sub : ty * 4 + 2 * (sub >> 1)) < H) {   // (else: the sub-block lies below the image)
+        // (opaque: the optimiser otherwise hoists every lane- and HW-derived invariant of the phases -- masks, LDS addresses,
+        //  scalar offsets -- to the top of the kernel and spills them)
+        const int n = opaque_v(lane & 15), kq = opaque_v(lane >> 4), HW = opaque_s(H * W);
+        int x, y;
+        pixel_of(b, tx, ty, n, x, y);
+        const bool xlive = x < W && y < H;
+        const int p = min(y, H - 1) * W + min(x, W - 1);
+        const float r0 = ray[0], r1 = ray[1], r2 = ray[2];
         float rr = 0.0f;   // |r|^2 of the pixel
 #pragma unroll
         for (int i = 0; i < NPL; ++i) rr = __builtin_fmaf(Rr[i], Rr[i], rr);
@@ -167,6 +309,7 @@ __global__ __launch_bounds__(64, 2) void sweep_mfma_kernel(SweepArgs a, const fl
         float cost[NHALF * 16];
 #pragma unroll
         for (int i = 0; i < NHALF * 16; ++i) cost[i] = 0.0f;
+        MSTAMP(0)   // row setup: rays, reference features
 
         for (int v = 0; v < V && !failed; ++v) {
             ViewXform xf;
@@ -189,10 +332,12 @@ __global__ __launch_bounds__(64, 2) void sweep_mfma_kernel(SweepArgs a, const fl
                     plane_sample_pos_fast(xf, t2a, t2b, t2c, dcl[k], cx, cy, rcx, rcy, half_w, half_h, ix, iy);
                     xy[j] = cell_of(ix, iy, W, H, fw[j], fn[j]);
                     if (k >= D || !xlive) xy[j] = NO_CELL;
-                    __builtin_amdgcn_sched_barrier(0);   // (one plane at a time: the scheduler otherwise interleaves all 16 chains)
+                    if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (four planes' chains at a time)
                 }
 
-                int j0 = 0, len = 16;   // current pass: j in [j0, j0 + len)
+                MSTAMP(1)   // sample positions
+                int j0 = MFMA_ABL_STOP == 1 ? 16 : 0, len = 16;   // current pass: j in [j0, j0 + len)
+                if (MFMA_ABL_STOP == 1) { for (int j = 0; j < 16; ++j) cost[h * 16 + j] += fw[j] + fn[j] + (float)xy[j]; }
                 while (j0 < 16) {
                     const int j1 = j0 + len;
                     // (pinned per pass and per phase: nothing derived from the cells is carried from one phase into the next)
@@ -214,7 +359,7 @@ __global__ __launch_bounds__(64, 2) void sweep_mfma_kernel(SweepArgs a, const fl
                         } else {
                             cmin[lane] = INT_MAX;
                             cmax[lane] = INT_MIN;
-                            __syncthreads();
+                            WAVE_LDS_SYNC();
 #pragma unroll
                             for (int j = 0; j < 16; ++j) xy[j] = opaque_v(xy[j]);
                             int run = -1, rmin = 0, rmax = 0;
@@ -231,33 +376,33 @@ __global__ __launch_bounds__(64, 2) void sweep_mfma_kernel(SweepArgs a, const fl
                                 }
                             }
                             if (run >= 0) { atomicMin(&cmin[run], rmin); atomicMax(&cmax[run], rmax); }
-                            __syncthreads();
+                            WAVE_LDS_SYNC();
                             // lane = texel row: cells of rows lane - 1 and lane touch it
                             int lo = INT_MAX, hi = INT_MIN;
                             if (lane < ncell) { lo = cmin[lane]; hi = cmax[lane]; }
                             if (lane >= 1 && lane <= ncell) { lo = min(lo, cmin[lane - 1]); hi = max(hi, cmax[lane - 1]); }
                             const int nblk = lo <= hi ? (hi - lo + 2 + 15) >> 4 : 0;   // texels lo .. hi + 1
-                            int incl = nblk;
-#pragma unroll
-                            for (int o = 1; o < 64; o <<= 1) {
-                                const int t = __shfl_up(incl, o);
-                                if (lane >= o) incl += t;
-                            }
+                            const int incl = wave_scan_incl(nblk);
                             nb = __builtin_amdgcn_readlane(incl, 63);
                             fits = nb <= MAXB;
                             if (fits) {
                                 const int fb = incl - nblk;
                                 rowoff[lane] = 16 * fb - lo;
                                 for (int i = 0; i < nblk; ++i) blk[fb + i] = ((ybase + lane) << 16) | ((lo + 16 * i) & 0xffff);
-                                __syncthreads();
+                                WAVE_LDS_SYNC();
                             }
                         }
                     }
+                    MSTAMP(2)   // row table
                     if (!fits) {
+                        MCOUNT(7, 1)   // failed trials
                         if (len == 1) { failed = true; break; }
                         len >>= 1;
                         continue;
                     }
+                    MCOUNT(6, 1)    // passes
+                    MCOUNT(8, nb)   // blocks
+                    if (MFMA_ABL_STOP == 2) { cost[h * 16] += (float)(nb + rowoff[lane & 7] + blk[lane & 7]); j0 = j1; len = min(j0 & -j0, 16 - j0); continue; }
 
                     // ---- X = <r, s> for the blocks of the pass, on the matrix pipe -----------------------------------
                     auto load_block = [&](int bi, v4f(&S)[NCH > 0 ? NCH : 1], float(&T)[NTL > 0 ? NTL : 1], v4f& g) {
@@ -266,6 +411,14 @@ __global__ __launch_bounds__(64, 2) void sweep_mfma_kernel(SweepArgs a, const fl
                         const bool ok = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
                         const int t16 = (yy * W + xx) * 16;
                         const int vo = ok ? t16 + kq * HW * 16 : OOB;
+#ifdef MFMA_ABL_NOLOAD   // timing experiment (results wrong): what do the texel loads of the X phase cost?
+#pragma unroll
+                        for (int gi = 0; gi < NCH; ++gi) S[gi] = v4f{(float)vo, 1.f, 2.f, 3.f};
+#pragma unroll
+                        for (int tp = 0; tp < NTL; ++tp) T[tp] = (float)vo;
+                        g = v4f{1.f, 1.f, 1.f, 1.f};
+                        return;
+#endif
 #pragma unroll
                         for (int gi = 0; gi < NCH; ++gi)
                             S[gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, gi * 4 * HW * 16, 0));
@@ -286,6 +439,14 @@ __global__ __launch_bounds__(64, 2) void sweep_mfma_kernel(SweepArgs a, const fl
                     // independent one issues after 32)
                     auto compute_block = [&](int bi, v4f(&S)[NCH > 0 ? NCH : 1], float(&T)[NTL > 0 ? NTL : 1], v4f& g) {
                         v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#ifdef MFMA_ABL_NOMFMA   // timing experiment (results wrong): what do the MFMAs of the X phase cost?
+#pragma unroll
+                        for (int gi = 0; gi < NCH; ++gi) { acc0 += S[gi]; }
+#pragma unroll
+                        for (int tp = 0; tp < NTL; ++tp) acc1[0] += T[tp];
+                        store_block(bi, acc0 + acc1, g);
+                        return;
+#endif
 #pragma unroll
                         for (int gi = 0; gi < NCH; ++gi) {
                             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(S[gi][0], Rr[4 * gi + 0], acc0, 0, 0, 0);
@@ -302,7 +463,7 @@ __global__ __launch_bounds__(64, 2) void sweep_mfma_kernel(SweepArgs a, const fl
                     };
                     if (nb > 0) {
                         if (lane < 4) blk[nb + lane] = (int)0xfffe0000;   // empty blocks behind the list: loads beyond it fetch nothing
-                        __syncthreads();
+                        WAVE_LDS_SYNC();
                         v4f SA[NCH > 0 ? NCH : 1], SB[NCH > 0 ? NCH : 1], SC[NCH > 0 ? NCH : 1];
                         float TA[NTL > 0 ? NTL : 1], TB[NTL > 0 ? NTL : 1], TC[NTL > 0 ? NTL : 1];
                         v4f gA, gB, gC;
@@ -320,9 +481,11 @@ __global__ __launch_bounds__(64, 2) void sweep_mfma_kernel(SweepArgs a, const fl
                                 compute_block(bi + 2, SC, TC, gC);
                             }
                         }
-                        __syncthreads();
+                        WAVE_LDS_SYNC();
                     }
 
+                    MSTAMP(3)   // X on the matrix pipe
+                    if (MFMA_ABL_STOP == 3) { cost[h * 16] += Xs[lane] + G4s[lane] + G1s[lane]; j0 = j1; len = min(j0 & -j0, 16 - j0); continue; }
                     // ---- combine: cost of this lane's planes of the pass ---------------------------------------------
 #pragma unroll
                     for (int j = 0; j < 16; ++j) { xy[j] = opaque_v(xy[j]); fw[j] = opaque_f(fw[j]); fn[j] = opaque_f(fn[j]); }
@@ -355,13 +518,17 @@ __global__ __launch_bounds__(64, 2) void sweep_mfma_kernel(SweepArgs a, const fl
                         }
                         if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two planes' LDS reads in flight at a time
                     }
-                    __syncthreads();   // the tables and X of this pass are dead
+                    WAVE_LDS_SYNC();   // the tables and X of this pass are dead
+                    MSTAMP(4)   // combine
                     j0 = j1;
                     len = min(j0 & -j0, 16 - j0);
                 }
             }
         }
-        if (failed) break;
+        MCOUNT(9, 1)   // pixel sub-blocks
+        if (MFMA_ABL_STOP == 4) { if (a.depth_out && xlive && kq == 0) { float sm = 0.f; for (int i = 0; i < NHALF * 16; ++i) sm += cost[i]; a.depth_out[(size_t)b * HW + p] = sm; } }
+        else if (MFMA_ABL_STOP != 0) { if (a.depth_out && xlive && kq == 0) { float sm = 0.f; for (int i = 0; i < NHALF * 16; ++i) sm += cost[i]; a.depth_out[(size_t)b * HW + p] = sm; } }
+        else if (!failed) {
 
         // ---- epilogue: cost store, log-softmax over D, expectation ------------------------------------------------
         // (buffer stores: one 32-bit lane offset, the plane as the scalar offset -- 64-bit per-plane pointers would be
@@ -405,21 +572,41 @@ __global__ __launch_bounds__(64, 2) void sweep_mfma_kernel(SweepArgs a, const fl
             }
             if (a.depth_out && xlive && kq == 0) a.depth_out[(size_t)b * HW + p] = esum / ssum;
         }
+        }
     }
     if (failed && lane == 0) {   // the gather kernel redoes the tile
         const int tiles_y = (H + 3) / 4;
         tile_flags[b * tiles_x * tiles_y + ty * tiles_x + tx] = 1;
         atomicAdd(&queue[GATHER_COUNT_SLOT], 1);
     }
+    MSTAMP(5)
+    if (threadIdx.x == 0) s_item[slot == 0 ? 2 : slot - 1] = item_next >= 0 ? resolve(got_own) : -1;   // (the ring slot two ahead = the one behind)
+    // the tile after the next is published, everybody is done with this one's slot.  (A raw barrier: __syncthreads() would
+    // also wait for this tile's output stores to be acknowledged and for the next tile's pixel loads.)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    slot = slot == 2 ? 0 : slot + 1;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) Rr[i] = Rn[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ray[i] = rayn[i];
+    MSTAMP(10)
+    }   // tiles
+#ifdef MFMA_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(queue + 16) + i, stamp_acc[i]);
+#endif
 }
 
 template <int NPL>
 hipError_t launch_npl(const SweepArgs& a, const float4* packed, int* flags, int* queue, int tiles_x, int tiles, hipStream_t stream) {
-    const long long nblk = 8ll * ((tiles + 7) / 8) * a.B;
+    // persistent grid: two workgroups of four waves per CU (LDS: 2 x 80 KB), a multiple of 8; fewer when there is less work
+    long long nblk = ((long long)sweep_device_cus() * MFMA_WG_PER_CU + 7) & ~7ll;
+    const long long need = 8ll * (((long long)tiles * a.B + 7) / 8);   // a workgroup per tile
+    if (need < nblk) nblk = need;
     if (a.D <= 64)
-        hipLaunchKernelGGL((sweep_mfma_kernel<NPL, 1>), dim3((unsigned)nblk), dim3(64), 0, stream, a, packed, flags, queue, tiles_x, tiles);
+        hipLaunchKernelGGL((sweep_mfma_kernel<NPL, 1>), dim3((unsigned)nblk), dim3(256), 0, stream, a, packed, flags, queue, tiles_x, tiles);
     else
-        hipLaunchKernelGGL((sweep_mfma_kernel<NPL, 2>), dim3((unsigned)nblk), dim3(64), 0, stream, a, packed, flags, queue, tiles_x, tiles);
+        hipLaunchKernelGGL((sweep_mfma_kernel<NPL, 2>), dim3((unsigned)nblk), dim3(256), 0, stream, a, packed, flags, queue, tiles_x, tiles);
     return hipGetLastError();
 }
 
