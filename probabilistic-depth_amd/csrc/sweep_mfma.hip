@@ -49,7 +49,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 #ifndef MFMA_MAXB
-#define MFMA_MAXB 14
+#define MFMA_MAXB 15
 #endif
 #ifndef MFMA_WG_PER_CU
 #define MFMA_WG_PER_CU 2
@@ -108,6 +108,36 @@ __device__ __forceinline__ int wave_max_i(int v) {
 }
 #undef MFMA_DPP_STEP
 
+// plane_sample_pos_fast() of geometry.hpp for TWO planes at a time in packed fp32 (v_pk_mul / v_pk_add / v_pk_fma_f32: each
+// component rounds exactly like the scalar instruction, so the positions are bit-identical): the kernel runs at two waves
+// per SIMD, where the instruction rate of a wave, not the lane rate, is what the vector phases are short of.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f splat2(float x) { return v2f{x, x}; }
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f div_core2(v2f n, v2f d, v2f y) {
+    const v2f q0 = n * y;
+    const v2f r0 = fma2(-d, q0, n);
+    const v2f q1 = fma2(r0, y, q0);
+    const v2f r1 = fma2(-d, q1, n);
+    return fma2(r1, y, q1);
+}
+__device__ __forceinline__ void plane_sample_pos_fast2(const ViewXform& x, float t2a, float t2b, float t2c, v2f d, float cx, float cy,
+                                                       float rcx, float rcy, float half_w, float half_h, v2f& ix, v2f& iy) {
+    const v2f px = splat2(x.kt[0]) + splat2(t2a) * d;
+    const v2f py = splat2(x.kt[1]) + splat2(t2b) * d;
+    const v2f pz = splat2(x.kt[2]) + splat2(t2c) * d;
+    const v2f den = pz + splat2(1e-10f);
+    const v2f y0 = v2f{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    const v2f e = fma2(-den, y0, splat2(1.0f));
+    const v2f y = fma2(e, y0, y0);
+    const v2f u = div_core2(px, den, y);
+    const v2f v = div_core2(py, den, y);
+    const v2f gx = div_core2(u - splat2(cx), splat2(cx), splat2(rcx));
+    const v2f gy = div_core2(v - splat2(cy), splat2(cy), splat2(rcy));
+    ix = fma2(gx + splat2(1.0f), splat2(half_w), splat2(-0.5f));
+    iy = fma2(gy + splat2(1.0f), splat2(half_h), splat2(-0.5f));
+}
+
 // Footprint of a sample position as make_footprint() (geometry.hpp) computes it, packed: (y0 << 16) | (x0 & 0xffff) of the
 // top-left texel, or NO_CELL when no tap lies inside the image (NaN positions included); fw, fn = the fractions.
 constexpr int NO_CELL = INT_MIN;
@@ -126,11 +156,10 @@ __device__ __forceinline__ int cell_y(int xy) { return xy >> 16; }
 // LDS of one wave
 struct __attribute__((aligned(16))) WaveLds {
     float Xs[16 * XSTRIDE];     // X[pixel][slot]
-    float G4s[MAXB * 16 * 4];   // Gram record (N, H, V, D1) per slot
-    float G1s[MAXB * 16];       // Gram D2 per slot
+    float G4s[MAXB * 16 * 4];   // Gram record (N, H, V, D1 + D2) per slot
     int cmin[MAXROWS], cmax[MAXROWS];   // per cell row: min / max x0
     int rowoff[MAXROWS];        // per texel row: slot = x + rowoff
-    int blk[MAXB + 4];          // per block: (y << 16) | (x & 0xffff) of its first texel
+    int blk[MAXB + 8];          // per block: (y << 16) | (x & 0xffff) of its first texel
 };
 
 // NPL = packed feature planes of a source view (ceil(C / 4)); NHALF = ceil(D / 64).
@@ -145,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds& L = wlds[wave];
-    float* const Xs = L.Xs; float* const G4s = L.G4s; float* const G1s = L.G1s;
+    float* const Xs = L.Xs; float* const G4s = L.G4s;
     int* const cmin = L.cmin; int* const cmax = L.cmax; int* const rowoff = L.rowoff; int* const blk = L.blk;
     const int D = a.D, H = a.H, W = a.W, V = a.V, C = a.C;
 
@@ -167,8 +196,8 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
     // two half rows overlap more than those of one full row: 30 % fewer blocks on a forward motion).  One decision per
     // batch item, from four probe pixels: does the sample move by more than half a source row between the first and the
     // last plane?  (Any choice is correct; this one is within 1 % of the best choice per tile on both benchmark poses.)
-    __shared__ unsigned char s_wide[256];
-    for (int bb = threadIdx.x; bb < min(a.B, 256); bb += 256) {
+    __shared__ unsigned char s_wide[64];
+    for (int bb = threadIdx.x; bb < min(a.B, 64); bb += 256) {
         ViewXform xf;
         make_view_xform(a.K + bb * 9, a.R + (size_t)bb * V * 9, a.t + (size_t)bb * V * 3, a.blas_mode, xf);
         const float cx = a.cxcy[bb * 2 + 0], cy = a.cxcy[bb * 2 + 1];
@@ -234,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
     // and its reference features -- lane (n, kq): pixel n, channel slice kq, the B operands of every MFMA of the sub-block.
     // They are issued one tile ahead, so that their latency (first touch: HBM) lies under the previous tile's work.
     auto pixel_of = [&](int b_, int tx_, int ty_, int n_, int& x_, int& y_) {
-        const bool wide_ = b_ < 256 ? s_wide[b_] != 0 : false;
+        const bool wide_ = b_ < 64 ? s_wide[b_] != 0 : false;
         x_ = wide_ ? tx_ * 16 + n_ : tx_ * 16 + 8 * (wave & 1) + (n_ & 7);
         y_ = wide_ ? ty_ * 4 + wave : ty_ * 4 + 2 * (wave >> 1) + (n_ >> 3);
     };
@@ -250,6 +279,11 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
         for (int i = 0; i < 3; ++i) ray_[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rray, p_ * 4, i * HW_ * 4, 0));
         const __amdgpu_buffer_rsrc_t rref =
             __builtin_amdgcn_make_buffer_rsrc((void*)(a.ref + (size_t)b_ * a.ref_bstride), 0, C * HW_ * 4, 0x00020000);
+#ifdef MFMA_ABL_NOREF   // timing experiment (results wrong): what do the reference-feature loads cost?
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) Rr_[i] = (float)(p_ + i);
+        return;
+#endif
 #pragma unroll
         for (int g = 0; g < NCH; ++g)
 #pragma unroll
@@ -282,14 +316,16 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
     int got_own = 0;
     if (threadIdx.x == 0 && item_next >= 0 && !own_done) got_own = atomicAdd(&queue[xcd], 1);   // (issued now, looked at when the tile is done)
     float Rn[NPL], rayn[3];
+#ifndef MFMA_NO_XPREFETCH
     if (item_next >= 0) load_pixel(item_next, Rn, rayn);
+#endif
     const int sub = wave;
     int b, tx, ty;
     decode(item, b, tx, ty);
     const float cx = a.cxcy[b * 2 + 0], cy = a.cxcy[b * 2 + 1];
     const float rcx = refined_rcp(cx), rcy = refined_rcp(cy);
     bool failed = false;   // wave-uniform
-    const bool wide = b < 256 ? s_wide[b] != 0 : false;
+    const bool wide = b < 64 ? s_wide[b] != 0 : false;
 
     if ((wide ? ty * 4 + sub : ty * 4 + 2 * (sub >> 1)) < H) {   // (else: the sub-block lies below the image)
         // (opaque: the optimiser otherwise hoists every lane- and HW-derived invariant of the phases -- masks, LDS addresses,
@@ -311,7 +347,8 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
         for (int i = 0; i < NHALF * 16; ++i) cost[i] = 0.0f;
         MSTAMP(0)   // row setup: rays, reference features
 
-        for (int v = 0; v < V && !failed; ++v) {
+        if (MFMA_ABL_STOP == 9) { cost[0] = rr + r0 + r1 + r2; }
+        for (int v = 0; v < (MFMA_ABL_STOP == 9 ? 0 : V) && !failed; ++v) {
             ViewXform xf;
             make_view_xform(a.K + b * 9, a.R + ((size_t)b * V + v) * 9, a.t + ((size_t)b * V + v) * 3, a.blas_mode, xf);
             float t2a, t2b, t2c;
@@ -325,15 +362,24 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
                 // ---- sample positions of this lane's 16 planes (NaN: plane beyond D or pixel beyond the image) ----------
                 int xy[16];
                 float fw[16], fn[16];
+#ifdef MFMA_REP_GEOM   // timing experiment: the phase twice (same results) -- its cost in situ is the difference
+                for (int rep = 0; rep < 2; ++rep) {
+                t2a = opaque_f(t2a);
+#endif
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
+                for (int j = 0; j < 16; j += 2) {
                     const int k = 64 * h + 4 * j + kq;
-                    float ix, iy;
-                    plane_sample_pos_fast(xf, t2a, t2b, t2c, dcl[k], cx, cy, rcx, rcy, half_w, half_h, ix, iy);
-                    xy[j] = cell_of(ix, iy, W, H, fw[j], fn[j]);
+                    v2f ix, iy;
+                    plane_sample_pos_fast2(xf, t2a, t2b, t2c, v2f{dcl[k], dcl[k + 4]}, cx, cy, rcx, rcy, half_w, half_h, ix, iy);
+                    xy[j] = cell_of(ix.x, iy.x, W, H, fw[j], fn[j]);
+                    xy[j + 1] = cell_of(ix.y, iy.y, W, H, fw[j + 1], fn[j + 1]);
                     if (k >= D || !xlive) xy[j] = NO_CELL;
-                    if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (four planes' chains at a time)
+                    if (k + 4 >= D || !xlive) xy[j + 1] = NO_CELL;
+                    if ((j & 6) == 6) __builtin_amdgcn_sched_barrier(0);   // (four pairs' chains at a time)
                 }
+#ifdef MFMA_REP_GEOM
+                }
+#endif
 
                 MSTAMP(1)   // sample positions
                 int j0 = MFMA_ABL_STOP == 1 ? 16 : 0, len = 16;   // current pass: j in [j0, j0 + len)
@@ -344,29 +390,49 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
 #pragma unroll
                     for (int j = 0; j < 16; ++j) xy[j] = opaque_v(xy[j]);
                     // ---- row table -----------------------------------------------------------------------------
+#ifdef MFMA_REP_TABLE
+                    int nb = 0, ybase = 0;
+                    bool fits = true;
+                    for (int rep = 0; rep < 2; ++rep) {
+                    nb = 0; fits = true;
+#endif
+                    // the cells of the pass (planes outside [j0, j1): none), so that the loops below run over all 16 without
+                    // range branches
+                    int xyp[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) xyp[j] = (j >= j0 && j < j1) ? xy[j] : NO_CELL;
                     int lmin = INT_MAX, lmax = INT_MIN;
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
-                        if (j >= j0 && j < j1 && xy[j] != NO_CELL) { lmin = min(lmin, cell_y(xy[j])); lmax = max(lmax, cell_y(xy[j])); }
+                        const bool valid = xyp[j] != NO_CELL;
+                        lmin = min(lmin, valid ? cell_y(xyp[j]) : INT_MAX);
+                        lmax = max(lmax, valid ? cell_y(xyp[j]) : INT_MIN);
                     }
+#ifdef MFMA_REP_TABLE
+                    ybase = wave_min_i(lmin);
+                    const int ytop = wave_max_i(lmax);
+#else
                     const int ybase = wave_min_i(lmin), ytop = wave_max_i(lmax);
                     int nb = 0;
                     bool fits = true;
+#endif
                     if (ybase <= ytop) {
                         const int ncell = ytop - ybase + 1;
-                        if (ncell + 1 > MAXROWS) {
+                        if (ncell + 1 > MAXB) {   // (every texel row takes a block: cannot fit, and MAXB < MAXROWS)
                             fits = false;
                         } else {
                             cmin[lane] = INT_MAX;
                             cmax[lane] = INT_MIN;
                             WAVE_LDS_SYNC();
-#pragma unroll
-                            for (int j = 0; j < 16; ++j) xy[j] = opaque_v(xy[j]);
+                            // per cell row the min / max x0 over the wave by LDS atomics; a lane first folds its consecutive planes
+                            // of equal row (the position moves monotonically along the epipolar line), so that on a rectified pair
+                            // -- every plane of every pixel in one row -- a lane issues one pair of atomics, not sixteen that
+                            // serialise on one address
                             int run = -1, rmin = 0, rmax = 0;
 #pragma unroll
                             for (int j = 0; j < 16; ++j) {
-                                if (j >= j0 && j < j1 && xy[j] != NO_CELL) {
-                                    const int r = cell_y(xy[j]) - ybase, cxx = cell_x(xy[j]);
+                                if (xyp[j] != NO_CELL) {
+                                    const int r = cell_y(xyp[j]) - ybase, cxx = cell_x(xyp[j]);
                                     if (r != run) {
                                         if (run >= 0) { atomicMin(&cmin[run], rmin); atomicMax(&cmax[run], rmax); }
                                         run = r; rmin = cxx; rmax = cxx;
@@ -393,6 +459,9 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
                             }
                         }
                     }
+#ifdef MFMA_REP_TABLE
+                    }
+#endif
                     MSTAMP(2)   // row table
                     if (!fits) {
                         MCOUNT(7, 1)   // failed trials
@@ -405,46 +474,40 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
                     if (MFMA_ABL_STOP == 2) { cost[h * 16] += (float)(nb + rowoff[lane & 7] + blk[lane & 7]); j0 = j1; len = min(j0 & -j0, 16 - j0); continue; }
 
                     // ---- X = <r, s> for the blocks of the pass, on the matrix pipe -----------------------------------
-                    auto load_block = [&](int bi, v4f(&S)[NCH > 0 ? NCH : 1], float(&T)[NTL > 0 ? NTL : 1], v4f& g) {
-                        const int be = blk[bi];
+                    // (the block list rides in a register -- lane l holds entry l -- so a block's entry is a v_readlane away,
+                    //  not an LDS round trip in front of every block's loads)
+                    int myblk = 0;
+                    auto load_block = [&](int bi, v4f(&S)[NCH > 0 ? NCH : 1], float(&T)[NTL > 0 ? NTL : 1]) {
+                        const int be = __builtin_amdgcn_readlane(myblk, bi);
                         const int yy = be >> 16, xx = (int)(short)(be & 0xffff) + n;
                         const bool ok = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
                         const int t16 = (yy * W + xx) * 16;
-                        const int vo = ok ? t16 + kq * HW * 16 : OOB;
+                        const int vo = opaque_v(ok ? t16 + kq * HW * 16 : OOB);   // (opaque: one load with a selected offset, no branch)
 #ifdef MFMA_ABL_NOLOAD   // timing experiment (results wrong): what do the texel loads of the X phase cost?
 #pragma unroll
                         for (int gi = 0; gi < NCH; ++gi) S[gi] = v4f{(float)vo, 1.f, 2.f, 3.f};
 #pragma unroll
                         for (int tp = 0; tp < NTL; ++tp) T[tp] = (float)vo;
-                        g = v4f{1.f, 1.f, 1.f, 1.f};
                         return;
 #endif
 #pragma unroll
                         for (int gi = 0; gi < NCH; ++gi)
                             S[gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, gi * 4 * HW * 16, 0));
-                        const int vt = ok ? t16 + kq * 4 : OOB;
+                        const int vt = opaque_v(ok ? t16 + kq * 4 : OOB);
 #pragma unroll
                         for (int tp = 0; tp < NTL; ++tp)
                             T[tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vt, (4 * NCH + tp) * HW * 16, 0));
-                        // lanes kq = 0: Gram record (N, H, V, D1) of texel n; kq = 1: (D2, 0, 0, 0)
-                        const int vg = (ok && kq < 2) ? t16 + kq * HW * 16 : OOB;
-                        g = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vg, NPL * HW * 16, 0));
-                    };
-                    auto store_block = [&](int bi, const v4f& acc, const v4f& g) {
-                        *reinterpret_cast<v4f*>(&Xs[n * XSTRIDE + 16 * bi + 4 * kq]) = acc;
-                        if (kq == 0) *reinterpret_cast<v4f*>(&G4s[(16 * bi + n) * 4]) = g;
-                        if (kq == 1) G1s[16 * bi + n] = g.x;
                     };
                     // one block = ceil(C/4) MFMAs in two alternating accumulator chains (a dependent f32 MFMA waits 40 cycles, an
-                    // independent one issues after 32)
-                    auto compute_block = [&](int bi, v4f(&S)[NCH > 0 ? NCH : 1], float(&T)[NTL > 0 ? NTL : 1], v4f& g) {
+                    // independent one issues after 32); X[texel][pixel] of the block to LDS
+                    auto compute_block = [&](int bi, v4f(&S)[NCH > 0 ? NCH : 1], float(&T)[NTL > 0 ? NTL : 1], bool keep) {
                         v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #ifdef MFMA_ABL_NOMFMA   // timing experiment (results wrong): what do the MFMAs of the X phase cost?
 #pragma unroll
                         for (int gi = 0; gi < NCH; ++gi) { acc0 += S[gi]; }
 #pragma unroll
                         for (int tp = 0; tp < NTL; ++tp) acc1[0] += T[tp];
-                        store_block(bi, acc0 + acc1, g);
+                        if (keep) *reinterpret_cast<v4f*>(&Xs[n * XSTRIDE + 16 * bi + 4 * kq]) = acc0 + acc1;
                         return;
 #endif
 #pragma unroll
@@ -459,34 +522,90 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
                             if (tp & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(T[tp], Rr[4 * NCH + tp], acc1, 0, 0, 0);
                             else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(T[tp], Rr[4 * NCH + tp], acc0, 0, 0, 0);
                         }
-                        store_block(bi, acc0 + acc1, g);
+                        if (keep) *reinterpret_cast<v4f*>(&Xs[n * XSTRIDE + 16 * bi + 4 * kq]) = acc0 + acc1;
                     };
                     if (nb > 0) {
-                        if (lane < 4) blk[nb + lane] = (int)0xfffe0000;   // empty blocks behind the list: loads beyond it fetch nothing
+                        if (lane < 8) blk[nb + lane] = (int)0xfffe0000;   // empty blocks behind the list: loads beyond it fetch nothing
                         WAVE_LDS_SYNC();
+                        myblk = blk[min(lane, MAXB + 7)];
+                        WAVE_LDS_SYNC();
+                        // Gram records of the pass's slots (texel = slot of a block): lane l takes slots l, l + 64, ...  The
+                        // loads are issued here and land in LDS behind the multiplications.
+                        // (vmcnt(0) here -- everything older has long landed: the next tile's pixel loads were issued at the top of
+                        //  the tile, the previous tile's output stores before that.  With stores possibly pending the compiler
+                        //  cannot count on in-order return and drains the loads of the loop below instead of overlapping them.)
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
+                        constexpr int NGI = (MAXB * 16 + 63) / 64;
+                        v4f g4[NGI];
+                        float g1[NGI];
+#pragma unroll
+                        for (int it = 0; it < NGI; ++it) {
+                            const int slot = lane + 64 * it;
+                            const int be = __shfl(myblk, slot >> 4);
+                            const int yy = be >> 16, xx = (int)(short)(be & 0xffff) + (slot & 15);
+                            const bool ok = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && it * 64 < 16 * nb;
+                            const int vg = opaque_v(ok ? (yy * W + xx) * 16 : OOB);
+                            g4[it] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vg, NPL * HW * 16, 0));
+                            g1[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vg, (NPL + 1) * HW * 16, 0));
+                        }
                         v4f SA[NCH > 0 ? NCH : 1], SB[NCH > 0 ? NCH : 1], SC[NCH > 0 ? NCH : 1];
                         float TA[NTL > 0 ? NTL : 1], TB[NTL > 0 ? NTL : 1], TC[NTL > 0 ? NTL : 1];
-                        v4f gA, gB, gC;
-                        load_block(0, SA, TA, gA);
-                        load_block(1, SB, TB, gB);
-                        for (int bi = 0; bi < nb; bi += 3) {   // two blocks in flight behind the one being multiplied
-                            load_block(bi + 2, SC, TC, gC);
-                            compute_block(bi, SA, TA, gA);
-                            if (bi + 1 < nb) {
-                                load_block(bi + 3, SA, TA, gA);
-                                compute_block(bi + 1, SB, TB, gB);
-                            }
-                            if (bi + 2 < nb) {
-                                load_block(bi + 4, SB, TB, gB);
-                                compute_block(bi + 2, SC, TC, gC);
+#ifdef MFMA_REP_X
+                        for (int rep = 0; rep < 2; ++rep) {
+#endif
+#ifdef MFMA_NSET4   // experiment: three blocks in flight behind the one being multiplied
+                        v4f SD[NCH > 0 ? NCH : 1];
+                        float TD[NTL > 0 ? NTL : 1];
+                        load_block(0, SA, TA);
+                        load_block(1, SB, TB);
+                        load_block(2, SC, TC);
+                        for (int bi = 0; bi < nb; bi += 4) {
+                            load_block(bi + 3, SD, TD);
+                            compute_block(bi, SA, TA, true);
+                            if (bi + 1 < nb) { load_block(bi + 4, SA, TA); compute_block(bi + 1, SB, TB, true); }
+                            if (bi + 2 < nb) { load_block(bi + 5, SB, TB); compute_block(bi + 2, SC, TC, true); }
+                            if (bi + 3 < nb) { load_block(bi + 6, SC, TC); compute_block(bi + 3, SD, TD, true); }
+                        }
+#else
+                        load_block(0, SA, TA);
+                        load_block(1, SB, TB);
+                        // two blocks in flight behind the one being multiplied.  (Unrolled over the at most MAXB blocks, with forward
+                        // exits: around a loop the compiler merges the pending-load state of entry and back edge and ends up
+                        // draining the prefetched blocks in front of the first multiplication of every round.)
+#pragma unroll
+                        for (int bi = 0; bi < MAXB; bi += 3) {
+                            if (bi >= nb) break;
+                            // (loads and multiplications of a round are unconditional -- the entries behind the list are empty
+                            //  blocks, fetched out of range -- so that every path carries the same pending loads; only the stores
+                            //  of blocks beyond the list are skipped)
+                            load_block(bi + 2, SC, TC);
+                            compute_block(bi, SA, TA, true);
+                            load_block(bi + 3, SA, TA);
+                            compute_block(bi + 1, SB, TB, bi + 1 < nb);
+                            load_block(bi + 4, SB, TB);
+                            compute_block(bi + 2, SC, TC, bi + 2 < nb);
+                        }
+#endif
+#ifdef MFMA_REP_X
+                        }
+#endif
+#pragma unroll
+                        for (int it = 0; it < NGI; ++it) {
+                            const int slot = lane + 64 * it;
+                            if (slot < MAXB * 16) {   // (compile-time for all but the last round)
+                                g4[it].w = g4[it].w + g1[it];   // (the combine only uses D1 + D2: the sum it would form itself)
+                                *reinterpret_cast<v4f*>(&G4s[slot * 4]) = g4[it];
                             }
                         }
                         WAVE_LDS_SYNC();
                     }
 
                     MSTAMP(3)   // X on the matrix pipe
-                    if (MFMA_ABL_STOP == 3) { cost[h * 16] += Xs[lane] + G4s[lane] + G1s[lane]; j0 = j1; len = min(j0 & -j0, 16 - j0); continue; }
+                    if (MFMA_ABL_STOP == 3) { cost[h * 16] += Xs[lane] + G4s[lane]; j0 = j1; len = min(j0 & -j0, 16 - j0); continue; }
                     // ---- combine: cost of this lane's planes of the pass ---------------------------------------------
+#ifdef MFMA_REP_COMB
+                    for (int rep = 0; rep < 2; ++rep) {
+#endif
 #pragma unroll
                     for (int j = 0; j < 16; ++j) { xy[j] = opaque_v(xy[j]); fw[j] = opaque_f(fw[j]); fn[j] = opaque_f(fn[j]); }
 #pragma unroll
@@ -502,22 +621,27 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
                                 const float G01x = G4s[(st + 1) * 4], G01z = G4s[(st + 1) * 4 + 2];
                                 const float G10x = G4s[sb * 4], G10y = G4s[sb * 4 + 1];
                                 const float G11x = G4s[(sb + 1) * 4];
-                                const float D2 = G1s[st];
                                 const float fe = 1.0f - fw[j], fs = 1.0f - fn[j];
                                 // |sum_t w_t s_t|^2, separable in the x weights (e, w) and the y weights (s, n) -- the
                                 // expression of sweep_tiled.hip's band combine, term for term
                                 const float ee = fe * fe, ww = fw[j] * fw[j], ew = fe * fw[j];
                                 const float A = ee * G00.x + ww * G01x + 2.0f * ew * G00.y;
                                 const float B = ee * G10x + ww * G11x + 2.0f * ew * G10y;
-                                const float Cq = ee * G00.z + ww * G01z + ew * (G00.w + D2);
+                                const float Cq = ee * G00.z + ww * G01z + ew * G00.w;
                                 const float Q = (fs * fs) * A + (fn[j] * fn[j]) * B + 2.0f * (fs * fn[j]) * Cq;
                                 const float XW = (fs * fe) * X00 + (fs * fw[j]) * X01 + (fn[j] * fe) * X10 + (fn[j] * fw[j]) * X11;
                                 q = (Q - 2.0f * XW) + rr;
                             }
+#ifdef MFMA_REP_COMB
+                            if (rep == 0) cost[h * 16 + j] = opaque_f(div_sigma(q)) * 0.0f + cost[h * 16 + j]; else
+#endif
                             cost[h * 16 + j] = cost[h * 16 + j] + div_sigma(q);
                         }
                         if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two planes' LDS reads in flight at a time
                     }
+#ifdef MFMA_REP_COMB
+                    }
+#endif
                     WAVE_LDS_SYNC();   // the tables and X of this pass are dead
                     MSTAMP(4)   // combine
                     j0 = j1;
@@ -529,6 +653,10 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
         if (MFMA_ABL_STOP == 4) { if (a.depth_out && xlive && kq == 0) { float sm = 0.f; for (int i = 0; i < NHALF * 16; ++i) sm += cost[i]; a.depth_out[(size_t)b * HW + p] = sm; } }
         else if (MFMA_ABL_STOP != 0) { if (a.depth_out && xlive && kq == 0) { float sm = 0.f; for (int i = 0; i < NHALF * 16; ++i) sm += cost[i]; a.depth_out[(size_t)b * HW + p] = sm; } }
         else if (!failed) {
+#ifdef MFMA_REP_EPI
+        for (int rep = 0; rep < 2; ++rep) {
+        cost[0] = opaque_f(cost[0]);
+#endif
 
         // ---- epilogue: cost store, log-softmax over D, expectation ------------------------------------------------
         // (buffer stores: one 32-bit lane offset, the plane as the scalar offset -- 64-bit per-plane pointers would be
@@ -572,6 +700,9 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
             }
             if (a.depth_out && xlive && kq == 0) a.depth_out[(size_t)b * HW + p] = esum / ssum;
         }
+#ifdef MFMA_REP_EPI
+        }
+#endif
         }
     }
     if (failed && lane == 0) {   // the gather kernel redoes the tile
@@ -583,12 +714,20 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
     if (threadIdx.x == 0) s_item[slot == 0 ? 2 : slot - 1] = item_next >= 0 ? resolve(got_own) : -1;   // (the ring slot two ahead = the one behind)
     // the tile after the next is published, everybody is done with this one's slot.  (A raw barrier: __syncthreads() would
     // also wait for this tile's output stores to be acknowledged and for the next tile's pixel loads.)
+#ifdef MFMA_ABL_NOBAR   // timing experiment (races on s_item): what does the per-tile barrier cost?
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     slot = slot == 2 ? 0 : slot + 1;
+#ifdef MFMA_NO_XPREFETCH
+    if (item_next >= 0) load_pixel(item_next, Rr, ray);
+#else
 #pragma unroll
     for (int i = 0; i < NPL; ++i) Rr[i] = Rn[i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) ray[i] = rayn[i];
+#endif
     MSTAMP(10)
     }   // tiles
 #ifdef MFMA_STAMPS
