@@ -134,7 +134,7 @@ def main():
     metrics = torch.tensor([hi - lo, kern_ms, float(depth.mean()), float(torch.isfinite(depth).all())],
                            dtype=torch.float32, device=dev)
     allm = pdist.gather_metrics(metrics).cpu()
-    fallback = pdepth_amd._native.fallback_tiles(hi - lo, cfg["H"], cfg["W"])
+    fallback = pdepth_amd._native.fallback_tiles(hi - lo, cfg["H"], cfg["W"], gather_flag=2 if a.algo == "cells" else 1)
 
     packed_entry = None
     if a.algo == "auto":   # secondary: the same step on features already in the kernels' staging layout

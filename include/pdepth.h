@@ -65,8 +65,7 @@ enum {
     PDEPTH_ALGO_TILED_1 = 2, /* LDS-tiled band kernel, one 16x4 tile per block                          */
     PDEPTH_ALGO_TILED_2 = 3, /* LDS-tiled band kernel, two tiles per block (D <= 64)                    */
     PDEPTH_ALGO_CELLS = 4,   /* cell-list kernels (L2 metric, D <= 128; other inputs: PDEPTH_E_ARG)     */
-    PDEPTH_ALGO_MFMA = 5     /* matrix-pipe kernel (L2 metric, D <= 128, the feature widths it is built for:
-                                ceil(C/4) in {2, 16, 17, 18}; other inputs: PDEPTH_E_ARG)               */
+    PDEPTH_ALGO_MFMA = 5     /* matrix-pipe kernel (L2 metric, D <= 128, C <= 72; other inputs: PDEPTH_E_ARG)   */
 };
 
 /* Geometry + layout of one batched sweep call. */

@@ -290,12 +290,14 @@ def sweep(ref, src, K, R, t, rays, cxcy, d_candi, sigma, metric=METRIC_L2, algo=
 _last_workspace = None
 
 
-def fallback_tiles(B, H, W):
-    """Diagnostics: how many 16x4 tiles of the last ALGO_AUTO sweep were left to the gather kernel."""
+def fallback_tiles(B, H, W, gather_flag=1):
+    """Diagnostics: how many 16x4 tiles of the last sweep were left to the gather kernel.  A tile's flag is the value the
+    gather kernel is launched for: 1 after the tiled and the matrix-pipe kernels; the cell-list path flags 1 = redone by
+    its generic kernel and 2 = gather kernel (pass gather_flag=2 after algo='cells')."""
     if _last_workspace is None:
         return 0
     n = B * ((W + 15) // 16) * ((H + 3) // 4)
-    return int(_last_workspace[: 4 * n].view(torch.int32).sum().item())
+    return int((_last_workspace[: 4 * n].view(torch.int32) == gather_flag).sum().item())
 
 
 def dpv_reduce(logits, d_candi, want_logp=True, want_depth=True, inplace=False):

@@ -51,10 +51,12 @@ pdepth::SweepArgs make_args(const pdepth_sweep_desc* d, const pdepth_camera* cam
     return a;
 }
 
-// Implementation behind ALGO_AUTO for the L2 metric, read once per process: the LDS-tiled band kernel
-// (sweep_tiled.hip, default: the fastest on every BASELINE configuration but the 64x128 model-real one) or, with
-// PDEPTH_SWEEP_IMPL=cells, the cell-list kernels (sweep_cells_fast.hip + sweep_cells.hip), which make no geometric
-// assumption at all and serve as an independent second implementation in the parity suite.
+// Implementation behind ALGO_AUTO for the L2 metric.  Default: the matrix-pipe kernel (sweep_mfma.hip) wherever it is built
+// for the shape, except single-view sweeps of at most 64 planes over large images, where the LDS-tiled band kernel
+// (sweep_tiled.hip) is the faster one on a forward-motion pose (measured, tools/dbg/mfma_matrix.py: the matrix-pipe kernel
+// is 8-30 % faster on 20 of 24 shape x pose combinations, 6-15 % slower on that class with a forward motion).
+// PDEPTH_SWEEP_IMPL=tiled | mfma | cells (read once per process) forces one for AUTO: A/B timing, and the parity suite
+// runs the cell-list kernels as an independent implementation that way.
 enum { IMPL_DEFAULT = 0, IMPL_CELLS = 1, IMPL_TILED = 2, IMPL_MFMA = 3 };
 int sweep_impl() {
     static const int impl = [] {
@@ -100,7 +102,7 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
     if (d->algo == PDEPTH_ALGO_MFMA) {
         const pdepth::SweepArgs probe = make_args(d, cam, ref, src, d_candi);
         if (!pdepth::sweep_mfma_supports(probe))
-            return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_MFMA needs the L2 metric, D <= 128 and ceil(C/4) in {2, 16, 17, 18}", who);
+            return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_MFMA needs the L2 metric, D <= 128 and C <= 72", who);
     }
     if (d->algo == PDEPTH_ALGO_TILED_2 && d->D > 64)
         return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_TILED_2 needs D <= 64", who);
@@ -126,7 +128,10 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
             return launched(pdepth::launch_sweep_tiled_n1(a, workspace, (hipStream_t)stream, packed_ready), who);
         if (d->algo == PDEPTH_ALGO_TILED_2)
             return launched(pdepth::launch_sweep_tiled_n2(a, workspace, (hipStream_t)stream, packed_ready), who);
-        if (d->algo == PDEPTH_ALGO_MFMA || (d->algo == PDEPTH_ALGO_AUTO && sweep_impl() == IMPL_MFMA && pdepth::sweep_mfma_supports(a)))
+        const bool tiled_class = d->V == 1 && d->D <= 64 && (long long)d->H * d->W >= 96 * 1024;
+        if (d->algo == PDEPTH_ALGO_MFMA ||
+            (d->algo == PDEPTH_ALGO_AUTO && pdepth::sweep_mfma_supports(a) &&
+             (sweep_impl() == IMPL_MFMA || (sweep_impl() == IMPL_DEFAULT && !tiled_class))))
             return launched(pdepth::launch_sweep_mfma(a, workspace, (hipStream_t)stream, packed_ready), who);
         // (L1 has no correlation form: always the tiled kernel)
         if (d->algo == PDEPTH_ALGO_CELLS || (d->metric == PDEPTH_METRIC_L2 && d->D <= pdepth::sweep_cells_max_planes() &&

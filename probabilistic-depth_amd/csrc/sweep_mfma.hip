@@ -248,16 +248,21 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
         return steal();
     };
     // item -> batch item, tile
+    // floor(nn / dd) for 0 <= nn < 2^22, 0 < dd: (nn + 0.5) / dd is at least 0.5 / dd away from an integer, far more than the
+    // rounding error of the product with the reciprocal (the integer divide costs ~40 dependent instructions, four per tile)
+    auto fdiv = [](int nn, int dd) { return (int)(((float)nn + 0.5f) * __builtin_amdgcn_rcpf((float)dd)); };
+    const bool small_idx = (long long)ntile * a.B < (1ll << 22);
     auto decode = [&](int item, int& b_, int& tx_, int& ty_) {
         const int q_ = item >> 28, iq = item & 0x0fffffff, band_tiles = band_tiles_of(q_);
-        b_ = iq / band_tiles;
+        b_ = small_idx ? fdiv(iq, band_tiles) : iq / band_tiles;
         const int ti = iq - b_ * band_tiles;
         int tile = band_first_of(q_) + ti;
         if (colmajor) {
-            const int band_rows = qq / tiles_x;
-            tile = (q_ * band_rows + ti % band_rows) * tiles_x + ti / band_rows;
+            const int band_rows = qq / tiles_x, tc = small_idx ? fdiv(ti, band_rows) : ti / band_rows;
+            tile = (q_ * band_rows + (ti - tc * band_rows)) * tiles_x + tc;
         }
-        tx_ = tile % tiles_x; ty_ = tile / tiles_x;
+        ty_ = small_idx ? fdiv(tile, tiles_x) : tile / tiles_x;
+        tx_ = tile - ty_ * tiles_x;
     };
     // this wave's pixel of a tile (sub-block = wave) and the loads that do not depend on anything computed: the pixel's ray
     // and its reference features -- lane (n, kq): pixel n, channel slice kq, the B operands of every MFMA of the sub-block.
@@ -315,10 +320,6 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
     const int item_next = __builtin_amdgcn_readfirstlane(s_item[slot == 2 ? 0 : slot + 1]);
     int got_own = 0;
     if (threadIdx.x == 0 && item_next >= 0 && !own_done) got_own = atomicAdd(&queue[xcd], 1);   // (issued now, looked at when the tile is done)
-    float Rn[NPL], rayn[3];
-#ifndef MFMA_NO_XPREFETCH
-    if (item_next >= 0) load_pixel(item_next, Rn, rayn);
-#endif
     const int sub = wave;
     int b, tx, ty;
     decode(item, b, tx, ty);
@@ -471,6 +472,16 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
                     }
                     MCOUNT(6, 1)    // passes
                     MCOUNT(8, nb)   // blocks
+                    // The planes of this pass are done with their cells: from here on xy[j] holds their two X / Gram slots
+                    // (top row | bottom row << 16; slot = x0 + rowoff of the texel row).  Computed here, not in the combine:
+                    // the LDS round trip to the row table rides under the block loads of the matrix phase.
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        if (j >= j0 && j < j1 && xy[j] != NO_CELL) {
+                            const int r = cell_y(xy[j]) - ybase, cxx = cell_x(xy[j]);
+                            xy[j] = (cxx + rowoff[r]) | ((cxx + rowoff[r + 1]) << 16);
+                        }
+                    }
                     if (MFMA_ABL_STOP == 2) { cost[h * 16] += (float)(nb + rowoff[lane & 7] + blk[lane & 7]); j0 = j1; len = min(j0 & -j0, 16 - j0); continue; }
 
                     // ---- X = <r, s> for the blocks of the pass, on the matrix pipe -----------------------------------
@@ -611,10 +622,11 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         if (j >= j0 && j < j1) {
-                            float q = rr;
+                            // (no tap inside the image: |r|^2 -- and NaN where the position itself is not finite, as the
+                            //  reference's weights inf - floor(inf) make it)
+                            float q = rr + (fw[j] + fn[j]) * 0.0f;
                             if (xy[j] != NO_CELL) {
-                                const int r = cell_y(xy[j]) - ybase, cxx = cell_x(xy[j]);
-                                const int st = cxx + rowoff[r], sb = cxx + rowoff[r + 1];
+                                const int st = xy[j] & 0xffff, sb = xy[j] >> 16;
                                 const float* xr = &Xs[n * XSTRIDE];
                                 const float X00 = xr[st], X01 = xr[st + 1], X10 = xr[sb], X11 = xr[sb + 1];
                                 const v4f G00 = *reinterpret_cast<const v4f*>(&G4s[st * 4]);
@@ -622,22 +634,26 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
                                 const float G10x = G4s[sb * 4], G10y = G4s[sb * 4 + 1];
                                 const float G11x = G4s[(sb + 1) * 4];
                                 const float fe = 1.0f - fw[j], fs = 1.0f - fn[j];
-                                // |sum_t w_t s_t|^2, separable in the x weights (e, w) and the y weights (s, n) -- the
-                                // expression of sweep_tiled.hip's band combine, term for term
-                                const float ee = fe * fe, ww = fw[j] * fw[j], ew = fe * fw[j];
-                                const float A = ee * G00.x + ww * G01x + 2.0f * ew * G00.y;
-                                const float B = ee * G10x + ww * G11x + 2.0f * ew * G10y;
-                                const float Cq = ee * G00.z + ww * G01z + ew * G00.w;
-                                const float Q = (fs * fs) * A + (fn[j] * fn[j]) * B + 2.0f * (fs * fn[j]) * Cq;
-                                const float XW = (fs * fe) * X00 + (fs * fw[j]) * X01 + (fn[j] * fe) * X10 + (fn[j] * fw[j]) * X11;
-                                q = (Q - 2.0f * XW) + rr;
+                                // |sum_t w_t s_t|^2, separable in the x weights (e, w) and the y weights (s, n); fused
+                                // multiply-adds (each term rounds once: at least as close to the exact value as the unfused form)
+                                const float ee = fe * fe, ww = fw[j] * fw[j], ew2 = 2.0f * (fe * fw[j]);
+                                const float A = __builtin_fmaf(ee, G00.x, __builtin_fmaf(ww, G01x, ew2 * G00.y));   // top row
+                                const float B = __builtin_fmaf(ee, G10x, __builtin_fmaf(ww, G11x, ew2 * G10y));     // bottom row
+                                const float Cq = __builtin_fmaf(ee, G00.z, __builtin_fmaf(ww, G01z, (fe * fw[j]) * G00.w));   // cross rows
+                                const float Q = __builtin_fmaf(fs * fs, A, __builtin_fmaf(fn[j] * fn[j], B, (2.0f * (fs * fn[j])) * Cq));
+                                const float XW = __builtin_fmaf(fs * fe, X00, __builtin_fmaf(fs * fw[j], X01,
+                                                 __builtin_fmaf(fn[j] * fe, X10, (fn[j] * fw[j]) * X11)));
+                                q = __builtin_fmaf(-2.0f, XW, Q) + rr;
                             }
 #ifdef MFMA_REP_COMB
                             if (rep == 0) cost[h * 16 + j] = opaque_f(div_sigma(q)) * 0.0f + cost[h * 16 + j]; else
 #endif
                             cost[h * 16 + j] = cost[h * 16 + j] + div_sigma(q);
                         }
-                        if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two planes' LDS reads in flight at a time
+#ifndef MFMA_COMB_GROUP
+#define MFMA_COMB_GROUP 2
+#endif
+                        if ((j & (MFMA_COMB_GROUP - 1)) == MFMA_COMB_GROUP - 1) __builtin_amdgcn_sched_barrier(0);   // so many planes' LDS reads in flight at a time
                     }
 #ifdef MFMA_REP_COMB
                     }
@@ -720,14 +736,7 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
     slot = slot == 2 ? 0 : slot + 1;
-#ifdef MFMA_NO_XPREFETCH
-    if (item_next >= 0) load_pixel(item_next, Rr, ray);
-#else
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) Rr[i] = Rn[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) ray[i] = rayn[i];
-#endif
+    if (item_next >= 0) load_pixel(item_next, Rr, ray);   // (the next tile's pixel loads fly over the barrier and the tile setup)
     MSTAMP(10)
     }   // tiles
 #ifdef MFMA_STAMPS
@@ -751,13 +760,24 @@ hipError_t launch_npl(const SweepArgs& a, const float4* packed, int* flags, int*
 
 }  // namespace
 
-// shapes the matrix-pipe kernel is instantiated for: L2, D <= 128, ceil(C/4) in the list below
+// shapes the matrix-pipe kernel is built for: L2, D <= 128, C <= 72 (one instantiation per ceil(C/4): the reference
+// features of a pixel and the texel features of a block live in registers)
+constexpr int MFMA_MAX_NPL = 18;
 bool sweep_mfma_supports(const SweepArgs& a) {
     const int npl = (a.C + 3) / 4;
     const long long hw = (long long)a.H * a.W;
-    return a.metric == 0 && a.D <= 128 && (npl == 17 || npl == 16 || npl == 2 || npl == 18) && a.W <= 32760 && a.H <= 32760 &&
-           hw * a.D * 4 < (1ll << 31) && hw * a.C * 4 < (1ll << 31) && hw * (npl + 2) * 16 < (1ll << 31);
+    return a.metric == 0 && a.D <= 128 && npl <= MFMA_MAX_NPL && a.W <= 32760 && a.H <= 32760 &&
+           hw * a.D * 4 < (1ll << 31) && hw * a.C * 4 < (1ll << 31) && hw * (npl + 2) * 16 < (1ll << 31) && hw * 12 < (1ll << 31);
 }
+
+namespace {
+template <int NPL>
+hipError_t launch_by_npl(int npl, const SweepArgs& a, const float4* packed, int* flags, int* queue, int tiles_x, int tiles, hipStream_t stream) {
+    if (npl == NPL) return launch_npl<NPL>(a, packed, flags, queue, tiles_x, tiles, stream);
+    if constexpr (NPL > 1) return launch_by_npl<NPL - 1>(npl, a, packed, flags, queue, tiles_x, tiles, stream);
+    return hipErrorInvalidValue;
+}
+}  // namespace
 
 // Launches the pre-pass (unless the workspace is already packed), the matrix-pipe kernel, then the gather kernel on the
 // tiles it flagged.  Workspace layout as the tiled kernel's.
@@ -768,13 +788,7 @@ hipError_t launch_sweep_mfma(const SweepArgs& a, void* workspace, hipStream_t st
     int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + sweep_ws_flag_only_bytes(a.B, a.H, a.W));
     hipError_t e = packed_ready ? clear_sweep_flags(a, workspace, stream) : launch_pack_c4(a, workspace, stream);
     if (e != hipSuccess) return e;
-    switch ((a.C + 3) / 4) {
-        case 17: e = launch_npl<17>(a, packed, flags, queue, tiles_x, tiles, stream); break;
-        case 16: e = launch_npl<16>(a, packed, flags, queue, tiles_x, tiles, stream); break;
-        case 18: e = launch_npl<18>(a, packed, flags, queue, tiles_x, tiles, stream); break;
-        case 2: e = launch_npl<2>(a, packed, flags, queue, tiles_x, tiles, stream); break;
-        default: return hipErrorInvalidValue;
-    }
+    e = launch_by_npl<MFMA_MAX_NPL>((a.C + 3) / 4, a, packed, flags, queue, tiles_x, tiles, stream);
     if (e != hipSuccess) return e;
     SweepArgs ag = a;
     ag.packed_src = packed;

@@ -52,6 +52,19 @@ def test_reference_checkpoint_loads_through_the_trainers_zip():
     with pytest.raises(RuntimeError, match="Missing key"):
         model.load_state_dict(new_weights)
 
+def test_truncated_checkpoint_of_this_framework_is_rejected():
+    """Only a checkpoint with NONE of the residual 3-D blocks (a reference checkpoint) passes the strict load without
+    them; one that holds some of them is truncated and must raise."""
+    model = get_model(synth.default_cfg("default_feedback"), 0)
+    sd = model.state_dict()
+    dres = [k for k in sd if ".dres_modules." in k and not k.endswith("num_batches_tracked")]
+    assert len(dres) > 4
+    truncated = {k: v for k, v in sd.items() if k not in set(dres[len(dres) // 2:])}
+    with pytest.raises(RuntimeError):
+        model.load_state_dict(truncated)
+    model.load_state_dict({k: v for k, v in sd.items() if ".dres_modules." not in k})   # the reference-checkpoint case
+
+
 
 def test_hip_ops_refuse_autograd_inputs():
     """The ctypes kernels have no backward: an input that requires grad must raise instead of silently cutting

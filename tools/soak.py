@@ -114,7 +114,9 @@ def main():
             continue
         d = {kk: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for kk, v in b.items()}
         metric = "L1" if case % 7 == 3 else "L2"
-        algo = ("tiled1", "tiled2", "cells")[case % 3]
+        algo = ("tiled1", "tiled2", "cells", "mfma")[case % 4]
+        if algo == "mfma" and (metric == "L1" or s["D"] > 128 or s["C"] > 72):
+            algo = "tiled1"
         if algo == "cells" and (metric == "L1" or s["D"] > 128):
             algo = "tiled1"
         if algo == "tiled2" and s["D"] > 64:
