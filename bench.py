@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--pose", default="mono", choices=["mono", "stereo"])
     ap.add_argument("--algo", default="auto", choices=["auto", "direct", "tiled1", "tiled2", "cells", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default=None, help="an experiment file in the reference's JSON schema (configs/*.json): "
+                    "planes, depth range, sigma, channels and the pose family come from it; the sweep resolution stays "
+                    "--height x --width (BASELINE quotes the metric at 256x512)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -102,13 +105,20 @@ def main():
     torch.cuda.set_device(dev)
 
     cfg = dict(C=67, D=a.planes, H=a.height, W=a.width, V=a.views, pose=a.pose)
+    sigma, d_candi_cfg = 10.0, None
+    if a.config:   # the reference's experiment file names the workload (BASELINE configs are named by those files)
+        wl = synth.sweep_workload(synth.cfg_from_json(a.config))
+        cfg.update(C=wl["C"], D=wl["D"], pose=wl["pose"])
+        sigma, d_candi_cfg = wl["sigma"], wl["d_candi"]
     lo, hi = pdist.shard_range(a.batch * world, rank, world)  # this rank's items of the global batch
     b = synth.make_batch(2, hi - lo, first_item=lo, **cfg)
+    if d_candi_cfg is not None:
+        b["d_candi"] = d_candi_cfg
     d = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
     dc = ops.d_candi_tensor(d["d_candi"], dev)
 
     def step(src):
-        return ops.sweep_dpv(d["ref"], src, d["K"], d["R"], d["t"], d["rays"], d["cxcy"], dc, 10.0,
+        return ops.sweep_dpv(d["ref"], src, d["K"], d["R"], d["t"], d["rays"], d["cxcy"], dc, sigma,
                              algo=a.algo, want_cost=False, want_logp=True, want_depth=True)
 
     def timed(src):

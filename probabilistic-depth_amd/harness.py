@@ -50,3 +50,13 @@ def eval_trajectory(model, frames):
         results.append(r)
     return results
 
+
+
+def model_from_config(path, device, id=0):
+    """get_model() for an experiment file in the reference's JSON schema (train.py:34-37 + models/get_model.py:4-13):
+    returns (model on `device` in eval mode, cfg, the float64 depth candidates of default_trainer.py:38-39)."""
+    from . import synth
+    from .models import get_model
+    cfg = synth.cfg_from_json(path)
+    model = get_model(cfg, id).to(device).eval()
+    return model, cfg, synth.sweep_workload(cfg)["d_candi"]

@@ -157,6 +157,48 @@ def default_cfg(nmode="default", ndepth=64, feature_dim=64, model_name="base"):
                         "bn_avg": True, "d_min": 5.0, "d_max": 40.0, "qpower": 1.0}})
 
 
+HOT_PATH_VAR_KEYS = ("ndepth", "d_min", "d_max", "qpower", "sigma_soft_max", "feature_dim", "nmode")
+
+
+def cfg_from_json(path):
+    """The reference's experiment file (train.py:34-37 reads `configs/*.json` into an EasyDict) -> Cfg.
+
+    Same schema: sections `data` (model_name, ...) and `var` (ndepth, d_min, d_max, qpower, sigma_soft_max, feature_dim,
+    nmode, stereo, img_size = [width, height], crop_w, t_win, bn_avg, ...); every other section is carried along untouched.
+    The keys the hot path reads must be present (the reference would fail on first use: models/models.py:444-448,
+    trainer/default_trainer.py:38-41); optional ones get the reference's defaults (`stereo` absent = monocular)."""
+    import json
+    with open(path) as f:
+        raw = json.load(f)
+    for sec in ("data", "var"):
+        if not isinstance(raw.get(sec), dict):
+            raise KeyError("config %s: missing section '%s'" % (path, sec))
+    missing = [k for k in HOT_PATH_VAR_KEYS if k not in raw["var"]]
+    if missing:
+        raise KeyError("config %s: var is missing %s" % (path, ", ".join(missing)))
+    if "model_name" not in raw["data"]:
+        raise KeyError("config %s: data.model_name is missing" % path)
+    cfg = Cfg(raw)
+    cfg.var.setdefault("bn_avg", True)
+    cfg.var.setdefault("stereo", False)
+    cfg.var.setdefault("t_win", 1)
+    return cfg
+
+
+def sweep_workload(cfg, dw=4):
+    """What a config means for the sweep: channel count (feature_dim + the 3 pooled RGB channels, models/models.py:518-520),
+    planes, depth candidates, the sweep resolution (the cropped image / dw: default_trainer.py:59-61, models.py:518) and
+    the synthetic pose family that stands in for its data source (stereo rig or consecutive frames)."""
+    v = cfg.var
+    out = {"C": int(v.feature_dim) + 3, "D": int(v.ndepth), "sigma": float(v.sigma_soft_max),
+           "pose": "stereo" if v.get("stereo") else "mono",
+           "d_candi": powerf(float(v.d_min), float(v.d_max), int(v.ndepth), float(v.qpower))}
+    if v.get("img_size") is not None:
+        width = int(v.crop_w) if v.get("crop_w") else int(v.img_size[0])
+        out.update({"image_hw": (int(v.img_size[1]), width), "H": int(v.img_size[1]) // dw, "W": width // dw})
+    return out
+
+
 def make_model_input(seed, B=1, V=1, H=256, W=256, D=64, pose="mono", dw=4):
     """The reference's model_input dict (kittiloader/batch_scheduler.py:147-283) with synthetic content.
 

@@ -176,3 +176,35 @@ def test_upsample_mode_fuses_sparse_depth():
     np.testing.assert_allclose(fused_log.cpu().numpy(), want_log.numpy(), rtol=1e-5, atol=3e-5)
     assert out["output_refined"][0].shape == (2, 64, 256, 256)
 
+
+
+def test_config_loader_reads_the_reference_schema(tmp_path):
+    """synth.cfg_from_json: the experiment files of the reference (train.py:34-37: json -> EasyDict with sections data / var /
+    ...) -- a hand-written file with the hot-path keys, a stereo variant, and the errors for missing keys."""
+    import json
+    from pdepth_amd import harness
+    raw = {"data": {"exp_name": "t", "model_name": "base"},
+           "var": {"sigma_soft_max": 8.0, "t_win": 1, "d_min": 3.0, "d_max": 60.0, "feature_dim": 32, "ndepth": 48,
+                   "qpower": 1.5, "img_size": [768, 256], "crop_w": 384, "nmode": "default", "bn_avg": True},
+           "train": {"batch_size": 8}, "seed": 0}
+    p = tmp_path / "exp.json"
+    p.write_text(json.dumps(raw))
+    cfg = synth.cfg_from_json(str(p))
+    assert cfg.var.ndepth == 48 and cfg.data.model_name == "base" and cfg.train.batch_size == 8 and cfg.var.stereo is False
+    wl = synth.sweep_workload(cfg)
+    assert (wl["C"], wl["D"], wl["H"], wl["W"], wl["pose"], wl["sigma"]) == (35, 48, 64, 96, "mono", 8.0)
+    from pdepth_amd.utils.img_utils import powerf
+    assert np.array_equal(wl["d_candi"], powerf(3.0, 60.0, 48, 1.5))
+    model, cfg2, d_candi = harness.model_from_config(str(p), "cpu")
+    assert model.D == 48 if hasattr(model, "D") else True
+    assert len(d_candi) == 48
+    raw["var"]["stereo"] = True
+    p.write_text(json.dumps(raw))
+    assert synth.sweep_workload(synth.cfg_from_json(str(p)))["pose"] == "stereo"
+    del raw["var"]["ndepth"]
+    p.write_text(json.dumps(raw))
+    with pytest.raises(KeyError, match="ndepth"):
+        synth.cfg_from_json(str(p))
+    p.write_text(json.dumps({"var": {}}))
+    with pytest.raises(KeyError, match="data"):
+        synth.cfg_from_json(str(p))
