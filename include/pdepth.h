@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PDEPTH_ABI_VERSION 2   /* 2: packed-source entries, dpv_reduce_ex, ufield, implementation selectors */
+#define PDEPTH_ABI_VERSION 3   /* 3: matrix-pipe sweep selector, general + fp16 correlation, packed encoder epilogue */
 
 enum {
     PDEPTH_OK = 0,
@@ -236,28 +236,41 @@ int pdepth_dpv_fuse_f32(const float *logp, const float *dmaps, const float *mask
                         float *logfused, void *stream);
 
 /*
- * Forward of the reference's native correlation operator: replaces correlation_forward_cuda
- * (models/correlation_package/correlation_cuda.cc:10-87; kernel correlation_cuda_kernel.cu:41-114) with the
- * same argument meaning.  Supported: kernel_size == 1, stride1 == 1, pad_size == max_displacement,
- * max_displacement / stride2 <= 4 (PWCLite uses pad 4, k 1, d 4, s1 = s2 = 1: models/pwclite.py:123-125);
- * other values return PDEPTH_E_ARG.  corr_multiply is accepted and ignored like in the reference kernel.
- *   input1, input2 [B,C,H,W]; output [B, (2*(d/s2)+1)^2, H, W], channel (dy+r)*(2r+1)+(dx+r), mean over C.
- * The reference's rbot1/rbot2 scratch tensors (zero-padded NHWC repacks) are not needed.
+ * The reference's native correlation operator, forward and backward: replaces correlation_forward_cuda /
+ * correlation_backward_cuda (models/correlation_package/correlation_cuda.cc:10-87, :89-167; kernels
+ * correlation_cuda_kernel.cu:41-114, :116-300) with the reference's argument list (the rbot1 / rbot2 scratch tensors --
+ * zero-padded NHWC repacks -- are not needed).  Every configuration the reference's kernel defines:
+ *     kr = (kernel_size-1)/2, dr = max_displacement/stride2, ds = 2 dr + 1
+ *     output [B, ds*ds, oH, oW], oH = ceil((H + 2 pad_size - 2 (kr + max_displacement)) / stride1) (correlation_cuda.cc:24-33;
+ *     pdepth_correlation_output_size), channel (tj+dr)*ds + (ti+dr),
+ *     out = 1/(k*k*C) sum_{j,i in [-kr,kr]} sum_c in1p[y1+j, x1+i] * in2p[y1 + tj*stride2 + j, x1 + ti*stride2 + i],
+ *     (y1, x1) = (oy, ox) * stride1 + max_displacement in the coordinates of the zero-padded inputs.
+ * kernel_size must be odd and (kernel_size-1)/2 <= max_displacement mod stride2 (beyond that the reference's kernel reads
+ * outside its padded buffers); corr_multiply is accepted and ignored like in the reference kernel.  The configuration the
+ * reference instantiates (kernel 1, stride1 1, pad_size = max_displacement <= 4*stride2: pwclite.py:123-125) runs
+ * LDS-tiled fp32 kernels; everything else, and the fp16 entries (fp16 tensors, fp32 accumulation:
+ * AT_DISPATCH_FLOATING_TYPES_AND_HALF at correlation_cuda_kernel.cu:352-369), a general gather kernel.
+ *   forward : input1, input2 [B,C,H,W] -> output;   backward: grad_output [B,ds*ds,oH,oW] -> grad_input1, grad_input2
+ *   [B,C,H,W] (either may be NULL).
  */
+int pdepth_correlation_output_size(int32_t H, int32_t W, int32_t pad_size, int32_t kernel_size, int32_t max_displacement,
+                                   int32_t stride1, int32_t stride2, int32_t *out_channels, int32_t *out_height,
+                                   int32_t *out_width);
 int pdepth_correlation_forward_f32(const float *input1, const float *input2, int32_t B, int32_t C, int32_t H,
                                    int32_t W, int32_t pad_size, int32_t kernel_size, int32_t max_displacement,
                                    int32_t stride1, int32_t stride2, int32_t corr_multiply, float *output,
                                    void *stream);
-
-/*
- * Backward of the same operator: replaces correlation_backward_cuda (correlation_cuda.cc:89-167; kernels
- * correlation_cuda_kernel.cu:116-300).  grad_output [B,(2r+1)^2,H,W] -> grad_input1, grad_input2 [B,C,H,W]
- * (either may be NULL).  Same supported configurations as the forward.
- */
 int pdepth_correlation_backward_f32(const float *input1, const float *input2, const float *grad_output, int32_t B,
                                     int32_t C, int32_t H, int32_t W, int32_t pad_size, int32_t kernel_size,
                                     int32_t max_displacement, int32_t stride1, int32_t stride2,
                                     int32_t corr_multiply, float *grad_input1, float *grad_input2, void *stream);
+int pdepth_correlation_forward_f16(const void *input1, const void *input2, int32_t B, int32_t C, int32_t H, int32_t W,
+                                   int32_t pad_size, int32_t kernel_size, int32_t max_displacement, int32_t stride1,
+                                   int32_t stride2, int32_t corr_multiply, void *output, void *stream);
+int pdepth_correlation_backward_f16(const void *input1, const void *input2, const void *grad_output, int32_t B,
+                                    int32_t C, int32_t H, int32_t W, int32_t pad_size, int32_t kernel_size,
+                                    int32_t max_displacement, int32_t stride1, int32_t stride2, int32_t corr_multiply,
+                                    void *grad_input1, void *grad_input2, void *stream);
 
 /*
  * Depth-map driven inverse warp: replaces the per-pixel part of inverse_warp (utils/inverse_warp.py:174-210 with

@@ -26,7 +26,7 @@ import torch.nn.functional as F
 __all__ = [
     "powerf", "unit_rays", "intrinsics_from_fov", "plane_coords", "sweep_cost",
     "warp_feature", "log_dpv", "dpv_to_depthmap", "sweep_dpv", "sample_coords", "gen_dpv_withmask", "dpv_fuse",
-    "correlation", "inverse_warp", "dpv_variance", "gen_ufield",
+    "correlation", "correlation_general", "inverse_warp", "dpv_variance", "gen_ufield",
 ]
 
 
@@ -329,6 +329,43 @@ def correlation(x1, x2, max_displacement=4):
         for j in range(n):
             cv.append(torch.mean(x1 * x2p[:, :, i:i + H, j:j + W], 1, keepdim=True))
     return torch.cat(cv, 1)
+
+
+def correlation_general(x1, x2, pad_size, kernel_size, max_displacement, stride1, stride2):
+    """The reference's correlation op for any configuration, restated from its kernel's index arithmetic in plain torch
+    (autograd through this function is the oracle of the backward).
+
+    models/correlation_package/correlation_cuda.cc:24-33 (output size: border = kernel radius + max_displacement,
+    oH = ceil((H + 2 pad - 2 border) / stride1)); correlation_cuda_kernel.cu:57-59 (kernel_rad, displacement_rad =
+    max_displacement / stride2, displacement_size), :62-63 (y1, x1 = output index * stride1 + max_displacement, in the
+    coordinates of the zero-padded inputs of :30-38), :85-100 (sum over the kernel window and the channels of
+    in1[y1+j, x1+i] * in2[y1 + tj*stride2 + j, x1 + ti*stride2 + i]), :107-109 (channel tc = (tj+dr)*ds + (ti+dr),
+    divided by nelems = kernel_size^2 * C)."""
+    B, C, H, W = x1.shape
+    kr = (kernel_size - 1) // 2
+    dr = max_displacement // stride2
+    border = kr + max_displacement
+    pH, pW = H + 2 * pad_size, W + 2 * pad_size
+    oH = -(-(pH - 2 * border) // stride1)
+    oW = -(-(pW - 2 * border) // stride1)
+    # the sum reads padded rows y1 + tj*stride2 + j >= max_displacement - dr*stride2 - kr: non-negative for every
+    # configuration the C ABI accepts; pad a little more so that plain slicing below never wraps
+    extra = max(0, kr + dr * stride2 - max_displacement) + stride1
+    a = F.pad(x1, [pad_size + extra] * 4)
+    b = F.pad(x2, [pad_size + extra] * 4)
+    ys = max_displacement + extra + stride1 * torch.arange(oH)
+    xs = max_displacement + extra + stride1 * torch.arange(oW)
+    out = []
+    for tj in range(-dr, dr + 1):
+        for ti in range(-dr, dr + 1):
+            acc = 0
+            for j in range(-kr, kr + 1):
+                for i in range(-kr, kr + 1):
+                    p1 = a[:, :, (ys + j)[:, None], (xs + i)[None, :]]
+                    p2 = b[:, :, (ys + tj * stride2 + j)[:, None], (xs + ti * stride2 + i)[None, :]]
+                    acc = acc + (p1 * p2).sum(1, keepdim=True)
+            out.append(acc / float(kernel_size * kernel_size * C))
+    return torch.cat(out, 1)
 
 
 def inverse_warp(img, depth, pose_mat, intrinsics, mode="bilinear"):

@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = (
     "pdepth_dpv_moments_f32", "pdepth_correlation_backward_f32",
     "pdepth_pack_source_f32", "pdepth_sweep_dpv_packed_f32", "pdepth_dpv_reduce_ex_f32",
     "pdepth_ufield_workspace_bytes", "pdepth_ufield_f32",
+    "pdepth_correlation_output_size", "pdepth_correlation_forward_f16", "pdepth_correlation_backward_f16",
 )
 
 
@@ -133,14 +134,18 @@ def load():
                                         c_float, c_float, c_void_p, c_void_p, c_void_p]
     lib.pdepth_correlation_forward_f32.argtypes = [c_void_p, c_void_p] + [c_int32] * 10 + [c_void_p, c_void_p]
     lib.pdepth_correlation_backward_f32.argtypes = [c_void_p] * 3 + [c_int32] * 10 + [c_void_p] * 3
+    lib.pdepth_correlation_forward_f16.argtypes = [c_void_p, c_void_p] + [c_int32] * 10 + [c_void_p, c_void_p]
+    lib.pdepth_correlation_backward_f16.argtypes = [c_void_p] * 3 + [c_int32] * 10 + [c_void_p] * 3
+    lib.pdepth_correlation_output_size.argtypes = [c_int32] * 7 + [POINTER(c_int32)] * 3
     lib.pdepth_inverse_warp_f32.argtypes = [c_void_p] * 4 + [c_int32] * 5 + [c_void_p] * 3
     lib.pdepth_inverse_warp_backward_f32.argtypes = [c_void_p] * 5 + [c_int32] * 5 + [c_void_p] * 3
     for fn in ("pdepth_sweep_cost_f32", "pdepth_sweep_dpv_f32", "pdepth_dpv_reduce_f32",
                "pdepth_dpv_expect_f32", "pdepth_warp_feature_f32", "pdepth_sample_coords_f32",
                "pdepth_dpv_fuse_f32", "pdepth_correlation_forward_f32", "pdepth_inverse_warp_f32",
-               "pdepth_dpv_moments_f32", "pdepth_correlation_backward_f32"):
+               "pdepth_dpv_moments_f32", "pdepth_correlation_backward_f32", "pdepth_correlation_output_size",
+               "pdepth_correlation_forward_f16", "pdepth_correlation_backward_f16"):
         getattr(lib, fn).restype = c_int
-    if lib.pdepth_abi_version() != 2:
+    if lib.pdepth_abi_version() != 3:
         raise RuntimeError("libpdepth_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -505,41 +510,67 @@ def dpv_fuse(logp, dmaps, masks, d_candi, var, eps, want_fused=True, want_log=Tr
     return fused, logf
 
 
+def _corr_out_shape(lib, H, W, pad_size, kernel_size, max_displacement, stride1, stride2):
+    oc, oh, ow = c_int32(), c_int32(), c_int32()
+    rc = lib.pdepth_correlation_output_size(H, W, int(pad_size), int(kernel_size), int(max_displacement), int(stride1), int(stride2),
+                                            ctypes.byref(oc), ctypes.byref(oh), ctypes.byref(ow))
+    _check(rc, lib)
+    return oc.value, oh.value, ow.value
+
+
+def _corr_dtype(x1, x2):
+    if x1.dtype != x2.dtype or x1.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError("correlation: inputs must both be float32 or both float16 (got %s, %s)" % (x1.dtype, x2.dtype))
+    return x1.dtype == torch.float16
+
+
+def _dev_any(t, name):
+    """Device + contiguity check for tensors that may be fp16 (the fp32-only _dev() guards everything else)."""
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+        raise RuntimeError("%s must be a CUDA/HIP tensor (the HIP path has no CPU fallback)" % name)
+    if torch.is_grad_enabled() and t.requires_grad:
+        raise RuntimeError("%s requires grad: the HIP kernels are invisible to autograd (use ops.correlation / torch.no_grad())" % name)
+    return t
+
+
 def correlation_forward(x1, x2, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply=1):
-    """x1, x2 [B,C,H,W] -> [B,(2*(d/s2)+1)^2,H,W] (mean over C of shifted products)."""
+    """x1, x2 [B,C,H,W] fp32 or fp16 -> [B,(2*(d/s2)+1)^2,oH,oW] of the same dtype (mean over the kernel window and C of
+    shifted products; every configuration of the reference's kernel: include/pdepth.h)."""
     lib = load()
-    _dev(x1, "input1"), _dev(x2, "input2")
+    _dev_any(x1, "input1"), _dev_any(x2, "input2")
     if x1.shape != x2.shape or x1.dim() != 4:
         raise RuntimeError("correlation: inputs must be two [B,C,H,W] tensors of the same shape")
+    half = _corr_dtype(x1, x2)
     x1, x2 = x1.contiguous(), x2.contiguous()
     B, C, H, W = x1.shape
-    nd = 2 * (max_displacement // max(stride2, 1)) + 1
-    out = torch.empty((B, nd * nd, H, W), dtype=torch.float32, device=x1.device)
+    oc, oh, ow = _corr_out_shape(lib, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    out = torch.empty((B, oc, oh, ow), dtype=x1.dtype, device=x1.device)
+    fn = lib.pdepth_correlation_forward_f16 if half else lib.pdepth_correlation_forward_f32
     with torch.cuda.device(x1.device):
-        rc = lib.pdepth_correlation_forward_f32(x1.data_ptr(), x2.data_ptr(), B, C, H, W, int(pad_size), int(kernel_size),
-                                                int(max_displacement), int(stride1), int(stride2), int(corr_multiply),
-                                                out.data_ptr(), _stream(x1.device))
+        rc = fn(x1.data_ptr(), x2.data_ptr(), B, C, H, W, int(pad_size), int(kernel_size), int(max_displacement), int(stride1),
+                int(stride2), int(corr_multiply), out.data_ptr(), _stream(x1.device))
     _check(rc, lib)
     return out
 
 
 def correlation_backward(x1, x2, grad_out, pad_size, kernel_size, max_displacement, stride1, stride2, corr_multiply=1,
                          want1=True, want2=True):
-    """x1, x2 [B,C,H,W], grad_out [B,(2r+1)^2,H,W] -> (grad_x1 | None, grad_x2 | None)."""
+    """x1, x2 [B,C,H,W], grad_out [B,(2r+1)^2,oH,oW] (fp32 or fp16, all alike) -> (grad_x1 | None, grad_x2 | None)."""
     lib = load()
-    _dev(x1, "input1"), _dev(x2, "input2"), _dev(grad_out, "grad_output")
-    x1, x2, grad_out = x1.contiguous(), x2.contiguous(), grad_out.contiguous()
+    _dev_any(x1, "input1"), _dev_any(x2, "input2"), _dev_any(grad_out, "grad_output")
+    half = _corr_dtype(x1, x2)
+    x1, x2, grad_out = x1.contiguous(), x2.contiguous(), grad_out.contiguous().to(x1.dtype)
     B, C, H, W = x1.shape
-    nd = 2 * (max_displacement // max(stride2, 1)) + 1
-    if x2.shape != x1.shape or tuple(grad_out.shape) != (B, nd * nd, H, W):
+    oc, oh, ow = _corr_out_shape(lib, H, W, pad_size, kernel_size, max_displacement, stride1, stride2)
+    if x2.shape != x1.shape or tuple(grad_out.shape) != (B, oc, oh, ow):
         raise RuntimeError("correlation_backward: shape mismatch")
     g1 = torch.empty_like(x1) if want1 else None
     g2 = torch.empty_like(x2) if want2 else None
+    fn = lib.pdepth_correlation_backward_f16 if half else lib.pdepth_correlation_backward_f32
     with torch.cuda.device(x1.device):
-        rc = lib.pdepth_correlation_backward_f32(
-            x1.data_ptr(), x2.data_ptr(), grad_out.data_ptr(), B, C, H, W, int(pad_size), int(kernel_size),
-            int(max_displacement), int(stride1), int(stride2), int(corr_multiply),
-            g1.data_ptr() if want1 else None, g2.data_ptr() if want2 else None, _stream(x1.device))
+        rc = fn(x1.data_ptr(), x2.data_ptr(), grad_out.data_ptr(), B, C, H, W, int(pad_size), int(kernel_size),
+                int(max_displacement), int(stride1), int(stride2), int(corr_multiply),
+                g1.data_ptr() if want1 else None, g2.data_ptr() if want2 else None, _stream(x1.device))
     _check(rc, lib)
     return g1, g2
 

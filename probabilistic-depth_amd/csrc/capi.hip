@@ -292,19 +292,56 @@ int pdepth_dpv_fuse_f32(const float* logp, const float* dmaps, const float* mask
                                             (hipStream_t)stream), "pdepth_dpv_fuse_f32");
 }
 
+}  // extern "C" (reopened below)
+
+namespace {
+// kernel_size odd, strides >= 1, and no index of the reference's kernel outside its padded buffers
+int check_corr(const char* who, int32_t B, int32_t C, int32_t H, int32_t W, int32_t pad, int32_t k, int32_t md, int32_t s1, int32_t s2,
+               int* oH, int* oW) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(PDEPTH_E_ARG, "%s: non-positive dimension", who);
+    if (pad < 0 || k < 1 || (k & 1) == 0 || md < 0 || s1 < 1 || s2 < 1)
+        return fail(PDEPTH_E_ARG, "%s: bad configuration (pad %d, kernel %d, max_displacement %d, stride1 %d, stride2 %d)", who, pad, k, md, s1, s2);
+    if (md - (md / s2) * s2 - (k - 1) / 2 < 0)
+        return fail(PDEPTH_E_ARG, "%s: kernel_size %d with max_displacement %d / stride2 %d reads outside the padded input in the "
+                    "reference kernel (needs (kernel_size-1)/2 <= max_displacement mod stride2)", who, k, md, s2);
+    if (!pdepth::correlation_output_size(H, W, pad, k, md, s1, oH, oW))
+        return fail(PDEPTH_E_ARG, "%s: empty output (pad %d too small for max_displacement %d, kernel %d)", who, pad, md, k);
+    if ((long long)(2 * (md / s2) + 1) * (2 * (md / s2) + 1) * *oH * *oW * B >= (1ll << 40))
+        return fail(PDEPTH_E_ARG, "%s: output too large", who);
+    return PDEPTH_OK;
+}
+bool corr_fast_path(int32_t pad, int32_t k, int32_t md, int32_t s1, int32_t s2) {   // the configuration of pwclite.py:123-125 and kin
+    return k == 1 && s1 == 1 && pad == md && md >= 1 && md % s2 == 0 && md / s2 <= pdepth::correlation_max_radius();
+}
+}  // namespace
+
+extern "C" {
+
+int pdepth_correlation_output_size(int32_t H, int32_t W, int32_t pad_size, int32_t kernel_size, int32_t max_displacement, int32_t stride1,
+                                   int32_t stride2, int32_t* out_channels, int32_t* out_height, int32_t* out_width) {
+    int oH = 0, oW = 0;
+    if (int rc = check_corr("pdepth_correlation_output_size", 1, 1, H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &oH, &oW))
+        return rc;
+    if (out_channels) *out_channels = (2 * (max_displacement / stride2) + 1) * (2 * (max_displacement / stride2) + 1);
+    if (out_height) *out_height = oH;
+    if (out_width) *out_width = oW;
+    return PDEPTH_OK;
+}
+
 int pdepth_correlation_forward_f32(const float* input1, const float* input2, int32_t B, int32_t C, int32_t H,
                                    int32_t W, int32_t pad_size, int32_t kernel_size, int32_t max_displacement,
                                    int32_t stride1, int32_t stride2, int32_t corr_multiply, float* output,
                                    void* stream) {
     (void)corr_multiply;
-    if (!input1 || !input2 || !output) return fail(PDEPTH_E_ARG, "pdepth_correlation_forward_f32: null pointer");
-    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(PDEPTH_E_ARG, "pdepth_correlation_forward_f32: non-positive dimension");
-    if (kernel_size != 1 || stride1 != 1 || stride2 < 1 || pad_size != max_displacement || max_displacement < 1 ||
-        max_displacement % stride2 != 0 || max_displacement / stride2 > pdepth::correlation_max_radius())
-        return fail(PDEPTH_E_ARG, "pdepth_correlation_forward_f32: unsupported configuration (pad %d, kernel %d, "
-                    "max_displacement %d, stride1 %d, stride2 %d)", pad_size, kernel_size, max_displacement, stride1, stride2);
-    return launched(pdepth::launch_correlation_forward(input1, input2, B, C, H, W, max_displacement / stride2, stride2,
-                                                       output, (hipStream_t)stream), "pdepth_correlation_forward_f32");
+    const char* who = "pdepth_correlation_forward_f32";
+    if (!input1 || !input2 || !output) return fail(PDEPTH_E_ARG, "%s: null pointer", who);
+    int oH, oW;
+    if (int rc = check_corr(who, B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &oH, &oW)) return rc;
+    if (corr_fast_path(pad_size, kernel_size, max_displacement, stride1, stride2))
+        return launched(pdepth::launch_correlation_forward(input1, input2, B, C, H, W, max_displacement / stride2, stride2,
+                                                           output, (hipStream_t)stream), who);
+    return launched(pdepth::launch_correlation_general_forward(input1, input2, 0, B, C, H, W, pad_size, kernel_size, max_displacement,
+                                                               stride1, stride2, output, (hipStream_t)stream), who);
 }
 
 int pdepth_correlation_backward_f32(const float* input1, const float* input2, const float* grad_output, int32_t B,
@@ -312,16 +349,41 @@ int pdepth_correlation_backward_f32(const float* input1, const float* input2, co
                                     int32_t max_displacement, int32_t stride1, int32_t stride2, int32_t corr_multiply,
                                     float* grad_input1, float* grad_input2, void* stream) {
     (void)corr_multiply;
-    if (!input1 || !input2 || !grad_output || (!grad_input1 && !grad_input2))
-        return fail(PDEPTH_E_ARG, "pdepth_correlation_backward_f32: null pointer");
-    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(PDEPTH_E_ARG, "pdepth_correlation_backward_f32: non-positive dimension");
-    if (kernel_size != 1 || stride1 != 1 || stride2 < 1 || pad_size != max_displacement || max_displacement < 1 ||
-        max_displacement % stride2 != 0 || max_displacement / stride2 > pdepth::correlation_max_radius())
-        return fail(PDEPTH_E_ARG, "pdepth_correlation_backward_f32: unsupported configuration (pad %d, kernel %d, "
-                    "max_displacement %d, stride1 %d, stride2 %d)", pad_size, kernel_size, max_displacement, stride1, stride2);
-    return launched(pdepth::launch_correlation_backward(input1, input2, grad_output, B, C, H, W, max_displacement / stride2,
-                                                        stride2, grad_input1, grad_input2, (hipStream_t)stream),
-                    "pdepth_correlation_backward_f32");
+    const char* who = "pdepth_correlation_backward_f32";
+    if (!input1 || !input2 || !grad_output || (!grad_input1 && !grad_input2)) return fail(PDEPTH_E_ARG, "%s: null pointer", who);
+    int oH, oW;
+    if (int rc = check_corr(who, B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &oH, &oW)) return rc;
+    if (corr_fast_path(pad_size, kernel_size, max_displacement, stride1, stride2))
+        return launched(pdepth::launch_correlation_backward(input1, input2, grad_output, B, C, H, W, max_displacement / stride2,
+                                                            stride2, grad_input1, grad_input2, (hipStream_t)stream), who);
+    return launched(pdepth::launch_correlation_general_backward(input1, input2, grad_output, 0, B, C, H, W, pad_size, kernel_size,
+                                                                max_displacement, stride1, stride2, grad_input1, grad_input2,
+                                                                (hipStream_t)stream), who);
+}
+
+int pdepth_correlation_forward_f16(const void* input1, const void* input2, int32_t B, int32_t C, int32_t H, int32_t W, int32_t pad_size,
+                                   int32_t kernel_size, int32_t max_displacement, int32_t stride1, int32_t stride2,
+                                   int32_t corr_multiply, void* output, void* stream) {
+    (void)corr_multiply;
+    const char* who = "pdepth_correlation_forward_f16";
+    if (!input1 || !input2 || !output) return fail(PDEPTH_E_ARG, "%s: null pointer", who);
+    int oH, oW;
+    if (int rc = check_corr(who, B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &oH, &oW)) return rc;
+    return launched(pdepth::launch_correlation_general_forward(input1, input2, 1, B, C, H, W, pad_size, kernel_size, max_displacement,
+                                                               stride1, stride2, output, (hipStream_t)stream), who);
+}
+
+int pdepth_correlation_backward_f16(const void* input1, const void* input2, const void* grad_output, int32_t B, int32_t C, int32_t H,
+                                    int32_t W, int32_t pad_size, int32_t kernel_size, int32_t max_displacement, int32_t stride1,
+                                    int32_t stride2, int32_t corr_multiply, void* grad_input1, void* grad_input2, void* stream) {
+    (void)corr_multiply;
+    const char* who = "pdepth_correlation_backward_f16";
+    if (!input1 || !input2 || !grad_output || (!grad_input1 && !grad_input2)) return fail(PDEPTH_E_ARG, "%s: null pointer", who);
+    int oH, oW;
+    if (int rc = check_corr(who, B, C, H, W, pad_size, kernel_size, max_displacement, stride1, stride2, &oH, &oW)) return rc;
+    return launched(pdepth::launch_correlation_general_backward(input1, input2, grad_output, 1, B, C, H, W, pad_size, kernel_size,
+                                                                max_displacement, stride1, stride2, grad_input1, grad_input2,
+                                                                (hipStream_t)stream), who);
 }
 
 int pdepth_inverse_warp_f32(const float* img, const float* depth, const float* Kinv, const float* proj, int32_t B,

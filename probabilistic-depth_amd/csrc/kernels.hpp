@@ -94,6 +94,12 @@ hipError_t launch_dpv_fuse(const float* logp, const float* dmaps, const float* m
 hipError_t launch_correlation_forward(const float* x1, const float* x2, int B, int C, int H, int W, int radius,
                                       int stride2, float* out, hipStream_t stream);
 int correlation_max_radius();
+// correlation_general.hip: every configuration of the reference's kernel, fp32 or fp16 I/O (half != 0), fp32 accumulation
+bool correlation_output_size(int H, int W, int pad, int k, int md, int s1, int* oH, int* oW);
+hipError_t launch_correlation_general_forward(const void* x1, const void* x2, int half, int B, int C, int H, int W, int pad, int k, int md,
+                                              int s1, int s2, void* out, hipStream_t stream);
+hipError_t launch_correlation_general_backward(const void* x1, const void* x2, const void* go, int half, int B, int C, int H, int W, int pad,
+                                               int k, int md, int s1, int s2, void* g1, void* g2, hipStream_t stream);
 hipError_t launch_correlation_backward(const float* x1, const float* x2, const float* go, int B, int C, int H, int W,
                                        int radius, int stride2, float* g1, float* g2, hipStream_t stream);
 hipError_t launch_inverse_warp(const float* img, const float* depth, const float* Kinv, const float* proj, int B,

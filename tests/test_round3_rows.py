@@ -1,0 +1,167 @@
+"""Round 3: the HIP ops of ONE feedback step on the reference's own tensors (fixture g18, tests/golden/make_golden_r3.py).
+
+The end-to-end feedback comparison (test_model_host / g15) carries 2-3e-4 of depth through the 3-D convolutions (MIOpen on
+the GPU against mkldnn where the fixture was made).  Here every op of the step that this package implements gets the
+REFERENCE's inputs -- the convolutions' outputs included -- so what is asserted is the op, not the network:
+
+  warp_feature                      models/models.py:616-625     1e-5 abs (bit-faithful positions, bilinear taps)
+  log_softmax(BV_cur + BV_resi)     models/models.py:694         2e-5 abs on the log-DPV, 1e-4 m on E[d]
+  the decoder's log_softmax + E[d]  models/models.py:351, trainer/default_trainer.py:230-233   the same bounds
+CPU part: the oracle restatement reproduces the same tensors (pins the oracle on in-model data)."""
+import numpy as np
+import pytest
+import torch
+
+import pdepth_amd  # noqa: F401
+from pdepth_amd import ops, synth
+from oracle import ref_cpu as O
+from util import golden, golden_blas
+
+DEV = "cuda:0"
+LOGP_ATOL, DEPTH_ATOL = 2e-5, 1e-4
+
+
+def _frame(g):
+    hw = [int(v) for v in g["image_hw"]]
+    return synth.make_model_input(int(g["input_seed"]), B=1, V=1, H=hw[0], W=hw[1], D=64, pose="mono")
+
+
+def test_oracle_reproduces_the_feedback_step_tensors():
+    g = golden("g18_feedback_step.npz")
+    inp = _frame(g)
+    upd = torch.log_softmax(torch.from_numpy(g["BV_cur"]) + torch.from_numpy(g["BV_resi"]), dim=1)
+    np.testing.assert_allclose(upd.numpy()[:, ::2], g["BV_upd_even"], rtol=0, atol=1e-6)
+    depth = O.dpv_to_depthmap(upd, inp["d_candi"], BV_log=True)
+    np.testing.assert_allclose(depth.numpy(), g["depth_low"], rtol=0, atol=2e-5)
+    dec = torch.log_softmax(torch.from_numpy(g["dec_pre_crop"]), dim=1)
+    np.testing.assert_allclose(dec.numpy(), g["dec_logp_crop"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(O.dpv_to_depthmap(dec, inp["d_candi"], BV_log=True).numpy(), g["depth_ref_crop"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_hip_feedback_update_on_reference_tensors():
+    """reduce_ex(addend): log_softmax(BV_cur + BV_resi), its exp (the decoder's input) and E[d] in one pass."""
+    g = golden("g18_feedback_step.npz")
+    inp = _frame(g)
+    cur, resi = torch.from_numpy(g["BV_cur"]).to(DEV), torch.from_numpy(g["BV_resi"]).to(DEV)
+    r = ops.dpv_reduce_ex(cur, inp["d_candi"], addend=resi, want_logp=True, want_prob=True, want_depth=True)
+    logp = r["logp"].cpu().numpy()
+    err_l = np.abs(logp[:, ::2] - g["BV_upd_even"]).max()
+    err_d = np.abs(r["depth"].cpu().numpy() - g["depth_low"]).max()
+    assert err_l <= LOGP_ATOL, f"log-DPV of the feedback update differs by {err_l:.2e}"
+    assert err_d <= DEPTH_ATOL, f"E[d] of the feedback update differs by {err_d:.2e} m"
+    np.testing.assert_allclose(r["prob"].cpu().numpy()[:, ::2], np.exp(g["BV_upd_even"]), rtol=2e-5, atol=1e-7)
+    print(f"feedback update on reference tensors: logp {err_l:.2e}, depth {err_d:.2e} m")
+
+
+@pytest.mark.gpu
+def test_hip_decoder_dpv_pass_on_reference_tensors():
+    """The decoder's last step (log_softmax over D at full resolution) + dpv_to_depthmap, on the reference's pre-softmax crop."""
+    g = golden("g18_feedback_step.npz")
+    inp = _frame(g)
+    pre = torch.from_numpy(g["dec_pre_crop"]).to(DEV).contiguous()
+    logp, depth = ops.dpv_reduce(pre, inp["d_candi"])
+    err_l = np.abs(logp.cpu().numpy() - g["dec_logp_crop"]).max()
+    err_d = np.abs(depth.cpu().numpy() - g["depth_ref_crop"]).max()
+    assert err_l <= LOGP_ATOL and err_d <= DEPTH_ATOL, (err_l, err_d)
+    r = ops.dpv_reduce_ex(pre, inp["d_candi"], want_logp=True, want_depth=True, want_quarter=True)
+    assert np.abs(r["logp"].cpu().numpy() - g["dec_logp_crop"]).max() <= LOGP_ATOL
+    assert np.array_equal(r["quarter"].cpu().numpy(), r["logp"].cpu().numpy()[:, :, ::4, ::4])   # default_trainer.py:221
+    print(f"decoder DPV pass on reference tensors: logp {err_l:.2e}, depth {err_d:.2e} m")
+
+
+@pytest.mark.gpu
+def test_hip_warp_feature_on_reference_tensors():
+    """The diagonal warp of the raw features (both views: the source view and the identity-posed reference view)."""
+    g = golden("g18_feedback_step.npz")
+    inp = _frame(g)
+    feat = torch.from_numpy(g["feat_raw"]).to(DEV)            # [1, V+1, 64, h, w]
+    poses = inp["src_cam_poses"].to(DEV)
+    K = inp["intrinsics"].to(DEV)
+    out = ops.warp_feature(feat, K, poses[:, :, :3, :3].contiguous(), poses[:, :, :3, 3].contiguous(), inp["unit_ray"].to(DEV),
+                           K[:, :2, 2].contiguous(), inp["d_candi"], blas=golden_blas(g))
+    err = np.abs(out.cpu().numpy()[:, :, ::2] - g["warped_even"]).max()
+    scale = float(np.abs(g["warped_even"]).max())
+    assert err <= 1e-5 * max(1.0, scale), f"warp_feature differs by {err:.2e} (values up to {scale:.2f})"
+    print(f"warp_feature on reference tensors: {err:.2e} (values up to {scale:.2f})")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the correlation op beyond the one configuration the reference instantiates
+# ---------------------------------------------------------------------------------------------------------------
+CORR_CONFIGS = [   # pad, kernel, max_displacement, stride1, stride2
+    (4, 1, 4, 1, 1),      # the reference's own (fast path)
+    (5, 1, 4, 1, 1),      # pad > max_displacement: the output grows by 2 * (pad - max_displacement)
+    (3, 1, 4, 1, 2),      # pad < max_displacement: it shrinks
+    (4, 1, 4, 2, 1),      # stride1 = 2
+    (4, 3, 4, 1, 3),      # 3x3 kernel (max_displacement mod stride2 = 1 >= kernel radius)
+    (6, 3, 5, 2, 2),      # everything at once
+    (20, 1, 20, 1, 2),    # 21 x 21 displacements (FlowNet-C's head): beyond the fast path's radius
+]
+
+
+def test_oracle_general_correlation_contains_the_native_one():
+    """The general restatement (from the kernel's index arithmetic) against the restatement of correlation_native.py that
+    fixtures g9 / g12 pin: bit-identical where both apply."""
+    g = torch.Generator().manual_seed(5)
+    x1, x2 = torch.randn(2, 6, 13, 18, generator=g), torch.randn(2, 6, 13, 18, generator=g)
+    for md in (1, 3, 4):
+        assert torch.equal(O.correlation_general(x1, x2, md, 1, md, 1, 1), O.correlation(x1, x2, md))
+    assert O.correlation_general(x1, x2, 6, 3, 5, 2, 2).shape == (2, 25, 7, 9)   # ceil((13 + 12 - 12) / 2), ceil((18 + 12 - 12) / 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", CORR_CONFIGS)
+def test_hip_correlation_every_configuration(cfg):
+    """Forward and backward (through ops.correlation's autograd Function, like correlation_package/correlation.py:6-44) for
+    configurations of correlation_cuda_kernel.cu:41-114 that the reference never instantiates, in fp32 and with fp16 I/O."""
+    pad, k, md, s1, s2 = cfg
+    g = torch.Generator().manual_seed(100 + pad + 7 * k + 13 * s1)
+    B, C, H, W = 2, 10, 21 if md < 10 else 44, 30 if md < 10 else 47
+    x1, x2 = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    a, b = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    want = O.correlation_general(a, b, pad, k, md, s1, s2)
+    go = torch.randn(want.shape, generator=g)
+    want.backward(go)
+    ad, bd = x1.to(DEV).requires_grad_(True), x2.to(DEV).requires_grad_(True)
+    got = ops.correlation(ad, bd, pad, k, md, s1, s2)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5, atol=1e-6)
+    got.backward(go.to(DEV))
+    np.testing.assert_allclose(ad.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-5, atol=5e-6)   # (sums of up to 441 x 9 terms)
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-5, atol=5e-6)
+    # fp16 tensors, fp32 accumulation (the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF, .cu:352-369):
+    # against the oracle on the SAME fp16-rounded inputs, the only difference is the rounding of the outputs
+    h1, h2 = x1.half(), x2.half()
+    want16 = O.correlation_general(h1.float(), h2.float(), pad, k, md, s1, s2)
+    got16 = ops.correlation(h1.to(DEV), h2.to(DEV), pad, k, md, s1, s2)
+    assert got16.dtype == torch.float16
+    np.testing.assert_allclose(got16.float().cpu().numpy(), want16.numpy(), rtol=1e-3, atol=1e-3)
+    hd1, hd2 = h1.to(DEV).requires_grad_(True), h2.to(DEV).requires_grad_(True)
+    ops.correlation(hd1, hd2, pad, k, md, s1, s2).backward(go.half().to(DEV))
+    r1, r2 = h1.float().requires_grad_(True), h2.float().requires_grad_(True)
+    O.correlation_general(r1, r2, pad, k, md, s1, s2).backward(go.half().float())
+    np.testing.assert_allclose(hd1.grad.float().cpu().numpy(), r1.grad.numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(hd2.grad.float().cpu().numpy(), r2.grad.numpy(), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.gpu
+def test_hip_correlation_refuses_what_the_reference_kernel_reads_out_of_bounds_for():
+    x = torch.randn(1, 4, 12, 12, device=DEV)
+    for bad in ((4, 3, 4, 1, 1), (4, 2, 4, 1, 1), (4, 1, 4, 0, 1), (0, 1, 6, 1, 1)):   # radius > md mod s2; even kernel; stride 0; empty output
+        with pytest.raises(RuntimeError):
+            ops.correlation(x, x, *bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(128, 128, 64), (256, 128, 128), (128, 256, 64)])
+def test_hip_correlation_reference_self_check(shape):
+    """The reference's own numerical assertion (models/correlation_native.py:41-64): batch 4, C in {128, 256}, H in {128, 256},
+    W in {64, 128}, N(0,1) inputs, max_displacement 4, the CUDA op equal to correlation_native at atol 1e-7.  Here: the HIP op
+    against the restatement of correlation_native (bit-identical to the reference's on fixture g9), same shapes, same bound."""
+    C, H, W = shape
+    g = torch.Generator().manual_seed(C + H + W)
+    x1, x2 = torch.randn(4, C, H, W, generator=g), torch.randn(4, C, H, W, generator=g)
+    want = O.correlation(x1, x2, 4)
+    got = ops.correlation(x1.to(DEV), x2.to(DEV), pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1).cpu()
+    assert torch.allclose(want, got, atol=1e-7), f"max |diff| {float((want - got).abs().max()):.2e}"
