@@ -137,6 +137,19 @@ int pdepth_sweep_dpv_f32(const pdepth_sweep_desc *desc, const pdepth_camera *cam
  */
 int pdepth_pack_source_f32(const pdepth_sweep_desc *desc, const float *src, void *workspace,
                            size_t workspace_bytes, void *stream);
+/*
+ * The encoder epilogue, fused with that re-layout: replaces
+ *     feat_imgs_all = torch.cat((feat_imgs, F.avg_pool2d(rgb, dw_rate)), dim=1)     models/models.py:518-520, packnet.py:355-357
+ *     feat_img_ref = feat_imgs_all[i, -1], feat_imgs_src = feat_imgs_all[i, :-1]    models/models.py:530-534
+ * and pdepth_pack_source_f32 with ONE pass over the encoder output:
+ *   feat [B*(V+1), C-3, H, W] (the encoder's feature maps, view V of every item = the reference view),
+ *   rgb  [B*(V+1), 3, H*pool_rate, W*pool_rate] (the frames; pooled like F.avg_pool2d(kernel = stride = pool_rate)),
+ *   -> workspace: the V source views of every item in the staging layout (for pdepth_sweep_dpv_packed_f32, same desc),
+ *   -> ref_out [B, C, H, W]: the reference view's features, NCHW (what that entry takes as `ref`).
+ * desc: B, V (source views), C (= encoder channels + 3), D, H, W, algo = PDEPTH_ALGO_AUTO.
+ */
+int pdepth_pack_views_f32(const pdepth_sweep_desc *desc, const float *feat, const float *rgb, int32_t pool_rate,
+                          float *ref_out, void *workspace, size_t workspace_bytes, void *stream);
 int pdepth_sweep_dpv_packed_f32(const pdepth_sweep_desc *desc, const pdepth_camera *cam, const float *ref,
                                 const float *d_candi, float *cost, float *logp, float *depth,
                                 void *workspace, size_t workspace_bytes, void *stream);

@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "pdepth_pack_source_f32", "pdepth_sweep_dpv_packed_f32", "pdepth_dpv_reduce_ex_f32",
     "pdepth_ufield_workspace_bytes", "pdepth_ufield_f32",
     "pdepth_correlation_output_size", "pdepth_correlation_forward_f16", "pdepth_correlation_backward_f16",
+    "pdepth_pack_views_f32",
 )
 
 
@@ -221,6 +222,35 @@ def pack_source(src, n_planes=64):
         rc = lib.pdepth_pack_source_f32(ctypes.byref(desc), _dev(src, "src"), ws.data_ptr(), ws_bytes, _stream(src.device))
     _check(rc, lib)
     return PackedSource(ws, (B, V, C, H, W))
+
+
+def pack_views(feat, rgb, n_views, n_planes=64):
+    """The encoder epilogue in one pass (pdepth_pack_views_f32): feat [B*V1, Cf, h, w] (encoder output, view V1-1 of every
+    item = the reference view), rgb [B*V1, 3, H, W] -> (PackedSource of the V1-1 source views with Cf+3 channels -- the
+    pooled image appended like models/models.py:518-520 --, reference-view features [B, Cf+3, h, w]).  Raises for shapes
+    the packed sweep does not take (callers fall back to cat + sweep)."""
+    lib = load()
+    _no_autograd("pack_views", feat, rgb)
+    _dev(feat, "feat"), _dev(rgb, "rgb")
+    if feat.dim() != 4 or rgb.dim() != 4 or feat.shape[0] != rgb.shape[0] or rgb.shape[1] != 3 or feat.shape[0] % n_views:
+        raise RuntimeError("pack_views: feat [B*V1,Cf,h,w] and rgb [B*V1,3,H,W] expected")
+    feat, rgb = feat.contiguous(), rgb.contiguous()
+    N, Cf, h, w = feat.shape
+    rate = int(rgb.shape[3] / w)
+    if rate < 1 or rgb.shape[2] // rate != h or rgb.shape[3] // rate != w or n_views < 2:
+        raise RuntimeError("pack_views: the image must be an integral multiple of the feature map, with at least one source view")
+    B, V, C = N // n_views, n_views - 1, Cf + 3
+    desc = SweepDesc(B, V, C, int(n_planes), h, w, METRIC_L2, ALGO_AUTO, BLAS_FMA, 1.0, C * h * w, V * C * h * w, C * h * w)
+    ws_bytes = lib.pdepth_sweep_workspace_bytes(ctypes.byref(desc))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=feat.device)
+    ref = torch.empty((B, C, h, w), dtype=torch.float32, device=feat.device)
+    lib.pdepth_pack_views_f32.argtypes = [POINTER(SweepDesc), c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.pdepth_pack_views_f32.restype = c_int
+    with torch.cuda.device(feat.device):
+        rc = lib.pdepth_pack_views_f32(ctypes.byref(desc), feat.data_ptr(), rgb.data_ptr(), rate, ref.data_ptr(), ws.data_ptr(),
+                                       ws_bytes, _stream(feat.device))
+    _check(rc, lib)
+    return PackedSource(ws, (B, V, C, h, w)), ref
 
 
 def sweep(ref, src, K, R, t, rays, cxcy, d_candi, sigma, metric=METRIC_L2, algo=ALGO_AUTO,

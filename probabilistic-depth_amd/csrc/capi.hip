@@ -192,6 +192,26 @@ int pdepth_pack_source_f32(const pdepth_sweep_desc* desc, const float* src, void
     return launched(pdepth::launch_pack_c4(a, workspace, (hipStream_t)stream), who);
 }
 
+int pdepth_pack_views_f32(const pdepth_sweep_desc* desc, const float* feat, const float* rgb, int32_t pool_rate, float* ref_out,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    const char* who = "pdepth_pack_views_f32";
+    if (!desc || !feat || !rgb || !ref_out) return fail(PDEPTH_E_ARG, "%s: null pointer", who);
+    if (desc->B <= 0 || desc->V <= 0 || desc->C <= 3 || desc->D <= 0 || desc->H <= 0 || desc->W <= 0 || pool_rate < 1)
+        return fail(PDEPTH_E_ARG, "%s: bad dimension (C must count the 3 pooled image channels)", who);
+    if (!uses_packed_source(desc))
+        return fail(PDEPTH_E_ARG, "%s: this shape / algorithm does not run on a packed source", who);
+    if ((long long)desc->H * pool_rate * desc->W * pool_rate * 3 >= (1ll << 31))
+        return fail(PDEPTH_E_ARG, "%s: image too large", who);
+    const size_t need = tiled_ws_bytes(desc);
+    if (!workspace || workspace_bytes < need)
+        return fail(PDEPTH_E_WORKSPACE, "%s: needs %zu bytes of workspace (got %zu)", who, need, workspace_bytes);
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0)
+        return fail(PDEPTH_E_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
+    pdepth::SweepArgs a{};
+    a.B = desc->B; a.V = desc->V; a.C = desc->C; a.D = desc->D; a.H = desc->H; a.W = desc->W;
+    return launched(pdepth::launch_pack_views(a, feat, rgb, pool_rate, ref_out, workspace, (hipStream_t)stream), who);
+}
+
 int pdepth_sweep_dpv_packed_f32(const pdepth_sweep_desc* desc, const pdepth_camera* cam, const float* ref,
                                 const float* d_candi, float* cost, float* logp, float* depth, void* workspace,
                                 size_t workspace_bytes, void* stream) {

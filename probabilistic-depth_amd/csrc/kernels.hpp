@@ -50,6 +50,9 @@ hipError_t launch_sweep_tiled_n1(const SweepArgs& a, void* workspace, hipStream_
 hipError_t launch_sweep_tiled_n2(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false);  // two tiles per block
 hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t stream);          // pre-pass of both (also clears flags + queues)
 hipError_t clear_sweep_flags(const SweepArgs& a, void* workspace, hipStream_t stream);
+// encoder epilogue: cat(feat, avg_pool2d(rgb)) -> packed source views + NCHW reference view, in one pass (a.C = Cf + 3)
+hipError_t launch_pack_views(const SweepArgs& a, const float* feat, const float* rgb, int rate, float* ref_out, void* workspace,
+                             hipStream_t stream);
 int sweep_device_cus();
 // workspace head shared by the packed-source kernels: tile flags (+ the 64 queue / counter ints behind them)
 size_t sweep_ws_flag_only_bytes(int B, int H, int W);

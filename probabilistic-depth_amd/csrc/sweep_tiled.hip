@@ -1010,6 +1010,79 @@ __global__ __launch_bounds__(256) void pack_c4_kernel(const float* __restrict__ 
     o[(size_t)(ngrp + 1) * HW] = make_float4(d2, 0.f, 0.f, 0.f);
 }
 
+
+// Encoder epilogue: what the host model does between its feature encoder and the sweep --
+//     feats = cat(feat, avg_pool2d(rgb, rate))                 models/models.py:518-520, models/packnet.py:355-357
+//     reference view = feats[:, -1], sources = feats[:, :-1]   models/models.py:530-534
+// -- fused with the sweep's pre-pass: ONE pass over the encoder output writes the source views straight into the packed
+// layout (float4 channel groups + Gram planes, as pack_c4_kernel) and the reference view as NCHW [B, Cf+3, H, W].  The
+// concatenated [B, V+1, Cf+3, H, W] tensor is never materialised, and the sweep call that follows runs the packed entry
+// (no pre-pass of its own).  feat [B*(V+1), Cf, H, W]; rgb [B*(V+1), 3, H*rate, W*rate]; view V of every item = reference.
+// avg_pool2d as ATen computes it: window sum in row-major order, then divided by rate^2.
+__global__ __launch_bounds__(256) void pack_views_kernel(const float* __restrict__ feat, const float* __restrict__ rgb, int V, int Cf,
+                                                         int H, int W, int rate, float4* __restrict__ out, float* __restrict__ ref_out,
+                                                         int* __restrict__ flags, int nflags) {
+    const int HW = H * W, C = Cf + 3;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < nflags; i += gridDim.x * gridDim.y * 256) flags[i] = 0;
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, qq = nb >> 3, rr = nb & 7;   // XCD-aware block order, as pack_c4_kernel
+    const int blk = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
+    const int pix = blk * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const int bv = blockIdx.y, b = bv / (V + 1), v = bv % (V + 1);
+    const int y = pix / W, x = pix - y * W;
+    const float* f = feat + (size_t)bv * Cf * HW + pix;
+    const int RW = W * rate;
+    const float* im = rgb + (size_t)bv * 3 * (size_t)(H * rate) * RW;
+    const float inv = 1.0f;   // (the divide below is a true division, like ATen's)
+    (void)inv;
+    auto pooled = [&](int c, int py, int px) -> float {   // avg_pool2d(rgb, rate)[c, py, px]
+        const float* p = im + ((size_t)c * (H * rate) + (size_t)py * rate) * RW + (size_t)px * rate;
+        float sum = 0.0f;
+        for (int j = 0; j < rate; ++j)
+            for (int i = 0; i < rate; ++i) sum += p[(size_t)j * RW + i];
+        return sum / (float)(rate * rate);
+    };
+    if (v == V) {   // the reference view: NCHW copy + pooled image
+        float* o = ref_out + (size_t)b * C * HW + pix;
+        for (int c = 0; c < Cf; ++c) o[(size_t)c * HW] = f[(size_t)c * HW];
+        for (int c = 0; c < 3; ++c) o[(size_t)(Cf + c) * HW] = pooled(c, y, x);
+        return;
+    }
+    const bool hr = x + 1 < W, hd = y + 1 < H;
+    const int ngrp = (C + 3) / 4;
+    float4* o = out + (size_t)(b * V + v) * (ngrp + 2) * HW + pix;
+    float n = 0.f, h = 0.f, vv = 0.f, d1 = 0.f, d2 = 0.f;
+    for (int g = 0; g < ngrp; ++g) {
+        float c4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = g * 4 + j;
+            float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
+            if (c < Cf) {
+                const float* sc = f + (size_t)c * HW;
+                s00 = sc[0];
+                s01 = hr ? sc[1] : 0.f;
+                s10 = hd ? sc[W] : 0.f;
+                s11 = hr && hd ? sc[W + 1] : 0.f;
+            } else if (c < C) {
+                s00 = pooled(c - Cf, y, x);
+                s01 = hr ? pooled(c - Cf, y, x + 1) : 0.f;
+                s10 = hd ? pooled(c - Cf, y + 1, x) : 0.f;
+                s11 = hr && hd ? pooled(c - Cf, y + 1, x + 1) : 0.f;
+            }
+            c4[j] = s00;
+            n = __builtin_fmaf(s00, s00, n);
+            h = __builtin_fmaf(s00, s01, h);
+            vv = __builtin_fmaf(s00, s10, vv);
+            d1 = __builtin_fmaf(s00, s11, d1);
+            d2 = __builtin_fmaf(s01, s10, d2);
+        }
+        o[(size_t)g * HW] = make_float4(c4[0], c4[1], c4[2], c4[3]);
+    }
+    o[(size_t)ngrp * HW] = make_float4(n, h, vv, d1);
+    o[(size_t)(ngrp + 1) * HW] = make_float4(d2, 0.f, 0.f, 0.f);
+}
+
 #endif  // PDEPTH_NSUB == 1 (pre-pass kernel)
 
 static size_t tiled_lds_bytes(int D) {
@@ -1046,6 +1119,18 @@ hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t strea
     dim3 pgrid((HW + 255) / 256, a.B * a.V);
     hipLaunchKernelGGL(pack_c4_kernel, pgrid, dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V, a.C, a.H, a.W, packed,
                        flags, (int)(flag_bytes(a.B, a.H, a.W) / sizeof(int)));
+    return hipGetLastError();
+}
+
+// the encoder epilogue (pack_views_kernel): a.C = Cf + 3, a.V source views, views V+1 per item in feat / rgb
+hipError_t launch_pack_views(const SweepArgs& a, const float* feat, const float* rgb, int rate, float* ref_out, void* workspace,
+                             hipStream_t stream) {
+    int* flags = reinterpret_cast<int*>(workspace);
+    float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + flag_bytes(a.B, a.H, a.W));
+    const int HW = a.H * a.W;
+    dim3 pgrid((HW + 255) / 256, a.B * (a.V + 1));
+    hipLaunchKernelGGL(pack_views_kernel, pgrid, dim3(256), 0, stream, feat, rgb, a.V, a.C - 3, a.H, a.W, rate, packed, ref_out, flags,
+                       (int)(flag_bytes(a.B, a.H, a.W) / sizeof(int)));
     return hipGetLastError();
 }
 

@@ -221,6 +221,20 @@ def _tolerate_missing_dres_blocks(module, incompatible_keys):
         incompatible_keys.missing_keys[:] = [k for k in incompatible_keys.missing_keys if not is_dres(k)]
 
 
+class _SweepFeatures:
+    """What BaseModel._features hands to the sweep on the default path: the source views in the kernels' staging layout, the
+    reference view as NCHW -- both with the pooled image appended -- and the encoder's learned feature maps, which is all
+    that the callers' slices `feats[:, v, :-3]` (decoder skip connections, models.py:563-564) ever read."""
+
+    def __init__(self, learned, packed, ref):
+        self.learned, self.packed, self.ref = learned, packed, ref   # [B,V1,Cf,h,w], PackedSource, [B,Cf+3,h,w]
+
+    def __getitem__(self, idx):
+        if isinstance(idx, tuple) and len(idx) == 3 and idx[2] == slice(None, -3, None):
+            return self.learned[idx[0], idx[1]]
+        raise IndexError("only feats[:, v, :-3] (the learned channels of one view) can be read from the packed features")
+
+
 class BaseModel(nn.Module):
     """Inference-only host model: the sweep / warp / DPV ops are HIP kernels behind ctypes and are invisible to autograd
     (they raise if an input requires grad while grad mode is on); wrap calls in torch.no_grad() as the reference's
@@ -250,6 +264,7 @@ class BaseModel(nn.Module):
         self.register_load_state_dict_post_hook(_tolerate_missing_dres_blocks)
         self.viz = None
         self.sweep_algo = "auto"  # "direct" selects the gather kernel (debugging / comparison)
+        self.packed_epilogue = True   # encoder epilogue kernel + packed sweep entry (False: cat + avg_pool2d + plain entry)
         self.sweep_blas = None    # None = rounding of this host's CPU BLAS; "fma" / "separate" to force
 
     def set_viz(self, viz):
@@ -267,14 +282,28 @@ class BaseModel(nn.Module):
 
     # -- feature extraction + batched sweep --------------------------------------------------------
     def _features(self, model_input):
+        """(half-resolution features, raw features, sweep features), each [B, V+1, ., ., .].
+
+        The sweep features are the encoder output plus the average-pooled frame (models.py:518-520).  On the default path
+        they are never concatenated: the encoder epilogue kernel (ops.pack_views) writes the source views straight into the
+        sweep kernels' staging layout and the reference view as NCHW, and `feats` is a _SweepFeatures handle that carries
+        both (and still slices like the tensor for the decoder's skip connections, which only read the learned channels)."""
         rgb = model_input["rgb"]
         B, V1 = rgb.shape[0], rgb.shape[1]
         flat = rgb.reshape(B * V1, rgb.shape[2], rgb.shape[3], rgb.shape[4])
         half, raw, feat = self.base_encoder(flat)
-        rate = int(flat.shape[3] / feat.shape[3])
-        feats = torch.cat((feat, F.avg_pool2d(flat, rate)), dim=1)  # [B*V1, C+3, h, w]  (models.py:518-520)
         per_view = lambda x: x.view(B, V1, x.shape[1], x.shape[2], x.shape[3])
-        return per_view(half), per_view(raw), per_view(feats)
+        feats = None
+        if self.sweep_algo == "auto" and self.packed_epilogue and V1 >= 2 and not torch.is_grad_enabled():
+            try:
+                packed, ref = ops.pack_views(feat.float(), flat.float(), V1, self.D)
+                feats = _SweepFeatures(per_view(feat), packed, ref)
+            except RuntimeError:   # a shape the packed sweep does not take: the concatenated tensor below
+                feats = None
+        if feats is None:
+            rate = int(flat.shape[3] / feat.shape[3])
+            feats = per_view(torch.cat((feat, F.avg_pool2d(flat, rate)), dim=1))  # [B, V1, C+3, h, w]  (models.py:518-520)
+        return per_view(half), per_view(raw), feats
 
     def _camera(self, model_input):
         K = model_input["intrinsics"].float()
@@ -287,6 +316,9 @@ class BaseModel(nn.Module):
         K, poses, rays, cxcy = self._camera(model_input)
         R = poses[:, :-1, :3, :3]
         t = poses[:, :-1, :3, 3]
+        if isinstance(feats, _SweepFeatures):   # sources already in the staging layout: the packed entry, no pre-pass
+            return ops.sweep_cost(feats.ref, feats.packed, K, R, t, rays, cxcy, model_input["d_candi"],
+                                  self.sigma_soft_max, feat_dist="L2", algo="auto", blas=self.sweep_blas)
         return ops.sweep_cost(feats[:, -1], feats[:, :-1], K, R, t, rays, cxcy, model_input["d_candi"],
                               self.sigma_soft_max, feat_dist="L2", algo=self.sweep_algo, blas=self.sweep_blas)
 

@@ -39,12 +39,29 @@ class PacknetHead(nn.Module):
     @torch.no_grad()
     def forward(self, model_input, feat_imgs_all=None, want_cost=False):
         """Returns (BV = log_softmax(cost volumes, dim=1) [B,D,h,w], depth [B,h,w][, cost volumes])."""
-        if feat_imgs_all is None:
-            feat_imgs_all = self.features(model_input["rgb"])
+        ref = src = None
+        if feat_imgs_all is None and self.sweep_algo == "auto":
+            # the encoder epilogue kernel: pooled image appended, source views straight into the sweep's staging layout
+            rgb = model_input["rgb"]
+            B, V1 = rgb.shape[0], rgb.shape[1]
+            flat = rgb.reshape(B * V1, rgb.shape[2], rgb.shape[3], rgb.shape[4])
+            try:
+                src, ref = ops.pack_views(self.encoder(flat).float(), flat.float(), V1, len(model_input["d_candi"]))
+            except RuntimeError:
+                src = ref = None
+        if src is None:
+            if feat_imgs_all is None:
+                feat_imgs_all = self.features(model_input["rgb"])
+            ref, src = feat_imgs_all[:, -1], feat_imgs_all[:, :-1]
+            if self.sweep_algo == "auto":   # precomputed features: re-laid once, then the packed entry
+                try:
+                    src = ops.pack_source(src, len(model_input["d_candi"]))
+                except RuntimeError:
+                    pass
         poses = model_input["src_cam_poses"].float()
         K = model_input["intrinsics"].float()
         cost, BV, depth = ops.sweep_dpv(
-            feat_imgs_all[:, -1], feat_imgs_all[:, :-1], K, poses[:, :-1, :3, :3], poses[:, :-1, :3, 3],
+            ref, src, K, poses[:, :-1, :3, :3], poses[:, :-1, :3, 3],
             model_input["unit_ray"].float(), K[:, :2, 2].contiguous(), model_input["d_candi"], self.sigma_soft_max,
-            feat_dist="L2", algo=self.sweep_algo, want_cost=want_cost, blas=self.sweep_blas)
+            feat_dist="L2", algo=self.sweep_algo, want_cost=want_cost, blas=self.sweep_blas)   # (a PackedSource implies "auto")
         return (BV, depth, cost) if want_cost else (BV, depth)

@@ -75,6 +75,13 @@ def pack_source(src, n_planes=64):
     return _native.pack_source(src, n_planes)
 
 
+def pack_views(feat, rgb, n_views, n_planes=64):
+    """Encoder epilogue: cat(feat, avg_pool2d(rgb)) -> (packed source views, NCHW reference view) in one pass
+    (pdepth_pack_views_f32; models/models.py:518-534).  Pass the PackedSource as `src` and the tensor as `ref` to
+    sweep_cost / sweep_dpv."""
+    return _native.pack_views(feat, rgb, n_views, n_planes)
+
+
 def dpv_reduce(logits, d_candi, want_logp=True, want_depth=True, inplace=False):
     """(logp, depth) from logits [B,D,H,W]: log_softmax(dim=1) + dpv_to_depthmap(BV_log=True).
 

@@ -100,6 +100,7 @@ def test_band_mode_on_encoder_features(dev):
     cfg = synth.default_cfg("default")
     model = get_model(cfg, 0).to(dev).eval()
     synth.seed_weights(model, seed=8)
+    model.packed_epilogue = False   # this test wants the concatenated feature tensor itself
     rng = np.random.default_rng(31)
     base = rng.uniform(0, 1, size=(2, 1, 3, 256, 512)).astype(np.float32)
     rgb = np.concatenate([np.roll(base, 3, axis=4) * 0.9 + 0.05, base], axis=1)   # [B, V+1, 3, H, W], last = reference

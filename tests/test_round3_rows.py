@@ -165,3 +165,55 @@ def test_hip_correlation_reference_self_check(shape):
     want = O.correlation(x1, x2, 4)
     got = ops.correlation(x1.to(DEV), x2.to(DEV), pad_size=4, kernel_size=1, max_displacement=4, stride1=1, stride2=1).cpu()
     assert torch.allclose(want, got, atol=1e-7), f"max |diff| {float((want - got).abs().max()):.2e}"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the encoder epilogue kernel: cat + avg_pool2d + re-layout + Gram planes in one pass
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 2, 64, 64, 128, 4), (1, 3, 61, 37, 83, 4), (1, 2, 64, 64, 96, 2)])
+def test_hip_pack_views_is_cat_plus_pack_source(shape):
+    """ops.pack_views(feat, rgb) against the op sequence it replaces -- torch.cat((feat, F.avg_pool2d(rgb, rate))) (models.py:518-520),
+    the view split (:530-534) and pdepth_pack_source_f32: same reference-view tensor, and a sweep on the packed views that equals
+    the sweep on the concatenated tensor (the learned channels are copied bit for bit; the pooled image may differ from
+    ATen's GPU kernel in the last place)."""
+    import torch.nn.functional as F
+    B, V1, Cf, h, w, rate = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    feat = torch.randn(B * V1, Cf, h, w, generator=g).to(DEV)
+    rgb = torch.rand(B * V1, 3, h * rate, w * rate, generator=g).to(DEV)
+    packed, ref = ops.pack_views(feat, rgb, V1, 64)
+    both = torch.cat((feat, F.avg_pool2d(rgb, rate)), dim=1).view(B, V1, Cf + 3, h, w)
+    assert torch.equal(ref[:, :Cf], both[:, -1, :Cf])
+    assert (ref[:, Cf:] - both[:, -1, Cf:]).abs().max().item() <= 1e-6
+    b = synth.make_batch(77, B, C=Cf + 3, D=64, H=h, W=w, V=V1 - 1, pose="mono")
+    d = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    args = (d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0)
+    c_packed = ops.sweep_cost(ref, packed, *args)
+    c_plain = ops.sweep_cost(both[:, -1].contiguous(), both[:, :-1].contiguous(), *args)
+    rel = ((c_packed - c_plain).abs() / (1.0 + c_plain.abs())).max().item()
+    assert rel < 2e-6, rel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nmode", ["default", "default_feedback"])
+def test_model_on_the_packed_epilogue_equals_the_concatenating_path(nmode):
+    """BaseModel with the encoder epilogue kernel + packed sweep entry (default) against the same model with
+    torch.cat + avg_pool2d + the plain entry: the same outputs to rounding."""
+    from pdepth_amd.models import get_model
+    torch.manual_seed(0)
+    model = get_model(synth.default_cfg(nmode), 0).to(DEV).eval()
+    synth.seed_weights(model, seed=21)
+    inp = synth.make_model_input(21000, B=2, V=1, H=256, W=256, D=64, pose="mono")
+    inp = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in inp.items()}
+    with torch.no_grad():
+        assert model.packed_epilogue
+        a = model([inp])[0]
+        model.packed_epilogue = False
+        b = model([inp])[0]
+    for key in ("output", "output_refined"):
+        for x, y in zip(a[key], b[key]):
+            assert (x - y).abs().max().item() < 2e-4, key   # log-DPV: the pooled image's last place through the network
+    da = ops.dpv_expect(a["output_refined"][-1], inp["d_candi"], BV_log=True)
+    db = ops.dpv_expect(b["output_refined"][-1], inp["d_candi"], BV_log=True)
+    assert (da - db).abs().max().item() < 1e-3
