@@ -129,6 +129,16 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
         if (d->algo == PDEPTH_ALGO_TILED_2)
             return launched(pdepth::launch_sweep_tiled_n2(a, workspace, (hipStream_t)stream, packed_ready), who);
         const bool tiled_class = d->V == 1 && d->D <= 64 && (long long)d->H * d->W >= 96 * 1024;
+        if (d->algo == PDEPTH_ALGO_AUTO && sweep_impl() == IMPL_DEFAULT && tiled_class && pdepth::sweep_mfma_supports(a)) {
+            // The one shape class where the faster kernel depends on the pose (forward motion: the tiled band kernel; lines
+            // along the source rows, e.g. a rectified pair: the matrix-pipe kernel, 13 % faster).  The poses live on the
+            // device: the pre-pass decides (pick.hpp), both kernels are launched, the one not chosen leaves at once.
+            pdepth::SweepArgs ap = a;
+            ap.pick = pdepth::PICK_SKIP_IF_SET;
+            if (int rc = launched(pdepth::launch_sweep_tiled(ap, workspace, (hipStream_t)stream, packed_ready, pdepth::PH_PRE | pdepth::PH_KERNEL), who)) return rc;
+            ap.pick = pdepth::PICK_RUN_IF_SET;
+            return launched(pdepth::launch_sweep_mfma(ap, workspace, (hipStream_t)stream, packed_ready, pdepth::PH_KERNEL | pdepth::PH_GATHER), who);
+        }
         if (d->algo == PDEPTH_ALGO_MFMA ||
             (d->algo == PDEPTH_ALGO_AUTO && pdepth::sweep_mfma_supports(a) &&
              (sweep_impl() == IMPL_MFMA || (sweep_impl() == IMPL_DEFAULT && !tiled_class))))

@@ -30,7 +30,13 @@ struct SweepArgs {
     // launchers of the tiled / cell-list paths: the gather kernel reads it for the tiles handed to it when src == nullptr
     // (packed-source entry: the caller no longer has the NCHW source)
     const void* packed_src;
+    // device-side choice between two sweep kernels launched back to back (pick.hpp): 0 = none (the kernel runs), PICK_SKIP_IF_SET
+    // = leave at once if queue[PICK_SLOT] != 0, PICK_RUN_IF_SET = leave at once if it is 0.  In the pre-pass: != 0 = compute it.
+    int pick;
 };
+constexpr int PICK_SLOT = 50, PICK_MFMA = 1;          // workspace int behind the tile flags (cleared with them)
+constexpr int PICK_SKIP_IF_SET = 1, PICK_RUN_IF_SET = 2;
+constexpr int PH_PRE = 1, PH_KERNEL = 2, PH_GATHER = 4, PH_ALL = 7;   // phases of a sweep launcher: pre-pass / flag clear, kernel, gather
 
 // sweep_direct.hip
 hipError_t launch_sweep_direct(const SweepArgs& a, hipStream_t stream);
@@ -45,9 +51,9 @@ int sweep_direct_max_planes(int C);
 size_t sweep_tiled_workspace_bytes(int B, int V, int C, int H, int W);
 int sweep_tiled_max_planes();
 // packed_ready: the workspace already holds the packed source of exactly these views (pdepth_pack_source_f32)
-hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false);     // picks a variant
-hipError_t launch_sweep_tiled_n1(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false);  // one 16x4 tile per block
-hipError_t launch_sweep_tiled_n2(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false);  // two tiles per block
+hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false, int phases = PH_ALL);     // picks a variant
+hipError_t launch_sweep_tiled_n1(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false, int phases = PH_ALL);  // one 16x4 tile per block
+hipError_t launch_sweep_tiled_n2(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false, int phases = PH_ALL);  // two tiles per block
 hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t stream);          // pre-pass of both (also clears flags + queues)
 hipError_t clear_sweep_flags(const SweepArgs& a, void* workspace, hipStream_t stream);
 // encoder epilogue: cat(feat, avg_pool2d(rgb)) -> packed source views + NCHW reference view, in one pass (a.C = Cf + 3)
@@ -60,7 +66,7 @@ size_t sweep_ws_flag_bytes(int B, int H, int W);
 
 // sweep_mfma.hip (L2 only; same workspace as the tiled kernel): the channel contraction on the matrix pipe
 bool sweep_mfma_supports(const SweepArgs& a);
-hipError_t launch_sweep_mfma(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false);
+hipError_t launch_sweep_mfma(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false, int phases = PH_ALL);
 
 // sweep_cells.hip (L2 only; same workspace as the tiled kernel)
 int sweep_cells_max_planes();

@@ -40,6 +40,7 @@
 
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "pick.hpp"
 
 namespace pdepth {
 
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
     __shared__ WaveLds wlds[4];
     __shared__ float dcl[64 * NHALF];
 
+    if (a.pick == PICK_RUN_IF_SET && queue[PICK_SLOT] == 0) return;   // (the pre-pass chose the other kernel: pick.hpp)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLds& L = wlds[wave];
@@ -197,24 +199,7 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
     // batch item, from four probe pixels: does the sample move by more than half a source row between the first and the
     // last plane?  (Any choice is correct; this one is within 1 % of the best choice per tile on both benchmark poses.)
     __shared__ unsigned char s_wide[64];
-    for (int bb = threadIdx.x; bb < min(a.B, 64); bb += 256) {
-        ViewXform xf;
-        make_view_xform(a.K + bb * 9, a.R + (size_t)bb * V * 9, a.t + (size_t)bb * V * 3, a.blas_mode, xf);
-        const float cx = a.cxcy[bb * 2 + 0], cy = a.cxcy[bb * 2 + 1];
-        const float rcx = refined_rcp(cx), rcy = refined_rcp(cy);
-        bool steep = false;
-        for (int pr = 0; pr < 4; ++pr) {
-            const int px = (pr & 1) ? (7 * W) / 8 : W / 8, py = (pr & 2) ? (7 * H) / 8 : H / 8, pc = py * W + px;
-            const size_t HW0 = (size_t)H * W;
-            float t2a, t2b, t2c, ix0, iy0, ix1, iy1;
-            ray_term2(xf, a.rays[((size_t)bb * 3 + 0) * HW0 + pc], a.rays[((size_t)bb * 3 + 1) * HW0 + pc],
-                      a.rays[((size_t)bb * 3 + 2) * HW0 + pc], t2a, t2b, t2c);
-            plane_sample_pos_fast(xf, t2a, t2b, t2c, dcl[0], cx, cy, rcx, rcy, half_w, half_h, ix0, iy0);
-            plane_sample_pos_fast(xf, t2a, t2b, t2c, dcl[D - 1], cx, cy, rcx, rcy, half_w, half_h, ix1, iy1);
-            steep = steep || fabsf(iy1 - iy0) > 0.5f;
-        }
-        s_wide[bb] = steep ? 0 : 1;
-    }
+    for (int bb = threadIdx.x; bb < min(a.B, 64); bb += 256) s_wide[bb] = epipolar_lines_are_flat(a, bb) ? 1 : 0;
 
     // Persistent workgroups: the grid fills the chip once (two workgroups per CU) and every workgroup pulls tiles -- (batch
     // item, 16x4 tile) -- from the queue of its XCD; wave w takes the tile's sub-block w, so the four waves, which read
@@ -781,15 +766,16 @@ hipError_t launch_by_npl(int npl, const SweepArgs& a, const float4* packed, int*
 
 // Launches the pre-pass (unless the workspace is already packed), the matrix-pipe kernel, then the gather kernel on the
 // tiles it flagged.  Workspace layout as the tiled kernel's.
-hipError_t launch_sweep_mfma(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready) {
+hipError_t launch_sweep_mfma(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready, int phases) {
     const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 3) / 4, tiles = tiles_x * tiles_y;
     int* flags = reinterpret_cast<int*>(workspace);
     float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + sweep_ws_flag_bytes(a.B, a.H, a.W));
     int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + sweep_ws_flag_only_bytes(a.B, a.H, a.W));
-    hipError_t e = packed_ready ? clear_sweep_flags(a, workspace, stream) : launch_pack_c4(a, workspace, stream);
+    hipError_t e = hipSuccess;
+    if (phases & PH_PRE) e = packed_ready ? clear_sweep_flags(a, workspace, stream) : launch_pack_c4(a, workspace, stream);
     if (e != hipSuccess) return e;
-    e = launch_by_npl<MFMA_MAX_NPL>((a.C + 3) / 4, a, packed, flags, queue, tiles_x, tiles, stream);
-    if (e != hipSuccess) return e;
+    if (phases & PH_KERNEL) e = launch_by_npl<MFMA_MAX_NPL>((a.C + 3) / 4, a, packed, flags, queue, tiles_x, tiles, stream);
+    if (e != hipSuccess || !(phases & PH_GATHER)) return e;
     SweepArgs ag = a;
     ag.packed_src = packed;
     return launch_sweep_direct_flagged(ag, flags, queue + GATHER_COUNT_SLOT, tiles_x, tiles, stream);

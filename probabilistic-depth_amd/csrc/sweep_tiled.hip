@@ -56,6 +56,7 @@
 
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "pick.hpp"
 
 namespace pdepth {
 
@@ -232,6 +233,7 @@ template <int METRIC, bool SPEC>
 __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a, const float4* __restrict__ packed,
                                                               int* __restrict__ tile_flags, int* __restrict__ queue,
                                                               int tiles_x, int ntile) {
+    if (PDEPTH_COLD_ARG(int, pick) == PICK_SKIP_IF_SET && queue[PICK_SLOT] != 0) return;   // (the pre-pass chose the other kernel: pick.hpp)
     const int aD = SPEC ? 64 : a.D, aC = SPEC ? 67 : a.C, aV = SPEC ? 1 : a.V;
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
     float4* win = lds4;                                   // [NBUF][NTEX_MAX]
@@ -965,11 +967,17 @@ tile_done:
 // One thread per texel, channels in order (sequential fma: deterministic); the neighbours' loads hit L1/L2.
 __global__ __launch_bounds__(256) void pack_c4_kernel(const float* __restrict__ src, long long bstride,
                                                       long long vstride, int V, int C, int H, int W,
-                                                      float4* __restrict__ out, int* __restrict__ flags, int nflags) {
+                                                      float4* __restrict__ out, int* __restrict__ flags, int nflags, SweepArgs pa, int* pick_queue) {
     const int HW = H * W;
-    // also clears the tile flags of this call (saves a memset launch)
+    // also clears the tile flags of this call (saves a memset launch) -- except the kernel-choice slot, which the first
+    // block writes (cleared or set: pick.hpp)
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < nflags; i += gridDim.x * gridDim.y * 256)
-        flags[i] = 0;
+        if (flags + i != pick_queue + PICK_SLOT) flags[i] = 0;
+    if (pick_queue && blockIdx.x == 0 && blockIdx.y == 0) {
+        if (threadIdx.x == 0) pick_queue[PICK_SLOT] = 0;
+        __syncthreads();
+        if (pa.pick != 0) pick_for_launch(pa, pick_queue, threadIdx.x, 256);
+    }
     // XCD-aware block order (workgroups are dealt round-robin over the 8 XCDs): every XCD packs one contiguous band
     // of rows, so the row below -- which another block of the same band loads as its own row -- hits that XCD's L2
     const int nb = gridDim.x, xcd = blockIdx.x & 7, qq = nb >> 3, rr = nb & 7;
@@ -1117,8 +1125,9 @@ hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t strea
     float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + flag_bytes(a.B, a.H, a.W));
     const int HW = a.H * a.W;
     dim3 pgrid((HW + 255) / 256, a.B * a.V);
+    int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + flag_only_bytes(a.B, a.H, a.W));
     hipLaunchKernelGGL(pack_c4_kernel, pgrid, dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V, a.C, a.H, a.W, packed,
-                       flags, (int)(flag_bytes(a.B, a.H, a.W) / sizeof(int)));
+                       flags, (int)(flag_bytes(a.B, a.H, a.W) / sizeof(int)), a, queue);
     return hipGetLastError();
 }
 
@@ -1137,13 +1146,30 @@ hipError_t launch_pack_views(const SweepArgs& a, const float* feat, const float*
 // Two tiles per block pay off when two such blocks fit a CU (the cost tiles of both sub-tiles live in LDS: D <= 64)
 // and the image is large enough for the wider windows not to dominate; measured on the BASELINE configurations.
 // (PDEPTH_ALGO_TILED_1 / _2 force a variant.)
-hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready) {
+hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready, int phases) {
     const bool two = a.D <= 64 && (long long)a.H * a.W >= 96 * 1024 && a.W >= 128;
-    return two ? launch_sweep_tiled_n2(a, workspace, stream, packed_ready) : launch_sweep_tiled_n1(a, workspace, stream, packed_ready);
+    return two ? launch_sweep_tiled_n2(a, workspace, stream, packed_ready, phases) : launch_sweep_tiled_n1(a, workspace, stream, packed_ready, phases);
+}
+
+// flag clear of a call on an already packed source when the kernel is chosen on the device (else: a memset)
+__global__ __launch_bounds__(256) void clear_and_pick_kernel(SweepArgs pa, int* flags, int nflags, int* queue) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nflags; i += gridDim.x * 256)
+        if (flags + i != queue + PICK_SLOT) flags[i] = 0;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) queue[PICK_SLOT] = 0;
+        __syncthreads();
+        pick_for_launch(pa, queue, threadIdx.x, 256);
+    }
 }
 
 // The pre-pass also clears the tile flags and queue counters; a call on an already packed source clears them itself.
 hipError_t clear_sweep_flags(const SweepArgs& a, void* workspace, hipStream_t stream) {
+    if (a.pick != 0) {
+        int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + flag_only_bytes(a.B, a.H, a.W));
+        const int nflags = (int)(flag_bytes(a.B, a.H, a.W) / sizeof(int));
+        hipLaunchKernelGGL(clear_and_pick_kernel, dim3((nflags + 2047) / 2048), dim3(256), 0, stream, a, reinterpret_cast<int*>(workspace), nflags, queue);
+        return hipGetLastError();
+    }
     return hipMemsetAsync(workspace, 0, flag_bytes(a.B, a.H, a.W), stream);
 }
 
@@ -1168,13 +1194,14 @@ static bool getenv_once_no_spec() {
     return v;
 }
 
-hipError_t PDEPTH_CAT(launch_sweep_tiled_n, PDEPTH_NSUB)(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready) {
+hipError_t PDEPTH_CAT(launch_sweep_tiled_n, PDEPTH_NSUB)(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready, int phases) {
     const int tiles16_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;  // the gather kernel's (and the flags') tiles
     const int tiles_x = (a.W + TW * NSUB - 1) / (TW * NSUB);                  // this kernel's work items per row
     const int tiles = tiles_x * tiles_y;
     int* flags = reinterpret_cast<int*>(workspace);
     float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + flag_bytes(a.B, a.H, a.W));
-    hipError_t e = packed_ready ? clear_sweep_flags(a, workspace, stream) : launch_pack_c4(a, workspace, stream);
+    hipError_t e = hipSuccess;
+    if (phases & PH_PRE) e = packed_ready ? clear_sweep_flags(a, workspace, stream) : launch_pack_c4(a, workspace, stream);
     if (e != hipSuccess) return e;
     const size_t lds = tiled_lds_bytes(a.D);
     int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + flag_only_bytes(a.B, a.H, a.W));
@@ -1189,6 +1216,7 @@ hipError_t PDEPTH_CAT(launch_sweep_tiled_n, PDEPTH_NSUB)(const SweepArgs& a, voi
     dim3 grid(nblk);
     // (the dynamic-LDS attribute is per kernel, sticky and the same on every device: set it whenever more than the
     //  default is needed -- no cached state, and a failure is reported instead of surfacing as a launch error)
+    if (phases & PH_KERNEL) {
     if (a.metric == 0 && a.D == 64 && a.C == 67 && a.V == 1 && !getenv_once_no_spec()) {
         auto kern = PDEPTH_VARIANT::sweep_tiled_kernel<0, true>;
         if (lds > 64 * 1024) {
@@ -1211,8 +1239,9 @@ hipError_t PDEPTH_CAT(launch_sweep_tiled_n, PDEPTH_NSUB)(const SweepArgs& a, voi
         }
         hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles);
     }
+    }
     e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || !(phases & PH_GATHER)) return e;
     SweepArgs ag = a;
     ag.packed_src = packed;   // (the gather kernel's source when the caller passed a packed source only)
     return launch_sweep_direct_flagged(ag, flags, queue + GATHER_COUNT_SLOT, tiles16_x, tiles16_x * tiles_y, stream);

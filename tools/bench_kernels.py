@@ -54,11 +54,18 @@ def main():
     sweep_case("cfg5 D=128 512x1024 V=4 B=2 (per-GPU share of B=16)", 2, 67, 128, 512, 1024, 4, "mono", steps=5)
     sweep_case("cfg2 mono 256x512 B=4 gather kernel", 4, 67, 64, 256, 512, 1, "mono", algo="direct", steps=5)
     # the implementations behind "auto", forced (A/B): one-tile and two-tile builds of the tiled kernel, cell-list kernels
-    for algo in ("tiled1", "tiled2", "cells"):
+    for algo in ("tiled1", "tiled2", "cells", "mfma"):
         sweep_case("cfg2 mono 256x512 B=4", 4, 67, 64, 256, 512, 1, "mono", algo=algo)
         sweep_case("cfg3 stereo 256x512 B=4", 4, 67, 64, 256, 512, 1, "stereo", algo=algo)
         sweep_case("model-real 64x128 B=4", 4, 67, 64, 64, 128, 1, "mono", algo=algo, steps=50)
     sweep_case("cfg5 D=128 512x1024 V=4 B=2", 2, 67, 128, 512, 1024, 4, "mono", algo="cells", steps=5)
+    sweep_case("cfg5 D=128 512x1024 V=4 B=2", 2, 67, 128, 512, 1024, 4, "mono", algo="tiled1", steps=5)
+    # BASELINE config 1 as the reference runs it (train.py:64-73: eval is B = 1; models.py:518: the sweep at 1/4 resolution):
+    # one frame pair, 64x128 (256x512 image) and 64x96 (the default 256x384 crop).  Wall time of back-to-back calls here;
+    # the GPU time of the same calls (rocprofv3 kernel trace, launches per call) is in profiles/ (tools/prof_small.sh).
+    for (H, W) in ((64, 128), (64, 96)):
+        for algo in ("auto", "tiled1", "cells", "mfma"):
+            sweep_case("cfg1 one frame pair B=1 %dx%d" % (H, W), 1, 67, 64, H, W, 1, "mono", algo=algo, steps=100)
     # packed-source entry (pdepth_pack_source_f32 once, pdepth_sweep_dpv_packed_f32 per step) and the pre-pass alone
     b = synth.make_batch(2, 4, C=67, D=64, H=256, W=512, V=1, pose="mono")
     d = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
@@ -126,10 +133,11 @@ def model_cases():
     import time
     from pdepth_amd import harness
     from pdepth_amd.models import get_model
-    for nmode in ("default", "default_feedback"):
+    for nmode, packed in (("default", True), ("default", False), ("default_feedback", True), ("default_feedback", False)):
         model = get_model(synth.default_cfg(nmode), 0)
         synth.seed_weights(model, seed=8)
         model = model.cuda().eval()
+        model.packed_epilogue = packed   # True: encoder epilogue kernel + packed sweep entry; False: cat + avg_pool2d + plain entry
         frames = [harness.move_input(synth.make_model_input(4000 + i, B=1, V=1, H=256, W=512, D=64, pose="mono"), "cuda")
                   for i in range(5)]
         harness.eval_trajectory(model, frames)  # warm-up (MIOpen find)
@@ -140,7 +148,30 @@ def model_cases():
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 15 * 1e3
         print(json.dumps({"case": "cfg4-style whole model nmode=%s, 5-frame trajectory, B=1, 256x512 image" % nmode,
+                          "encoder_epilogue": "pack_views kernel + packed sweep entry" if packed else "torch.cat + avg_pool2d + plain entry",
                           "ms_per_frame": ms, "frames_per_s": 1e3 / ms}), flush=True)
+    # the head alone (PacknetHead: sweep -> log-softmax -> E[d]) from the encoder output, both ways, at the model's own
+    # 1/4 resolution and at the benchmark's 256x512
+    import torch.nn.functional as F
+    for (B, h, w) in ((1, 64, 128), (4, 256, 512)):
+        g = torch.Generator().manual_seed(3)
+        feat = torch.randn(B * 2, 64, h, w, generator=g).cuda()
+        rgb = torch.rand(B * 2, 3, 4 * h, 4 * w, generator=g).cuda()
+        it = synth.make_batch(2, B, C=67, D=64, H=h, W=w, V=1, pose="mono")
+        d = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in it.items()}
+        dc = ops.d_candi_tensor(d["d_candi"], "cuda")
+        cam = (d["K"], d["R"], d["t"], d["rays"], d["cxcy"], dc, 10.0)
+
+        def old():
+            both = torch.cat((feat, F.avg_pool2d(rgb, 4)), dim=1).view(B, 2, 67, h, w)
+            return ops.sweep_dpv(both[:, -1], both[:, :-1], *cam)
+
+        def new():
+            ps, ref = ops.pack_views(feat, rgb, 2, 64)
+            return ops.sweep_dpv(ref, ps, *cam)
+        for name, fn in (("torch.cat + avg_pool2d + pdepth_sweep_dpv_f32 (pre-pass inside)", old), ("pdepth_pack_views_f32 + pdepth_sweep_dpv_packed_f32", new)):
+            ms = timeit(fn, steps=50)
+            print(json.dumps({"case": "head from encoder output, B=%d %dx%d" % (B, h, w), "path": name, "ms": ms}), flush=True)
 
 
 if __name__ == "__main__":
