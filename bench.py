@@ -145,6 +145,11 @@ def main():
                            dtype=torch.float32, device=dev)
     allm = pdist.gather_metrics(metrics).cpu()
     fallback = pdepth_amd._native.fallback_tiles(hi - lo, cfg["H"], cfg["W"], gather_flag=2 if a.algo == "cells" else 1)
+    # which sweep kernel ran: the selector, or -- ALGO_AUTO on this shape class -- the device-side choice of the pre-pass
+    tiled_class = cfg["V"] == 1 and cfg["D"] <= 64 and cfg["H"] * cfg["W"] >= 96 * 1024
+    impl = a.algo if a.algo != "auto" else (pdepth_amd._native.sweep_choice(hi - lo, cfg["H"], cfg["W"]) if tiled_class else "mfma")
+    if os.environ.get("PDEPTH_SWEEP_IMPL") and a.algo == "auto":
+        impl = os.environ["PDEPTH_SWEEP_IMPL"]
 
     packed_entry = None
     if a.algo == "auto":   # secondary: the same step on features already in the kernels' staging layout
@@ -159,15 +164,25 @@ def main():
         bpv = algorithmic_bytes_per_volume(cfg["C"], cfg["V"], cfg["D"], cfg["H"], cfg["W"])
         prof = {}
         tj = os.path.join(REPO, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj) and a.algo == "auto" and a.pose == "mono":   # the committed counters are of the default workload
+        if os.path.exists(tj):
+            # committed PMC counters (tools/prof.sh): attached only to the workload AND the kernel they were collected on
             try:
-                prof = json.load(open(tj))
+                for rec in json.load(open(tj)).get("workloads", []):
+                    w = rec.get("workload", {})
+                    if (w.get("batch"), w.get("C"), w.get("D"), w.get("H"), w.get("W"), w.get("V"), w.get("pose"), w.get("kernel")) == \
+                            (hi - lo, cfg["C"], cfg["D"], cfg["H"], cfg["W"], cfg["V"], cfg["pose"], impl):
+                        prof = rec
             except Exception:
                 prof = {}
+        kname = {"mfma": "sweep_mfma_kernel (matrix-pipe kernel)", "tiled": "sweep_tiled_kernel (LDS-tiled band kernel)",
+                 "tiled1": "sweep_tiled_kernel, one tile per block", "tiled2": "sweep_tiled_kernel, two tiles per block",
+                 "cells": "sweep_cells_fast_kernel + sweep_cells_kernel", "direct": "sweep_direct_kernel (gather)"}.get(impl, str(impl))
         roof = {"traffic": prof.get("hbm_bytes_per_launch"),
                 "traffic_source": prof.get("source"),
-                "kernel": "fused sweep+DPV call = pack_c4_kernel (source re-layout pre-pass) + sweep_tiled_kernel "
-                          "(+ the gather kernel on flagged tiles)",
+                "kernel": "fused sweep+DPV call = pack_c4_kernel (source re-layout pre-pass) + " + kname +
+                          " (+ the gather kernel on flagged tiles" + ("; ALGO_AUTO launches both sweep kernels on this shape class and "
+                          "the pre-pass picks one on the device, the other leaves at once)" if (a.algo == "auto" and tiled_class) else ")"),
+                "sweep_kernel": impl,
                 # secondary figure of SURVEY 8(d): flops of the direct formulation, 11*D*h*w*V*C per volume, against
                 # the dense fp32 vector peak (157.3 TFLOP/s); the band mode executes fewer
                 "algorithmic_tflops": 11.0 * cfg["D"] * cfg["H"] * cfg["W"] * cfg["V"] * cfg["C"] * (hi - lo)

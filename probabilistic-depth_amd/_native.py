@@ -325,6 +325,17 @@ def sweep(ref, src, K, R, t, rays, cxcy, d_candi, sigma, metric=METRIC_L2, algo=
 _last_workspace = None
 
 
+def sweep_choice(B, H, W):
+    """Diagnostics: which kernel the device-side choice of the last ALGO_AUTO sweep picked -- 'mfma' / 'tiled' -- for the
+    shape class where both are launched (single view, <= 64 planes, large image: csrc/pick.hpp); the slot is 0 ('tiled')
+    after every other call."""
+    if _last_workspace is None:
+        return None
+    n = B * ((W + 15) // 16) * ((H + 3) // 4)
+    flag_only = (4 * n + 255) & ~255
+    return "mfma" if int(_last_workspace[flag_only + 200: flag_only + 204].view(torch.int32).item()) == 1 else "tiled"
+
+
 def fallback_tiles(B, H, W, gather_flag=1):
     """Diagnostics: how many 16x4 tiles of the last sweep were left to the gather kernel.  A tile's flag is the value the
     gather kernel is launched for: 1 after the tiled and the matrix-pipe kernels; the cell-list path flags 1 = redone by
