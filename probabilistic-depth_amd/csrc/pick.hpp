@@ -12,6 +12,23 @@
 
 namespace pdepth {
 
+// one probe pixel (pr = 0..3) of batch item b: does the sample move by more than half a source row over the depth range?
+__device__ __forceinline__ bool epipolar_probe_is_steep(const SweepArgs& a, int b, int pr) {
+    ViewXform xf;
+    make_view_xform(a.K + b * 9, a.R + (size_t)b * a.V * 9, a.t + (size_t)b * a.V * 3, a.blas_mode, xf);
+    const float cx = a.cxcy[b * 2 + 0], cy = a.cxcy[b * 2 + 1];
+    const float rcx = refined_rcp(cx), rcy = refined_rcp(cy);
+    const float half_w = (float)a.W / 2.0f, half_h = (float)a.H / 2.0f;
+    const size_t HW = (size_t)a.H * a.W;
+    const int px = (pr & 1) ? (7 * a.W) / 8 : a.W / 8, py = (pr & 2) ? (7 * a.H) / 8 : a.H / 8, pc = py * a.W + px;
+    float t2a, t2b, t2c, ix0, iy0, ix1, iy1;
+    ray_term2(xf, a.rays[((size_t)b * 3 + 0) * HW + pc], a.rays[((size_t)b * 3 + 1) * HW + pc], a.rays[((size_t)b * 3 + 2) * HW + pc],
+              t2a, t2b, t2c);
+    plane_sample_pos_fast(xf, t2a, t2b, t2c, a.d_candi[0], cx, cy, rcx, rcy, half_w, half_h, ix0, iy0);
+    plane_sample_pos_fast(xf, t2a, t2b, t2c, a.d_candi[a.D - 1], cx, cy, rcx, rcy, half_w, half_h, ix1, iy1);
+    return fabsf(iy1 - iy0) > 0.5f;   // (NaN: not steep)
+}
+
 __device__ __forceinline__ bool epipolar_lines_are_flat(const SweepArgs& a, int b) {
     ViewXform xf;
     make_view_xform(a.K + b * 9, a.R + (size_t)b * a.V * 9, a.t + (size_t)b * a.V * 3, a.blas_mode, xf);

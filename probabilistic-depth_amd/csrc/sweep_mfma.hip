@@ -199,7 +199,11 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
     // batch item, from four probe pixels: does the sample move by more than half a source row between the first and the
     // last plane?  (Any choice is correct; this one is within 1 % of the best choice per tile on both benchmark poses.)
     __shared__ unsigned char s_wide[64];
-    for (int bb = threadIdx.x; bb < min(a.B, 64); bb += 256) s_wide[bb] = epipolar_lines_are_flat(a, bb) ? 1 : 0;
+    // (thread = (batch item, probe): the four probes of an item side by side, not one after the other -- on a small problem
+    //  the prologue is a visible part of the launch)
+    if (threadIdx.x < 64) s_wide[threadIdx.x] = 1;
+    __syncthreads();
+    if ((int)(threadIdx.x >> 2) < min(a.B, 64) && epipolar_probe_is_steep(a, threadIdx.x >> 2, threadIdx.x & 3)) s_wide[threadIdx.x >> 2] = 0;
 
     // Persistent workgroups: the grid fills the chip once (two workgroups per CU) and every workgroup pulls tiles -- (batch
     // item, 16x4 tile) -- from the queue of its XCD; wave w takes the tile's sub-block w, so the four waves, which read
@@ -288,9 +292,18 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
 
     // s_item: a ring of three -- the tile being worked on, the next one (its pixel loads are in flight), and the one
     // thread 0 is fetching from the queue meanwhile
+    // (when the grid covers every tile -- small problems -- workgroup i simply takes tile i of its XCD's band: no atomics on
+    //  the critical path of a launch that is latency bound anyway; else the first two tiles come from ONE atomic)
+    const bool one_each = (long long)gridDim.x >= 8ll * ((ntile + 7) / 8) * a.B;
     if (threadIdx.x == 0) {
-        s_item[0] = resolve(atomicAdd(&queue[xcd], 1));
-        s_item[1] = s_item[0] < 0 ? -1 : resolve(own_done ? 0 : atomicAdd(&queue[xcd], 1));
+        if (one_each) {
+            s_item[0] = (int)(blockIdx.x >> 3) < n_own ? (xcd << 28) | (int)(blockIdx.x >> 3) : -1;
+            s_item[1] = -1;
+        } else {
+            const int got = atomicAdd(&queue[xcd], 2);
+            s_item[0] = resolve(got);
+            s_item[1] = s_item[0] < 0 ? -1 : resolve(own_done ? 0 : got + 1);
+        }
     }
     __syncthreads();
     int slot = 0;
@@ -734,8 +747,8 @@ template <int NPL>
 hipError_t launch_npl(const SweepArgs& a, const float4* packed, int* flags, int* queue, int tiles_x, int tiles, hipStream_t stream) {
     // persistent grid: two workgroups of four waves per CU (LDS: 2 x 80 KB), a multiple of 8; fewer when there is less work
     long long nblk = ((long long)sweep_device_cus() * MFMA_WG_PER_CU + 7) & ~7ll;
-    const long long need = 8ll * (((long long)tiles * a.B + 7) / 8);   // a workgroup per tile
-    if (need < nblk) nblk = need;
+    const long long need = 8ll * ((tiles + 7) / 8) * a.B;   // a workgroup per tile of the largest XCD band, times 8
+    if (need <= nblk) nblk = need;
     if (a.D <= 64)
         hipLaunchKernelGGL((sweep_mfma_kernel<NPL, 1>), dim3((unsigned)nblk), dim3(256), 0, stream, a, packed, flags, queue, tiles_x, tiles);
     else
