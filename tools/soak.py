@@ -104,7 +104,7 @@ def where(ca, cd, fin):
 def main():
     rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-    only = set(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else None
+    only = set(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 and sys.argv[3] else None
     force = sys.argv[4] if len(sys.argv) > 4 else None
     worst = worst_d = 0.0
     n = fb = 0
@@ -125,6 +125,8 @@ def main():
             algo = "auto"
         if force:
             algo = force
+            if force == "mfma" and (metric == "L1" or s["D"] > 128 or s["C"] > 72):
+                algo = "tiled1"   # (shapes the matrix-pipe kernel is not built for)
         args = (d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 8.0)
         tag = describe(case, algo, s, metric)
         if DPV:
