@@ -11,6 +11,6 @@ for spec in "$@"; do
   name=${spec%%:*}; defs=${spec#*:}
   /opt/rocm/bin/hipcc $FLAGS $defs -c $C/sweep_mfma.hip -o /tmp/sweep_mfma_$name.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_variants/libm_$name.so $C/capi.o $C/sweep_direct.o $C/sweep_tiled.o \
-      $C/sweep_tiled_n2.o /tmp/sweep_mfma_$name.o $C/sweep_cells.o $C/sweep_cells_fast.o $C/dpv.o $C/warp.o $C/extras.o $C/ufield.o
+      $C/sweep_tiled_n2.o /tmp/sweep_mfma_$name.o $C/sweep_cells.o $C/sweep_cells_fast.o $C/dpv.o $C/warp.o $C/extras.o $C/correlation_general.o $C/ufield.o
   echo built gpurun_variants/libm_$name.so "($defs)"
 done
