@@ -241,11 +241,27 @@ __global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const f
     // rounding error of the product with the reciprocal (the integer divide costs ~40 dependent instructions, four per tile)
     auto fdiv = [](int nn, int dd) { return (int)(((float)nn + 0.5f) * __builtin_amdgcn_rcpf((float)dd)); };
     const bool small_idx = (long long)ntile * a.B < (1ll << 22);
+    const int tiles_y_ = (H + 3) / 4;
+    const bool balanced = rr8 == 0 && tiles_y_ % 16 == 0 && tiles_y_ * tiles_x == ntile;
     auto decode = [&](int item, int& b_, int& tx_, int& ty_) {
         const int q_ = item >> 28, iq = item & 0x0fffffff, band_tiles = band_tiles_of(q_);
         b_ = small_idx ? fdiv(iq, band_tiles) : iq / band_tiles;
         const int ti = iq - b_ * band_tiles;
         int tile = band_first_of(q_) + ti;
+#ifndef MFMA_NO_BALANCE
+        if (balanced) {
+            // XCD q owns half-bands q and 8 + q of the image's 16 (q = 0: the top strip and the strip just below the middle):
+            // on a forward motion the cost of a tile grows with its distance from the image centre, and this way every XCD
+            // gets the same mix; the heavier half first and, inside a half, columns from both image borders inwards -- the
+            // launch ends on cheap tiles.  (Any static partition is valid: queues that run dry steal from the others.)
+            const int hb_rows = tiles_y_ / 16, half_tiles = hb_rows * tiles_x;
+            const int second = ti >= half_tiles ? 1 : 0, tih = ti - second * half_tiles;
+            const int hbi = (q_ < 4) == (second == 0) ? q_ : 8 + q_;
+            const int cc = small_idx ? fdiv(tih, hb_rows) : tih / hb_rows, r_ = tih - cc * hb_rows;
+            const int col = (cc & 1) ? tiles_x - 1 - (cc >> 1) : (cc >> 1);
+            tile = (hbi * hb_rows + r_) * tiles_x + col;
+        } else
+#endif
         if (colmajor) {
             const int band_rows = qq / tiles_x, tc = small_idx ? fdiv(ti, band_rows) : ti / band_rows;
             tile = (q_ * band_rows + (ti - tc * band_rows)) * tiles_x + tc;
