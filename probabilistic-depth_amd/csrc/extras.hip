@@ -10,6 +10,8 @@
 //               It is dead code w.r.t. get_model (only PWCLite uses it), provided for completeness.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace pdepth {
@@ -214,8 +216,103 @@ __global__ __launch_bounds__(256) void correlation_fwd_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// correlation forward on the matrix pipe (C <= 256, max_displacement <= 16): the sum over the channels is a contraction,
+// and for 16 neighbouring pixels of a row the texels of one displacement row they multiply with are 16 + 2 * max_displacement
+// consecutive texels -- a banded 16 x (16 + 2 md) x C matrix product.  v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32
+// accumulation) computes it in ceil((16 + 2 md) / 16) blocks of 16 texels; of the 16 x 16 results of a block the (pixel,
+// texel) pairs on the band's 2 r + 1 diagonals are outputs, the rest is matrix-pipe time nothing else wants.
+//   wave  = 16 pixels of one image row, all displacement rows in turn (4 waves per workgroup: 4 pixel groups of the row);
+//   B operand = x1[4 k + kq][y][x0 + n], held in registers for the whole wave (C / 4 of them);
+//   A operand = x2[4 k + kq][y + dy][t0 + m] by buffer_load_dword (16 lanes = 64 contiguous bytes; outside the image:
+//               out-of-range offset = 0 = the zero padding);
+//   results pass through 9 x 16 floats of LDS per wave so that every displacement plane gets 64-byte row segments.
+// ---------------------------------------------------------------------------------------------------
+typedef float corr_v4f __attribute__((ext_vector_type(4)));
+template <int KMAX>   // channel groups of 4 held in registers: C <= 4 * KMAX
+__global__ __launch_bounds__(256) void correlation_fwd_mfma_kernel(const float* __restrict__ x1, const float* __restrict__ x2, int C, int H,
+                                                                   int W, int r, int s2, float* __restrict__ out) {
+    __shared__ float tr[4][9 * 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
+    const int HW = H * W, md = r * s2, ND = 2 * r + 1, nk = (C + 3) / 4, nblk = (16 + 2 * md + 15) / 16;
+    const int xblocks = (W + 63) / 64;
+    const int b = blockIdx.x / (H * xblocks), rem = blockIdx.x - b * (H * xblocks), y = rem / xblocks;
+    const int x0 = (rem - y * xblocks) * 64 + wave * 16;
+    if (x0 >= W) return;   // (wave-uniform; no barrier in this kernel)
+    const int OOBO = 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(x1 + (size_t)b * C * HW), 0, C * HW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(x2 + (size_t)b * C * HW), 0, C * HW * 4, 0x00020000);
+    float Rb[KMAX];
+    {
+        const bool okp = x0 + n < W;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int c = 4 * k + kq;
+            Rb[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, (k < nk && c < C && okp) ? (c * HW + y * W + x0 + n) * 4 : OOBO, 0, 0));
+        }
+    }
+    const float inv = 1.0f / (float)C;
+    float* const t = tr[wave];
+    for (int di = 0; di < ND; ++di) {
+        const int row2 = y + (di - r) * s2;
+        const bool rowok = (unsigned)row2 < (unsigned)H;
+        for (int blk = 0; blk < nblk; ++blk) {
+            // four interleaved chains (pairwise at the end): a quarter of the additions per chain keeps the rounding of a
+            // 256-channel sum inside the reference's own 1e-7 self-check bound, and four matrix instructions are independent
+            corr_v4f accs[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) accs[q] = corr_v4f{0.f, 0.f, 0.f, 0.f};
+            const int tx = x0 - md + 16 * blk + n;
+            const bool okt = rowok && (unsigned)tx < (unsigned)W;
+            const int base = (row2 * W + tx) * 4;
+#pragma unroll
+            for (int k = 0; k < KMAX; k += 4) {   // (fully unrolled: Rb stays in registers; groups beyond C are skipped uniformly)
+                if (k < nk) {
+                    float av[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = 4 * (k + q) + kq;
+                        av[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2, (okt && c < C) ? base + c * HW * 4 : OOBO, 0, 0));
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) accs[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], Rb[k + q], accs[q], 0, 0, 0);
+                }
+            }
+            const corr_v4f acc = (accs[0] + accs[1]) + (accs[2] + accs[3]);
+            // lane (n, kq) holds texels m = 4 kq + i of the block for pixel n: offset of the texel from the pixel, in pixels
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int off = 16 * blk + 4 * kq + i - n - md;
+                const int q = off / s2;   // (s2 >= 1; exact when the offset is one of the displacements)
+                if (off >= -md && off <= md && q * s2 == off) t[(q + r) * 16 + n] = acc[i] * inv;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (wave-local: LDS operations of a wave complete in order)
+        float* o = out + ((size_t)b * ND * ND + (size_t)di * ND) * HW + (size_t)y * W + x0;
+        for (int idx = lane; idx < ND * 16; idx += 64) {
+            const int dj = idx >> 4, px = idx & 15;
+            if (x0 + px < W) o[(size_t)dj * HW + px] = t[idx];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+static bool correlation_forward_mfma_ok(int C, int H, int W, int radius, int stride2) {
+    return C <= 256 && radius * stride2 <= 16 && (long long)C * H * W * 4 < (1ll << 31);
+}
+
 hipError_t launch_correlation_forward(const float* x1, const float* x2, int B, int C, int H, int W, int radius,
                                       int stride2, float* out, hipStream_t stream) {
+    static const bool no_mfma = [] { const char* e = getenv("PDEPTH_CORR_NO_MFMA"); return e && e[0] == '1'; }();   // A/B timing
+    if (!no_mfma && radius >= 1 && radius <= RMAX && correlation_forward_mfma_ok(C, H, W, radius, stride2)) {
+        const long long nwg = (long long)B * H * ((W + 63) / 64);
+        if (nwg < (1ll << 31)) {
+            if (C <= 64) hipLaunchKernelGGL((correlation_fwd_mfma_kernel<16>), dim3((unsigned)nwg), dim3(256), 0, stream, x1, x2, C, H, W, radius, stride2, out);
+            else if (C <= 128) hipLaunchKernelGGL((correlation_fwd_mfma_kernel<32>), dim3((unsigned)nwg), dim3(256), 0, stream, x1, x2, C, H, W, radius, stride2, out);
+            else hipLaunchKernelGGL((correlation_fwd_mfma_kernel<64>), dim3((unsigned)nwg), dim3(256), 0, stream, x1, x2, C, H, W, radius, stride2, out);
+            return hipGetLastError();
+        }
+    }
     const int ND = 2 * radius + 1;
     dim3 grid((W + CT - 1) / CT, (H + CT - 1) / CT, B * ND);
     const int TW = CT + 2 * radius * stride2;

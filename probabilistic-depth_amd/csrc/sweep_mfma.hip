@@ -55,6 +55,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #ifndef MFMA_WG_PER_CU
 #define MFMA_WG_PER_CU 2
 #endif
+#ifndef MFMA_OCC   // waves per SIMD the register allocation must allow (experiment: 3 with MFMA_MAXB=9 and MFMA_WG_PER_CU=3)
+#define MFMA_OCC 2
+#endif
 #ifndef MFMA_ABL_STOP   // timing experiments (results wrong): 1 = skip everything after the sample positions, 2 = after the row
 #define MFMA_ABL_STOP 0 // table, 3 = after X, 4 = after the combine (no epilogue)
 #endif
@@ -165,7 +168,7 @@ struct __attribute__((aligned(16))) WaveLds {
 
 // NPL = packed feature planes of a source view (ceil(C / 4)); NHALF = ceil(D / 64).
 template <int NPL, int NHALF>
-__global__ __launch_bounds__(256, 2) void sweep_mfma_kernel(SweepArgs a, const float4* __restrict__ packed,
+__global__ __launch_bounds__(256, MFMA_OCC) void sweep_mfma_kernel(SweepArgs a, const float4* __restrict__ packed,
                                                              int* __restrict__ tile_flags, int* __restrict__ queue, int tiles_x,
                                                              int ntile) {
     constexpr int NCH = NPL / 4, NTL = NPL % 4;   // chunks of 16 channels (4 MFMAs per 16-byte load), left-over planes of 4
