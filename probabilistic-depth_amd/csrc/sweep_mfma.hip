@@ -509,7 +509,11 @@ __global__ __launch_bounds__(256, MFMA_OCC) void sweep_mfma_kernel(SweepArgs a, 
                         const int be = __builtin_amdgcn_readlane(myblk, bi);
                         const int yy = be >> 16, xx = (int)(short)(be & 0xffff) + n;
                         const bool ok = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
+#ifdef MFMA_ABL_ROWWRAP   // timing experiment (results wrong): every texel load from 16 source rows -- an L2-resident source
+                        const int t16 = ((yy & 15) * W + xx) * 16;
+#else
                         const int t16 = (yy * W + xx) * 16;
+#endif
                         const int vo = opaque_v(ok ? t16 + kq * HW * 16 : OOB);   // (opaque: one load with a selected offset, no branch)
 #ifdef MFMA_ABL_NOLOAD   // timing experiment (results wrong): what do the texel loads of the X phase cost?
 #pragma unroll

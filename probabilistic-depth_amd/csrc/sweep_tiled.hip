@@ -308,6 +308,20 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
         b_ = it / band_tiles;
         const int ti = it - b_ * band_tiles;
         tile_ = band_first_of(qx) + ti;
+#ifndef PDEPTH_NO_BALANCE
+        const int tiles_y_ = ntile / tiles_x;
+        if (rr == 0 && tiles_y_ % 16 == 0 && tiles_y_ * tiles_x == ntile) {
+            // XCD q owns half-bands q and 8 + q of the image's 16 (as the matrix-pipe kernel, sweep_mfma.hip): on a forward
+            // motion the cost of a tile grows with its distance from the image centre, and this way every XCD gets the same
+            // mix; the heavier half first and, inside a half, columns from both image borders inwards.
+            const int hb_rows = tiles_y_ / 16, half_tiles = hb_rows * tiles_x;
+            const int second = ti >= half_tiles ? 1 : 0, tih = ti - second * half_tiles;
+            const int hbi = (qx < 4) == (second == 0) ? qx : 8 + qx;
+            const int cc = tih / hb_rows, r_ = tih - cc * hb_rows;
+            const int col = (cc & 1) ? tiles_x - 1 - (cc >> 1) : (cc >> 1);
+            tile_ = (hbi * hb_rows + r_) * tiles_x + col;
+        } else
+#endif
         if (colmajor) {
             // walk the band column by column, so that the blocks in flight on one XCD share a narrow strip of
             // source columns (working set ~1 MB instead of the full image width)
@@ -351,6 +365,9 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     }
     int item = __builtin_amdgcn_readfirstlane(queued ? s_item[0] : ((int)(blockIdx.x >> 3) < n_own ? (int)(blockIdx.x >> 3) | (xcd << 24) : -1));
     int item_par = 0;
+#ifdef PDEPTH_EXIT_STAMPS
+    if (tid == 0) atomicMax(reinterpret_cast<unsigned long long*>(queue + 16) + 4, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
     while (item >= 0) {
     if (tid == 0 && queued && !own_done) nxt_own = atomicAdd(&queue[xcd], 1);
     int b, tile, p; bool live;
@@ -961,6 +978,14 @@ tile_done:
     item_par ^= 1;
     item = __builtin_amdgcn_readfirstlane(s_item[item_par]);   // (block-uniform)
     }  // work items
+#ifdef PDEPTH_EXIT_STAMPS   // diagnostic build (tools/dbg/tiled_tail.py): when do the persistent blocks run out of work?
+    if (tid == 0) {
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(queue + 16);
+        atomicMax(st + 0, ~t); atomicMax(st + 1, t); atomicAdd(st + 2, t); atomicAdd(st + 3, 1ull);
+        atomicMax(st + 5 + xcd, t);   // (last exit per XCD)
+    }
+#endif
 }
 
 }  // namespace PDEPTH_VARIANT

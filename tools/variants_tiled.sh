@@ -12,7 +12,7 @@ if [ "$1" = build ]; then
   for spec in "$@"; do
     name=${spec%%:*}; defs=${spec#*:}
     /opt/rocm/bin/hipcc $FLAGS -DPDEPTH_NSUB=2 $defs -c $C/sweep_tiled.hip -o /tmp/sweep_tiled_n2_$name.o
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_variants/lib_$name.so $C/capi.o $C/sweep_direct.o $C/sweep_tiled.o \
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_variants/lib_$name.so $C/capi.o $C/sweep_direct.o $C/sweep_tiled.o $C/sweep_mfma.o \
         /tmp/sweep_tiled_n2_$name.o $C/sweep_cells.o $C/sweep_cells_fast.o $C/dpv.o $C/warp.o $C/extras.o $C/correlation_general.o $C/ufield.o
     echo built gpurun_variants/lib_$name.so "($defs)"
   done
