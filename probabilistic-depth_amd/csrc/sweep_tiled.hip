@@ -369,6 +369,9 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     if (tid == 0) atomicMax(reinterpret_cast<unsigned long long*>(queue + 16) + 4, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
     while (item >= 0) {
+#ifdef PDEPTH_EXIT_STAMPS
+    const unsigned long long t_item0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (tid == 0 && queued && !own_done) nxt_own = atomicAdd(&queue[xcd], 1);
     int b, tile, p; bool live;
     map_item(item, b, tile, live, p);
@@ -966,6 +969,13 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     }
     }
 tile_done:
+#ifdef PDEPTH_EXIT_STAMPS   // (diagnostic: the item's duration in 10 ns ticks over the depth of its first pixel, its start over the second)
+    if (tid == 0 && PDEPTH_COLD_ARG(float*, depth_out)) {
+        float* dd = PDEPTH_COLD_ARG(float*, depth_out) + (size_t)b * HW + (tile / tiles_x * TH) * a.W + (tile % tiles_x) * TW * NSUB;
+        dd[0] = (float)(__builtin_amdgcn_s_memrealtime() - t_item0);
+        dd[1] = (float)(t_item0 & 0xffffff);
+    }
+#endif
     if (tid == 0) {   // publish the next item (the barrier below makes it visible)
         int nx = -1;
         if (queued) {

@@ -26,3 +26,15 @@ print("%s %s: blocks %d  kernel %.1f us  first exit %.1f us  mean exit %.1f us  
     pose, algo, n, (last_exit - start) * 0.01, (first_exit - start) * 0.01, (mean_exit - start) * 0.01, (last_exit - start) * 0.01,
     100.0 * (last_exit - mean_exit) / (last_exit - start)))
 print("last exit per XCD (us): " + " ".join("%.1f" % ((x - start) * 0.01) for x in u[5:13]))
+# per-item durations (the stamps build writes them over the depth of the item's first pixel)
+_, _, depth = ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], dc, 10.0, algo=algo)
+torch.cuda.synchronize()
+iw = 32 if algo == "tiled2" else 16
+dur = depth[:, ::4, ::iw].cpu() * 0.01          # us, [B, 64, W/iw]
+t0 = depth[:, ::4, 1::iw].cpu()
+print("item duration us: mean %.1f  min %.1f  p50 %.1f  p90 %.1f  max %.1f" % (dur.mean(), dur.min(), dur.median(), dur.flatten().kthvalue(int(0.9 * dur.numel())).values, dur.max()))
+print("mean duration per half-band (16 strips, top to bottom), all items and columns:")
+print(" ".join("%.0f" % dur[:, 4 * i:4 * i + 4, :].mean() for i in range(16)))
+print("mean duration per column:")
+print(" ".join("%.0f" % dur[:, :, c].mean() for c in range(dur.shape[2])))
+print("mean duration per batch item: " + " ".join("%.0f" % dur[i].mean() for i in range(dur.shape[0])))
