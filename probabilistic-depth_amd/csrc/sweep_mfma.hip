@@ -195,6 +195,9 @@ __global__ __launch_bounds__(256, MFMA_OCC) void sweep_mfma_kernel(SweepArgs a, 
     unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_t = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef MFMA_EXIT_STAMPS
+    const unsigned long long exit_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // Shape of a tile's four pixel sub-blocks (16 pixels each, one per wave): 16x1 (pixel rows) where the epipolar lines of
     // view 0 run along the source rows (rectified stereo: a row's 16 pixels share two source rows), else 8x2 (the texels of
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256, MFMA_OCC) void sweep_mfma_kernel(SweepArgs a, 
     // column where the band is a whole number of tile rows, so that overlapping source texels hit that XCD's L2.  A
     // workgroup whose own queue is exhausted takes tiles of the other queues: the bands do not cost the same (on a forward
     // motion those at the top and bottom of the image see the longest epipolar segments).
-    __shared__ int s_item[3];
+    __shared__ int s_item[2];
     const int xcd = blockIdx.x & 7, qq = ntile >> 3, rr8 = ntile & 7;
     auto band_tiles_of = [&](int q) { return qq + (q < rr8 ? 1 : 0); };
     auto band_first_of = [&](int q) { return q < rr8 ? q * (qq + 1) : rr8 * (qq + 1) + (q - rr8) * qq; };
@@ -309,34 +312,24 @@ __global__ __launch_bounds__(256, MFMA_OCC) void sweep_mfma_kernel(SweepArgs a, 
                 rref, 4 * (4 * NCH + tp) + kq_ < C ? (kq_ * HW_ + p_) * 4 : OOB, 4 * (4 * NCH + tp) * HW_ * 4, 0));
     };
 
-    // s_item: a ring of three -- the tile being worked on, the next one (its pixel loads are in flight), and the one
-    // thread 0 is fetching from the queue meanwhile
+    // s_item: this tile and the next.  (One tile of look-ahead and no more: a tile fetched early is a tile no other
+    // workgroup can take -- with two tiles of look-ahead the workgroups ran dry over the last 20 % of a launch, each
+    // finishing the tiles it had put aside while its neighbours idled.)
     // (when the grid covers every tile -- small problems -- workgroup i simply takes tile i of its XCD's band: no atomics on
-    //  the critical path of a launch that is latency bound anyway; else the first two tiles come from ONE atomic)
+    //  the critical path of a launch that is latency bound anyway)
     const bool one_each = (long long)gridDim.x >= 8ll * ((ntile + 7) / 8) * a.B;
     if (threadIdx.x == 0) {
-        if (one_each) {
-            s_item[0] = (int)(blockIdx.x >> 3) < n_own ? (xcd << 28) | (int)(blockIdx.x >> 3) : -1;
-            s_item[1] = -1;
-        } else {
-            const int got = atomicAdd(&queue[xcd], 2);
-            s_item[0] = resolve(got);
-            s_item[1] = s_item[0] < 0 ? -1 : resolve(own_done ? 0 : got + 1);
-        }
+        if (one_each) s_item[0] = (int)(blockIdx.x >> 3) < n_own ? (xcd << 28) | (int)(blockIdx.x >> 3) : -1;
+        else s_item[0] = resolve(atomicAdd(&queue[xcd], 1));
     }
     __syncthreads();
     int slot = 0;
     float Rr[NPL], ray[3];
-    {
-        const int it0 = __builtin_amdgcn_readfirstlane(s_item[0]);
-        if (it0 >= 0) load_pixel(it0, Rr, ray);
-    }
-    for (;;) {
-    const int item = __builtin_amdgcn_readfirstlane(s_item[slot]);
-    if (item < 0) break;
-    const int item_next = __builtin_amdgcn_readfirstlane(s_item[slot == 2 ? 0 : slot + 1]);
+    int item = __builtin_amdgcn_readfirstlane(s_item[0]);
+    if (item >= 0) load_pixel(item, Rr, ray);
+    while (item >= 0) {
     int got_own = 0;
-    if (threadIdx.x == 0 && item_next >= 0 && !own_done) got_own = atomicAdd(&queue[xcd], 1);   // (issued now, looked at when the tile is done)
+    if (threadIdx.x == 0 && !one_each && !own_done) got_own = atomicAdd(&queue[xcd], 1);   // (the next tile: issued now, looked at when this one is done)
     const int sub = wave;
     int b, tx, ty;
     decode(item, b, tx, ty);
@@ -748,21 +741,29 @@ __global__ __launch_bounds__(256, MFMA_OCC) void sweep_mfma_kernel(SweepArgs a, 
         atomicAdd(&queue[GATHER_COUNT_SLOT], 1);
     }
     MSTAMP(5)
-    if (threadIdx.x == 0) s_item[slot == 0 ? 2 : slot - 1] = item_next >= 0 ? resolve(got_own) : -1;   // (the ring slot two ahead = the one behind)
-    // the tile after the next is published, everybody is done with this one's slot.  (A raw barrier: __syncthreads() would
-    // also wait for this tile's output stores to be acknowledged and for the next tile's pixel loads.)
+    if (threadIdx.x == 0) s_item[slot ^ 1] = one_each ? -1 : resolve(got_own);
+    // the next tile is published, everybody is done with this one's slot.  (A raw barrier: __syncthreads() would also wait
+    // for this tile's output stores to be acknowledged.)
 #ifdef MFMA_ABL_NOBAR   // timing experiment (races on s_item): what does the per-tile barrier cost?
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
-    slot = slot == 2 ? 0 : slot + 1;
-    if (item_next >= 0) load_pixel(item_next, Rr, ray);   // (the next tile's pixel loads fly over the barrier and the tile setup)
+    slot ^= 1;
+    item = __builtin_amdgcn_readfirstlane(*(volatile int*)&s_item[slot]);
+    if (item >= 0) load_pixel(item, Rr, ray);   // (the next tile's pixel loads fly over its setup)
     MSTAMP(10)
     }   // tiles
 #ifdef MFMA_STAMPS
     if (lane == 0)
         for (int i = 0; i < 12; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(queue + 16) + i, stamp_acc[i]);
+#endif
+#ifdef MFMA_EXIT_STAMPS   // diagnostic build: when do the persistent workgroups run out of work?  (first / last / sum of exits, count, first start)
+    if (threadIdx.x == 0) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(queue + 16) + 12;
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        atomicMax(st + 0, ~t); atomicMax(st + 1, t); atomicAdd(st + 2, t); atomicAdd(st + 3, 1ull); atomicMax(st - 1, ~exit_t0);   // (slot 11 is otherwise unused)
+    }
 #endif
 }
 
