@@ -22,6 +22,8 @@
 // kernel evaluates it (geometry.hpp has the same un-normalisation for the bilinear sampler).
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 #include "kernels.hpp"
 
 namespace pdepth {
@@ -141,6 +143,72 @@ __global__ __launch_bounds__(512) void ufield_collapse_kernel(const float* __res
     }
 }
 
+// The same collapse for W % 4 == 0 (every row 16-byte aligned): lane = 4 neighbouring columns (16-byte loads: a wave reads
+// 1 KB of a row per instruction instead of 256 B), threadIdx.y = sixteenth of the rows, 2 planes per block.  Same sums in
+// the same order per column (rows ascending inside a segment, segments ascending), so the results match the scalar kernel's
+// whenever H splits into the same segments; in general they differ by the rounding of a different association.
+// grid (ceil(W/256), ceil(D/2), B), block (64, 16).
+template <bool BV_LOG>
+__global__ __launch_bounds__(1024) void ufield_collapse_vec4_kernel(const float* __restrict__ dpv, const float* __restrict__ depth_pred,
+                                                                    const float* __restrict__ zero_mask, const float* __restrict__ ax,
+                                                                    int D, int H, int W, float pshift, float* __restrict__ plane,
+                                                                    float* __restrict__ depth_zero) {
+    __shared__ float4 s_part[16][2][64];
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4, k0 = blockIdx.y * 2, b = blockIdx.z, seg = threadIdx.y;
+    const bool col = x < W;
+    const bool sampled = pshift != 0.0f;
+    int sx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sx[i] = col ? nearest_src(x + i, 0.0f, W, sampled) : -1;
+    const bool straight = sx[0] == x && sx[1] == x + 1 && sx[2] == x + 2 && sx[3] == x + 3;   // (the mask row segment is one 16-byte load)
+    const float* zm = zero_mask + (size_t)b * H * W;
+    const size_t HW = (size_t)H * W;
+    const float* v = dpv + ((size_t)b * D + k0) * HW + x;
+    const int rows = (H + 15) / 16, y_lo = seg * rows, y_hi = min(H, y_lo + rows);
+    float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    const bool two = k0 + 1 < D;
+    if (col) {
+#pragma unroll 4
+        for (int y = y_lo; y < y_hi; ++y) {
+            const int sy = nearest_src(y, -pshift, H, sampled);   // the mask is shifted back (flowfield_inv)
+            float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sy >= 0) {
+                if (straight) m = *reinterpret_cast<const float4*>(zm + (size_t)sy * W + x);
+                else {
+                    m.x = sx[0] >= 0 ? zm[(size_t)sy * W + sx[0]] : 0.0f; m.y = sx[1] >= 0 ? zm[(size_t)sy * W + sx[1]] : 0.0f;
+                    m.z = sx[2] >= 0 ? zm[(size_t)sy * W + sx[2]] : 0.0f; m.w = sx[3] >= 0 ? zm[(size_t)sy * W + sx[3]] : 0.0f;
+                }
+            }
+            const float4 p0 = *reinterpret_cast<const float4*>(v + (size_t)y * W);
+            const float4 p1 = two ? *reinterpret_cast<const float4*>(v + HW + (size_t)y * W) : make_float4(0.f, 0.f, 0.f, 0.f);
+            auto val = [](float p) { return BV_LOG ? expf(p) : p; };
+            acc[0].x = acc[0].x + val(p0.x) * m.x; acc[0].y = acc[0].y + val(p0.y) * m.y;
+            acc[0].z = acc[0].z + val(p0.z) * m.z; acc[0].w = acc[0].w + val(p0.w) * m.w;
+            acc[1].x = acc[1].x + val(p1.x) * m.x; acc[1].y = acc[1].y + val(p1.y) * m.y;
+            acc[1].z = acc[1].z + val(p1.z) * m.z; acc[1].w = acc[1].w + val(p1.w) * m.w;
+            if (k0 == 0) {
+                const float4 dpd = *reinterpret_cast<const float4*>(depth_pred + (size_t)b * HW + (size_t)y * W + x);
+                *reinterpret_cast<float4*>(depth_zero + (size_t)b * HW + (size_t)y * W + x) = make_float4(dpd.x * m.x, dpd.y * m.y, dpd.z * m.z, dpd.w * m.w);
+            }
+        }
+    }
+    s_part[seg][0][threadIdx.x] = acc[0];
+    s_part[seg][1][threadIdx.x] = acc[1];
+    __syncthreads();
+    const int j = threadIdx.y;   // thread (lane, j) finishes plane k0 + j of its 4 columns
+    if (col && j < 2 && k0 + j < D) {
+        float4 sum = s_part[0][j][threadIdx.x];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) {
+            const float4 t = s_part[q][j][threadIdx.x];
+            sum.x = sum.x + t.x; sum.y = sum.y + t.y; sum.z = sum.z + t.z; sum.w = sum.w + t.w;
+        }
+        const float4 a4 = *reinterpret_cast<const float4*>(ax + b * W + x);
+        // 0 / 0 = NaN where no pixel of the column qualifies, as in the reference
+        *reinterpret_cast<float4*>(plane + ((size_t)b * D + k0 + j) * W + x) = make_float4(sum.x / a4.x, sum.y / a4.y, sum.z / a4.z, sum.w / a4.w);
+    }
+}
+
 size_t ufield_workspace_bytes(int B, int H, int W) { return ((size_t)B * (2 * (size_t)H * W + W) * sizeof(float) + 255) & ~(size_t)255; }
 
 hipError_t launch_ufield(const float* dpv, const float* d_candi, const float* intr, const float* mask, int B, int D, int H,
@@ -153,6 +221,16 @@ hipError_t launch_ufield(const float* dpv, const float* d_candi, const float* in
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(ufield_mask_kernel, dim3(W, B), dim3(256), 0, stream, depth_pred, intr, mask, H, W, unc_ang, zstart, zend,
                        mind, quash, oob_depth, zero_mask, ax);
+    const bool aligned = W % 4 == 0 && ((reinterpret_cast<uintptr_t>(dpv) | reinterpret_cast<uintptr_t>(plane) | reinterpret_cast<uintptr_t>(depth_zero) |
+                                         reinterpret_cast<uintptr_t>(workspace)) & 15) == 0;
+    if (aligned) {
+        dim3 grid4((W + 255) / 256, (D + 1) / 2, B), block4(64, 16);
+        if (bv_log)
+            hipLaunchKernelGGL(ufield_collapse_vec4_kernel<true>, grid4, block4, 0, stream, dpv, depth_pred, zero_mask, ax, D, H, W, unc_ang, plane, depth_zero);
+        else
+            hipLaunchKernelGGL(ufield_collapse_vec4_kernel<false>, grid4, block4, 0, stream, dpv, depth_pred, zero_mask, ax, D, H, W, unc_ang, plane, depth_zero);
+        return hipGetLastError();
+    }
     dim3 grid((W + 63) / 64, (D + 3) / 4, B), block(64, 8);
     if (bv_log)
         hipLaunchKernelGGL(ufield_collapse_kernel<true>, grid, block, 0, stream, dpv, depth_pred, zero_mask, ax, D, H, W, unc_ang, plane, depth_zero);
