@@ -216,7 +216,7 @@ def _depth_to_pts(depthf, intr):
     return torch.cat([torch.mul(xf, depth).unsqueeze(0), torch.mul(yf, depth).unsqueeze(0), depth.unsqueeze(0)], 0)
 
 
-def gen_ufield(dpv, d_candi, intr, unc_ang, unc_shift, unc_span, BV_log=True, mask=None, normalize=False):
+def gen_ufield(dpv, d_candi, intr, unc_ang, unc_shift, unc_span, BV_log=True, mask=None, normalize=False, mind=3., quash_limit=True):
     """Uncertainty-field collapse of a [1,D,H,W] (log-)DPV -> (plane [1,D,W], masked depth map [1,H,W]).
 
     utils/img_utils.py:268-358 with the cfgx branch (:269-275: pshift = unc_ang rows, z band [unc_shift, unc_shift +
@@ -226,8 +226,10 @@ def gen_ufield(dpv, d_candi, intr, unc_ang, unc_shift, unc_span, BV_log=True, ma
     height-band + range mask on the shifted points (:311-315), optional validity mask (:316-321), quash to the
     nearest surface per column (:324-331), shift the mask back (:334-338), masked depth (:338), masked column sums of
     the probabilities divided by the column's mask count (:341-349), optional min/max normalisation (:353-355).
+    `mind` / `quash_limit`: the dataset branches (:277-290) -- kitti: 5 rows, band [0.6, 0.9], mind 0, no quash; ilim: no
+    shift, band [1.0, 1.3], mind 3, quash.
     """
-    zstart, zend, maxd, mind = unc_shift, unc_shift + unc_span, 100., 3.
+    zstart, zend, maxd = unc_shift, unc_shift + unc_span, 100.
     H, W = dpv.shape[2], dpv.shape[3]
     if unc_ang != 0:
         flow = torch.zeros((1, H, W, 2)).float()
@@ -249,11 +251,12 @@ def gen_ufield(dpv, d_candi, intr, unc_ang, unc_shift, unc_span, BV_log=True, ma
         else:
             mask_shifted = mask.clone()
         zero_mask = zero_mask * mask_shifted.squeeze(0)
-    cleaned = (depth_shifted * zero_mask).squeeze(0)
-    cleaned[cleaned == 0] = 1000
-    min_col, _ = torch.min(cleaned, axis=0)
-    quash = ((cleaned > min_col - 1.) & (cleaned < min_col + 1.)).float()
-    zero_mask = zero_mask * quash
+    if quash_limit:
+        cleaned = (depth_shifted * zero_mask).squeeze(0)
+        cleaned[cleaned == 0] = 1000
+        min_col, _ = torch.min(cleaned, axis=0)
+        quash = ((cleaned > min_col - 1.) & (cleaned < min_col + 1.)).float()
+        zero_mask = zero_mask * quash
     if unc_ang != 0:
         zm_pred = F.grid_sample(zero_mask.unsqueeze(0).unsqueeze(0), flow_inv, mode='nearest', align_corners=False).squeeze(0).squeeze(0)
     else:
@@ -267,6 +270,33 @@ def gen_ufield(dpv, d_candi, intr, unc_ang, unc_shift, unc_span, BV_log=True, ma
         maxval, _ = plane.max(1)
         plane = (plane - minval) / (maxval - minval)
     return plane, depth_zero
+
+
+UFIELD_DATASETS = {"kitti": dict(unc_ang=5, unc_shift=0.6, unc_span=0.3, mind=0., quash_limit=False),
+                   "ilim": dict(unc_ang=0, unc_shift=1.0, unc_span=0.3, mind=3., quash_limit=True)}
+
+
+def compute_unc_field(dpv_predicted, dpv_truth, d_candi, intr, mask, dataset):
+    """utils/img_utils.py:178-181: the field of the ground-truth DPV (probabilities, validity mask) and of the predicted
+    log-DPV (no mask), both through the dataset branch of gen_ufield; intr [1,3,3]."""
+    kw = UFIELD_DATASETS[dataset]
+    truth, _ = gen_ufield(dpv_truth, d_candi, intr.squeeze(0), BV_log=False, mask=mask, **kw)
+    pred, debugmap = gen_ufield(dpv_predicted, d_candi, intr.squeeze(0), BV_log=True, **kw)
+    return truth, pred, debugmap
+
+
+def compute_unc_rmse(field_truth, field_pred, d_candi):
+    """utils/img_utils.py:183-202: E[d] per column of the two [1,D,W] fields, the predicted one zeroed in the first and
+    last column (:187-188), columns where either is NaN dropped (:189-191).  What the function returns is the MEAN
+    ABSOLUTE difference over the remaining columns: its RMSE of :192 is overwritten by :193."""
+    dt = dpv_to_depthmap(field_truth.unsqueeze(2), d_candi, BV_log=False).squeeze(0).squeeze(0)
+    dp = dpv_to_depthmap(field_pred.unsqueeze(2), d_candi, BV_log=False).squeeze(0).squeeze(0).clone()
+    dp[0] = 0
+    dp[-1] = 0
+    ok = ~torch.isnan(dt) & ~torch.isnan(dp)
+    dt = torch.where(ok, dt, torch.zeros_like(dt))
+    dp = torch.where(ok, dp, torch.zeros_like(dp))
+    return torch.sum(torch.abs(dt * ok - dp * ok)) / torch.sum(ok)
 
 
 def sweep_dpv(feat_ref, feat_src, d_candi, R, t, K, rays, cx, cy, sigma, metric="L2"):

@@ -41,3 +41,29 @@ def gen_ufield(dpv_predicted, d_candi, intr_up, visualizer=None, img=None, BV_lo
         maxval, _ = plane.max(1)
         plane = (plane - minval) / (maxval - minval)
     return plane, depth_zero
+
+
+def compute_unc_field(dpv_refined_predicted, dpv_refined_truth, d_candi, intr_refined, mask_refined, cfg):
+    """(field of the ground-truth DPV, field of the predicted log-DPV, masked depth map of the prediction)
+    (utils/img_utils.py:178-181; called by the evaluation loop, trainer/default_trainer.py:243-244): two gen_ufield
+    collapses through the dataset branch of `cfg` -- the truth as probabilities under its validity mask, the prediction as
+    a log-DPV without one.  intr_refined [1,3,3]."""
+    unc_field_truth, _ = gen_ufield(dpv_refined_truth, d_candi, intr_refined.squeeze(0), BV_log=False, mask=mask_refined, cfg=cfg)
+    unc_field_predicted, debugmap = gen_ufield(dpv_refined_predicted, d_candi, intr_refined.squeeze(0), BV_log=True, cfg=cfg)
+    return unc_field_truth, unc_field_predicted, debugmap
+
+
+def compute_unc_rmse(unc_field_truth, unc_field_predicted, d_candi, plot=False):
+    """Error between two [1,D,W] uncertainty fields (utils/img_utils.py:183-202): E[d] per column of each, the
+    predicted one zeroed in the first and last column, columns where either is NaN (no qualifying pixel) dropped.
+    Despite the name the value returned is the mean absolute difference -- the reference overwrites its RMSE with it
+    (:192-193).  `plot` is accepted and ignored (the reference draws the two curves with matplotlib)."""
+    import torch
+    truth_depth = dpv_to_depthmap(unc_field_truth.unsqueeze(2), d_candi, BV_log=False).squeeze(0).squeeze(0)
+    pred_depth = dpv_to_depthmap(unc_field_predicted.unsqueeze(2), d_candi, BV_log=False).squeeze(0).squeeze(0)
+    pred_depth[0] = 0
+    pred_depth[-1] = 0
+    usable = ~torch.isnan(truth_depth) & ~torch.isnan(pred_depth)
+    truth_depth = torch.where(usable, truth_depth, torch.zeros_like(truth_depth))
+    pred_depth = torch.where(usable, pred_depth, torch.zeros_like(pred_depth))
+    return torch.sum(torch.abs(truth_depth - pred_depth)) / torch.sum(usable)

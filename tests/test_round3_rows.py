@@ -217,3 +217,50 @@ def test_model_on_the_packed_epilogue_equals_the_concatenating_path(nmode):
     da = ops.dpv_expect(a["output_refined"][-1], inp["d_candi"], BV_log=True)
     db = ops.dpv_expect(b["output_refined"][-1], inp["d_candi"], BV_log=True)
     assert (da - db).abs().max().item() < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the uncertainty-field metric glue: compute_unc_field / compute_unc_rmse (utils/img_utils.py:178-202), fixture g19
+# ---------------------------------------------------------------------------------------------------------------
+def test_oracle_unc_field_metric_matches_the_reference():
+    """The restatement against the reference's outputs on both dataset branches (kitti: shifted, no quash; ilim: unshifted,
+    quashed): same ATen ops in the same order on the same host family -> equal fields, NaN columns included."""
+    g = golden("g19_unc_field.npz")
+    intr = torch.from_numpy(g["intr"])
+    for tag in ("kitti", "ilim"):
+        truth, pred, dbg = O.compute_unc_field(torch.from_numpy(g[tag + "_pred_logdpv"]), torch.from_numpy(g[tag + "_truth_dpv"]),
+                                               g["d_candi"], intr, torch.from_numpy(g[tag + "_mask"]), tag)
+        np.testing.assert_allclose(truth.numpy(), g[tag + "_field_truth"], rtol=0, atol=1e-7, equal_nan=True, err_msg=tag)
+        np.testing.assert_allclose(pred.numpy(), g[tag + "_field_pred"], rtol=0, atol=1e-7, equal_nan=True, err_msg=tag)
+        np.testing.assert_allclose(dbg.numpy(), g[tag + "_debugmap"], rtol=0, atol=1e-6, err_msg=tag)
+        err = O.compute_unc_rmse(truth, pred, g["d_candi"])
+        assert abs(float(err) - float(g[tag + "_rmse"])) < 1e-6, tag
+
+
+@pytest.mark.gpu
+def test_hip_unc_field_metric():
+    """compute_unc_field / compute_unc_rmse of the package (two pdepth_ufield_f32 collapses + two pdepth_dpv_expect_f32) on the
+    reference's inputs.  A pixel whose height or depth lies within ~1e-4 of a mask threshold may flip (this path sums E[d]
+    in another order): the fields are compared on the columns the oracle finds stable under such a perturbation, the scalar
+    error with a bound that a handful of flipped pixels cannot exceed."""
+    from pdepth_amd.utils import img_utils
+    g = golden("g19_unc_field.npz")
+    intr = torch.from_numpy(g["intr"])
+    for tag in ("kitti", "ilim"):
+        cfg = synth.Cfg({"data": {"dataset_path": str(g[tag + "_path"])}})
+        pred_v, truth_v, mask = (torch.from_numpy(g[tag + k]) for k in ("_pred_logdpv", "_truth_dpv", "_mask"))
+        truth, pred, dbg = img_utils.compute_unc_field(pred_v.to(DEV), truth_v.to(DEV), g["d_candi"], intr.to(DEV), mask.to(DEV), cfg)
+        for got, vol, want, kw in ((truth, truth_v, g[tag + "_field_truth"], dict(BV_log=False, mask=mask)),
+                                   (pred, pred_v, g[tag + "_field_pred"], dict(BV_log=True))):
+            stable = np.ones(want.shape[2], dtype=bool)
+            okw = dict(O.UFIELD_DATASETS[tag], **kw)
+            base, _ = O.gen_ufield(vol, g["d_candi"], intr[0], **okw)
+            for eps in (-2e-5, 2e-5):
+                p2, _ = O.gen_ufield(vol, g["d_candi"] * (1.0 + eps), intr[0], **okw)
+                stable &= np.isclose(p2.numpy(), base.numpy(), rtol=1e-6, atol=1e-9, equal_nan=True).all(axis=(0, 1))
+            assert stable.mean() > 0.8, tag
+            np.testing.assert_allclose(got.cpu().numpy()[:, :, stable], want[:, :, stable], rtol=2e-5, atol=1e-6, equal_nan=True, err_msg=tag)
+        err = float(img_utils.compute_unc_rmse(truth, pred, g["d_candi"]))
+        assert abs(err - float(g[tag + "_rmse"])) < 5e-3 * max(1.0, float(g[tag + "_rmse"])), (tag, err, float(g[tag + "_rmse"]))
+    with pytest.raises(UnboundLocalError):
+        img_utils.gen_ufield(pred_v.to(DEV), g["d_candi"], intr[0].to(DEV), cfg=synth.Cfg({"data": {"dataset_path": "/data/other"}}))
