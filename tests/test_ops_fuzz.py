@@ -125,3 +125,27 @@ def test_correlation_and_warps_on_random_shapes():
             diff = (go.cpu() - wo).abs()
             assert float((diff > 2e-4).float().mean()) <= near_edge, (mode, B, C, H, W, float(diff.max()))
             assert (gv.cpu() != wv).float().mean().item() < 0.02
+
+
+def test_correlation_forward_matrix_pipe_on_random_shapes():
+    """The matrix-pipe forward of the fast configuration (kernel 1, stride1 1, pad = max_displacement; extras.hip) over channel
+    counts on both sides of its three instantiations (C <= 64 / 128 / 256), image widths around the 16-pixel groups and the
+    64-pixel workgroups, every radius and displacement stride it takes -- against the restatement of the reference's kernel."""
+    rng = np.random.default_rng(77)
+    gen = torch.Generator().manual_seed(77)
+    for i in range(60):
+        C = int(rng.choice([1, 3, 4, 5, 31, 64, 65, 67, 128, 129, 200, 256])) if i % 2 else int(rng.integers(1, 257))
+        H = int(rng.integers(1, 24))
+        W = int(rng.choice([1, 7, 15, 16, 17, 31, 33, 63, 64, 65, 80, 100, 129]))
+        r = int(rng.integers(1, 5))
+        s2 = int(rng.choice([1, 2, 3, 4]))
+        if r * s2 > 16:
+            s2 = 1
+        md = r * s2
+        B = int(rng.integers(1, 3))
+        x1, x2 = torch.randn(B, C, H, W, generator=gen), torch.randn(B, C, H, W, generator=gen)
+        want = O.correlation_general(x1, x2, md, 1, md, 1, s2)
+        got = ops.correlation(x1.to(DEV), x2.to(DEV), pad_size=md, kernel_size=1, max_displacement=md, stride1=1, stride2=s2).cpu()
+        assert got.shape == want.shape, (C, H, W, r, s2)
+        err = float((got - want).abs().max())
+        assert err < 2e-6, (C, H, W, r, s2, err)
