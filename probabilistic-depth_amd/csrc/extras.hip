@@ -12,6 +12,7 @@
 
 #include <cstdlib>
 
+#include "geometry.hpp"
 #include "kernels.hpp"
 
 namespace pdepth {
@@ -20,6 +21,21 @@ namespace pdepth {
 // and its sum; fused product and its sum; normalise + write), so the log-DPV is read once and each output written
 // once: 4*HW*(D*(1+outputs)+2) bytes.  DREG = planes held in registers (64 or 128); deeper volumes take the
 // re-reading kernel below.
+// exp / log / divide of the fusion kernels: hardware exp2 / log2 with an exact-argument reduction (exp_nonpos, geometry.hpp:
+// ~1.5 ulp), log2 x ln 2 (~2 ulp, absolute 1e-7 near 1) and a refined reciprocal -- the libm forms cost ~20 instructions
+// each, five per element, and made the kernel VALU bound (127 us for 402 MB).  -DPDEPTH_LIBM_FUSE restores them.
+#ifdef PDEPTH_LIBM_FUSE
+__device__ __forceinline__ float fuse_exp(float x) { return expf(x); }
+__device__ __forceinline__ float fuse_log(float x) { return logf(x); }
+__device__ __forceinline__ float fuse_div(float a, float b, float) { return a / b; }
+__device__ __forceinline__ float fuse_rcp(float) { return 0.0f; }
+#else
+__device__ __forceinline__ float fuse_exp(float x) { return exp_nonpos(x); }
+__device__ __forceinline__ float fuse_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309417f; }
+__device__ __forceinline__ float fuse_div(float a, float, float rb) { return a * rb; }
+__device__ __forceinline__ float fuse_rcp(float b) { return refined_rcp(b); }
+#endif
+
 template <int DREG>
 __global__ __launch_bounds__(256) void dpv_fuse_reg_kernel(const float* __restrict__ logp,
                                                            const float* __restrict__ dmaps,
@@ -38,6 +54,7 @@ __global__ __launch_bounds__(256) void dpv_fuse_reg_kernel(const float* __restri
     const float inv_mask = 1.0f - mask;
     const float sigma = sqrtf(var);
     const float two_var = 2.0f * (sigma * sigma);  // 2 * torch.pow(sig, 2)
+    const float r_two_var = fuse_rcp(two_var);
     const float uni = 1.0f / (float)D;
     const float* lp = logp + (size_t)b * D * HW + pix;
     float v[DREG], x[DREG];
@@ -47,26 +64,28 @@ __global__ __launch_bounds__(256) void dpv_fuse_reg_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < DREG; ++k) {
         const float a = fabsf(s_dc[k] - dmap);
-        v[k] = expf(-(a * a) / two_var);
+        v[k] = fuse_exp(fuse_div(-(a * a), two_var, r_two_var));
         if (k < D) sumg = sumg + v[k];
     }
     float sumf = 0.0f;
+    const float r_sumg = fuse_rcp(sumg);
 #pragma unroll
     for (int k = 0; k < DREG; ++k) {
-        float t = v[k] / sumg;
+        float t = fuse_div(v[k], sumg, r_sumg);
         if (t != t) t = -1.0f;                       // zero_invalid (img_utils.py:45)
         const float m = t * mask + uni * inv_mask;   // img_utils.py:371
-        v[k] = expf(x[k] + logf(fminf(fmaxf(m, eps), 1.0f)));
+        v[k] = fuse_exp(x[k] + fuse_log(fminf(fmaxf(m, eps), 1.0f)));
         if (k < D) sumf = sumf + v[k];
     }
+    const float r_sumf = fuse_rcp(sumf);
     float* of = fused ? fused + (size_t)b * D * HW + pix : nullptr;
     float* ol = logfused ? logfused + (size_t)b * D * HW + pix : nullptr;
 #pragma unroll
     for (int k = 0; k < DREG; ++k) {
         if (k < D) {
-            const float f = fminf(fmaxf(v[k] / sumf, eps), 1.0f);
+            const float f = fminf(fmaxf(fuse_div(v[k], sumf, r_sumf), eps), 1.0f);
             if (of) __builtin_nontemporal_store(f, of + (size_t)k * HW);
-            if (ol) __builtin_nontemporal_store(logf(f), ol + (size_t)k * HW);
+            if (ol) __builtin_nontemporal_store(fuse_log(f), ol + (size_t)k * HW);
         }
     }
 }
