@@ -145,6 +145,34 @@ def sweep_cost(feat_ref, feat_src, d_candi, R, t, K, rays, cx, cy, sigma, metric
     return cost
 
 
+def sweep_cost_at(feat_ref, feat_src, d_candi, R, t, K, rays, cx, cy, sigma, idx, metric="L2"):
+    """sweep_cost() for the pixels `idx` (flat indices, LongTensor [n]) only -> [1, D, n]: the same ops on the same values
+    -- (K@R)@rays is formed for every pixel and THEN restricted (a matmul over fewer columns may take another BLAS path),
+    everything after it is elementwise per pixel; grid_sample is called plane by plane on the one source view instead of on
+    its D-fold repeat (18 GB per view at BASELINE config 5).  tests/test_oracle_subset.py pins it to sweep_cost()."""
+    h, w = feat_ref.shape[2], feat_ref.shape[3]
+    d32 = torch.from_numpy(np.asarray(d_candi).astype(np.float32))
+    n_d, n = d32.shape[0], idx.shape[0]
+    ref_at = feat_ref.reshape(1, feat_ref.shape[1], h * w)[:, :, idx].reshape(1, -1, 1, n)
+    cost = torch.zeros(1, n_d, n)
+    for v in range(feat_src.shape[1]):
+        term1 = K.matmul(t[v]).reshape(3, 1)
+        term2 = K.matmul(R[v]).matmul(rays)[:, idx]
+        P = term1.unsqueeze(0) + term2.repeat(n_d, 1, 1) * d32.reshape(n_d, 1, 1)
+        P = P / (P[:, 2, :].unsqueeze(1) + 1e-10)
+        grid = torch.stack(((P[:, 0, :] - cx) / cx, (P[:, 1, :] - cy) / cy), dim=-1).reshape(n_d, 1, n, 2)
+        for k in range(n_d):
+            warped = F.grid_sample(feat_src[:, v], grid[k:k + 1], mode="bilinear", padding_mode="zeros", align_corners=False)
+            if metric == "L2":
+                dist = torch.sum((warped - ref_at) ** 2, 1)
+            elif metric == "L1":
+                dist = torch.sum(torch.abs(warped - ref_at), 1)
+            else:
+                raise Exception("undefined metric for feature distance ...")
+            cost[0, k] = cost[0, k] + dist.reshape(n) / sigma
+    return cost
+
+
 def warp_feature(feat_src, d_candi, R, t, K, rays, cx, cy):
     """Channel i of every view warped with depth plane i -> [1, V, D, h, w].
 

@@ -90,6 +90,35 @@ def test_config5_full_size_properties(dev):
     assert ((c2 - ca * s * s).abs() / (1.0 + ca.abs())).max().item() < 1e-5
 
 
+def test_config5_full_size_against_the_oracle_at_sampled_pixels(dev):
+    """Config 5 at its full size against the ORACLE: the whole-image oracle needs 18 GB per view here, its per-pixel form
+    (oracle.sweep_cost_at: the same ops on the same values, pinned to the whole-image form by tests/test_oracle_subset.py)
+    does 6 000 pixels -- random ones plus the image border and the rows / columns either side of the tile seams -- in
+    seconds.  Same bounds as everywhere: cost 2e-4 abs + 2e-5 rel, log-DPV 2e-4, depth 1e-4 m."""
+    from oracle import ref_cpu as O
+    H, W, D = 512, 1024, 128
+    b = synth.make_batch(5, 1, C=67, D=D, H=H, W=W, V=4, pose="mono")
+    rng = np.random.default_rng(55)
+    ys = np.concatenate([rng.integers(0, H, 4000), rng.choice([0, 1, 3, 4, H - 5, H - 4, H - 1], 1000), rng.integers(0, H, 1000)])
+    xs = np.concatenate([rng.integers(0, W, 4000), rng.integers(0, W, 1000), rng.choice([0, 1, 15, 16, 31, 32, W - 17, W - 16, W - 1], 1000)])
+    idx = torch.from_numpy(np.unique(ys * W + xs)).long()
+    K = b["K"][0]
+    ocost = O.sweep_cost_at(b["ref"][0:1], b["src"][0:1], b["d_candi"], b["R"][0], b["t"][0], K, b["rays"][0],
+                            K.numpy()[0, 2], K.numpy()[1, 2], 10.0, idx)                  # [1, D, n]
+    ologp = O.log_dpv(ocost.reshape(1, D, 1, -1))
+    odepth = O.dpv_to_depthmap(ologp, b["d_candi"], BV_log=True).reshape(-1)
+    d = to_dev(b, dev)
+    for algo in ("auto", "mfma", "tiled1", "cells", "direct"):
+        cost, logp, depth = _sweep(d, algo)
+        c_at = cost.reshape(1, D, H * W)[:, :, idx.to(dev)].cpu()
+        l_at = logp.reshape(1, D, H * W)[:, :, idx.to(dev)].cpu()
+        d_at = depth.reshape(H * W)[idx.to(dev)].cpu()
+        np.testing.assert_allclose(c_at.numpy(), ocost.numpy(), rtol=COST_RTOL, atol=COST_ATOL, err_msg=algo)
+        np.testing.assert_allclose(l_at.numpy(), ologp.reshape(1, D, -1).numpy(), rtol=0, atol=2e-4, err_msg=algo)
+        err = (d_at - odepth).abs().max().item()
+        assert err <= DEPTH_ATOL, f"{algo}: depth differs from the oracle by {err:.3e} at the sampled pixels"
+
+
 def test_band_mode_on_encoder_features(dev):
     """The correlation form (Q - 2XW) + |r|^2 cancels when features are large against their differences.  Real encoder
     outputs are not N(0,1): non-zero mean per channel, ref and src strongly correlated.  Take the feature maps of the
