@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--views", type=int, default=1)
     ap.add_argument("--pose", default="mono", choices=["mono", "stereo"])
     ap.add_argument("--algo", default="auto", choices=["auto", "direct", "tiled1", "tiled2", "cells", "mfma"])
+    ap.add_argument("--peaked", action="store_true", help="SURVEY 8(d)'s correlated feature variant (src = 0.7 shift(ref) + 0.3 noise: a peaked DPV)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", default=None, help="an experiment file in the reference's JSON schema (configs/*.json): "
                     "planes, depth range, sigma, channels and the pose family come from it; the sweep resolution stays "
@@ -105,6 +106,8 @@ def main():
     torch.cuda.set_device(dev)
 
     cfg = dict(C=67, D=a.planes, H=a.height, W=a.width, V=a.views, pose=a.pose)
+    if a.peaked:
+        cfg["peaked"] = True
     sigma, d_candi_cfg = 10.0, None
     if a.config:   # the reference's experiment file names the workload (BASELINE configs are named by those files)
         wl = synth.sweep_workload(synth.cfg_from_json(a.config))
@@ -227,7 +230,7 @@ def main():
             allm, wall, steps=a.steps, warmup=a.warmup, batch_per_gpu=a.batch, world=world,
             metric="depth-volumes/sec (D=64, 256x512)", unit="depth-volumes/s",
             workload=f"BASELINE configs[1]: default_mono eval, fused sweep+DPV, B={a.batch}/GPU, V={cfg['V']}, "
-                     f"C={cfg['C']}, D={cfg['D']}, {cfg['H']}x{cfg['W']}, pose={a.pose}, algo={a.algo}",
+                     f"C={cfg['C']}, D={cfg['D']}, {cfg['H']}x{cfg['W']}, pose={a.pose}, algo={a.algo}" + (", peaked features" if a.peaked else ""),
             bytes_per_volume=bpv, hbm_peak_gbs=HBM_PEAK_GBS, extras=extras)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)

@@ -27,8 +27,8 @@ def timeit(fn, steps=20, warmup=5):
     return a.elapsed_time(b) / steps
 
 
-def sweep_case(name, B, C, D, H, W, V, pose, algo="auto", steps=20):
-    b = synth.make_batch(2, B, C=C, D=D, H=H, W=W, V=V, pose=pose)
+def sweep_case(name, B, C, D, H, W, V, pose, algo="auto", steps=20, peaked=False):
+    b = synth.make_batch(2, B, C=C, D=D, H=H, W=W, V=V, pose=pose, peaked=peaked)
     d = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
     dc = ops.d_candi_tensor(d["d_candi"], "cuda")
     ms = timeit(lambda: ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], dc, 10.0,
@@ -50,6 +50,9 @@ def line(case, ms, byt, **kw):
 def main():
     sweep_case("cfg2 mono 256x512 B=4", 4, 67, 64, 256, 512, 1, "mono")
     sweep_case("cfg3 stereo 256x512 B=4 (per-GPU share of B=32)", 4, 67, 64, 256, 512, 1, "stereo")
+    # the correlated variant of the synthetic features (src = 0.7 shift(ref) + 0.3 noise: a peaked DPV) next to N(0,1)
+    sweep_case("cfg2 mono 256x512 B=4, peaked features", 4, 67, 64, 256, 512, 1, "mono", peaked=True)
+    sweep_case("cfg3 stereo 256x512 B=4, peaked features", 4, 67, 64, 256, 512, 1, "stereo", peaked=True)
     sweep_case("cfg1/2 model-real 64x128 B=4", 4, 67, 64, 64, 128, 1, "mono", steps=50)
     sweep_case("cfg5 D=128 512x1024 V=4 B=2 (per-GPU share of B=16)", 2, 67, 128, 512, 1024, 4, "mono", steps=5)
     sweep_case("cfg2 mono 256x512 B=4 gather kernel", 4, 67, 64, 256, 512, 1, "mono", algo="direct", steps=5)
