@@ -156,10 +156,51 @@ __global__ __launch_bounds__(256) void dpv_moments_kernel(const float* __restric
     var[(size_t)b * HW + pix] = s;
 }
 
+// The same two sweeps with the column held in registers (D <= DREG): the volume is read once; same operations in the same
+// order as the kernel above.
+template <int DREG>
+__global__ __launch_bounds__(256) void dpv_moments_reg_kernel(const float* __restrict__ dpv, const float* __restrict__ dc,
+                                                              int D, int HW, int bv_log, float* __restrict__ mean,
+                                                              float* __restrict__ var) {
+    __shared__ float s_dc[DREG];
+    for (int k = threadIdx.x; k < DREG; k += 256) s_dc[k] = k < D ? dc[k] : 0.0f;
+    __syncthreads();
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= HW) return;
+    const int b = blockIdx.y;
+    const float* x = dpv + (size_t)b * D * HW + pix;
+    float z[DREG];
+#pragma unroll
+    for (int k = 0; k < DREG; ++k) z[k] = k < D ? __builtin_nontemporal_load(x + (size_t)k * HW) : 0.0f;
+    float m = 0.0f;
+#pragma unroll
+    for (int k = 0; k < DREG; ++k) {
+        if (k < D) {
+            if (bv_log) z[k] = expf(z[k]);
+            m += s_dc[k] * z[k];
+        }
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < DREG; ++k) {
+        if (k < D) {
+            const float e = s_dc[k] - m;
+            s += (e * e) * z[k];
+        }
+    }
+    if (mean) mean[(size_t)b * HW + pix] = m;
+    var[(size_t)b * HW + pix] = s;
+}
+
 hipError_t launch_dpv_moments(const float* dpv, const float* d_candi, int B, int D, int H, int W, int bv_log,
                               float* mean, float* var, hipStream_t stream) {
     dim3 grid((H * W + 255) / 256, B);
-    hipLaunchKernelGGL(dpv_moments_kernel, grid, dim3(256), 0, stream, dpv, d_candi, D, H * W, bv_log, mean, var);
+    if (D <= 64)
+        hipLaunchKernelGGL(dpv_moments_reg_kernel<64>, grid, dim3(256), 0, stream, dpv, d_candi, D, H * W, bv_log, mean, var);
+    else if (D <= 128)
+        hipLaunchKernelGGL(dpv_moments_reg_kernel<128>, grid, dim3(256), 0, stream, dpv, d_candi, D, H * W, bv_log, mean, var);
+    else
+        hipLaunchKernelGGL(dpv_moments_kernel, grid, dim3(256), 0, stream, dpv, d_candi, D, H * W, bv_log, mean, var);
     return hipGetLastError();
 }
 
