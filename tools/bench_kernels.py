@@ -14,10 +14,18 @@ import pdepth_amd  # noqa: E402,F401
 from pdepth_amd import ops, synth  # noqa: E402
 
 
-def timeit(fn, steps=20, warmup=5):
+def timeit(fn, steps=20, warmup=5, warm_ms=30.0):
+    """Mean GPU time per call (HIP events around `steps` back-to-back calls) after `warmup` calls and at least `warm_ms` of
+    the same work: from idle the GPU's clocks take ~20 ms of work to come up (profiles/r03_bench_clock_ramp.txt), and the
+    early lines of this file used to be 10 % slow against the same case later in the run."""
+    import time
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < warm_ms:
+        fn()
+        torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(steps):
