@@ -12,8 +12,10 @@
 // its own) computes it from two registers per lane and 4 channels, with no LDS traffic per multiply.  About half of the
 // products are for (pixel, texel) pairs no plane samples; they cost matrix-pipe time only, which the kernel has to spare.
 //
-//   work item = one 16x4 tile of reference pixels of one batch item, ONE WAVE per item and per workgroup: no barriers
-//               between waves, nothing shared but the caches.  The wave takes the tile's four pixel rows one after the other;
+//   work item = one 16x4 tile of reference pixels of one batch item; a workgroup = 4 waves = the tile's four sub-blocks of
+//               16 pixels (16x1 or 8x2, one decision per batch item).  The waves share nothing but the caches -- they run
+//               side by side so that they find each other's source lines in L1 -- and meet at one raw barrier per tile;
+//               persistent workgroups pull tiles from per-XCD queues (balanced partition, one tile of look-ahead);
 //   lanes     = in the vector phases lane (px = lane & 15, pg = lane >> 4) owns pixel px and planes k = 4 j + pg
 //               (interleaved, so any range of j keeps all lanes busy); in the matrix phase lane (n, kq) feeds texel /
 //               pixel n and channel slice kq;
@@ -24,8 +26,8 @@
 //               range is halved (near planes, whose segments are long, end up in passes of their own);
 //   X         = per block: texel features by buffer_load_dwordx4 from the packed source (lane (n, kq) loads 4 channels of
 //               texel n: out-of-image texels are fetched out of range and arrive as zeros = padding_mode 'zeros'),
-//               reference features of the 16 pixels held in registers for the whole pixel row, ceil(C/4) MFMAs with two
-//               blocks' accumulators interleaved; result X[texel][pixel] to LDS (16 pixels x 16 MAXB slots), the Gram
+//               reference features of the 16 pixels held in registers for the whole sub-block, ceil(C/4) MFMAs in two
+//               accumulator chains, three blocks' loads in flight; result X[texel][pixel] to LDS (16 pixels x 16 MAXB slots), the Gram
 //               records of the block's texels next to it;
 //   combine   = per (pixel, plane): 4 X values, the Gram terms of the cell and the bilinear weights, cost accumulated
 //               over views in registers;
