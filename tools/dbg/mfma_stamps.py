@@ -6,6 +6,8 @@ import pdepth_amd
 from pdepth_amd import ops, synth, _native
 pose = sys.argv[1] if len(sys.argv) > 1 else "mono"
 B, C, D, H, W, V = 4, 67, 64, 256, 512, 1
+if len(sys.argv) > 2 and sys.argv[2] == "cfg5":   # BASELINE config 5's shape (one volume)
+    B, D, H, W, V = 1, 128, 512, 1024, 4
 b = synth.make_batch(2, B, C=C, D=D, H=H, W=W, V=V, pose=pose)
 d = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
 dc = ops.d_candi_tensor(d["d_candi"], "cuda")
