@@ -297,11 +297,6 @@ __global__ __launch_bounds__(256, MFMA_OCC) void sweep_mfma_kernel(SweepArgs a, 
         for (int i = 0; i < 3; ++i) ray_[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rray, p_ * 4, i * HW_ * 4, 0));
         const __amdgpu_buffer_rsrc_t rref =
             __builtin_amdgcn_make_buffer_rsrc((void*)(a.ref + (size_t)b_ * a.ref_bstride), 0, C * HW_ * 4, 0x00020000);
-#ifdef MFMA_ABL_NOREF   // timing experiment (results wrong): what do the reference-feature loads cost?
-#pragma unroll
-        for (int i = 0; i < NPL; ++i) Rr_[i] = (float)(p_ + i);
-        return;
-#endif
 #pragma unroll
         for (int g = 0; g < NCH; ++g)
 #pragma unroll
@@ -580,20 +575,6 @@ __global__ __launch_bounds__(256, MFMA_OCC) void sweep_mfma_kernel(SweepArgs a, 
 #ifdef MFMA_REP_X
                         for (int rep = 0; rep < 2; ++rep) {
 #endif
-#ifdef MFMA_NSET4   // experiment: three blocks in flight behind the one being multiplied
-                        v4f SD[NCH > 0 ? NCH : 1];
-                        float TD[NTL > 0 ? NTL : 1];
-                        load_block(0, SA, TA);
-                        load_block(1, SB, TB);
-                        load_block(2, SC, TC);
-                        for (int bi = 0; bi < nb; bi += 4) {
-                            load_block(bi + 3, SD, TD);
-                            compute_block(bi, SA, TA, true);
-                            if (bi + 1 < nb) { load_block(bi + 4, SA, TA); compute_block(bi + 1, SB, TB, true); }
-                            if (bi + 2 < nb) { load_block(bi + 5, SB, TB); compute_block(bi + 2, SC, TC, true); }
-                            if (bi + 3 < nb) { load_block(bi + 6, SC, TC); compute_block(bi + 3, SD, TD, true); }
-                        }
-#else
                         load_block(0, SA, TA);
                         load_block(1, SB, TB);
                         // two blocks in flight behind the one being multiplied.  (Unrolled over the at most MAXB blocks, with forward
@@ -612,7 +593,6 @@ __global__ __launch_bounds__(256, MFMA_OCC) void sweep_mfma_kernel(SweepArgs a, 
                             load_block(bi + 4, SB, TB);
                             compute_block(bi + 2, SC, TC, bi + 2 < nb);
                         }
-#endif
 #ifdef MFMA_REP_X
                         }
 #endif
@@ -666,10 +646,7 @@ __global__ __launch_bounds__(256, MFMA_OCC) void sweep_mfma_kernel(SweepArgs a, 
 #endif
                             cost[h * 16 + j] = cost[h * 16 + j] + div_sigma(q);
                         }
-#ifndef MFMA_COMB_GROUP
-#define MFMA_COMB_GROUP 2
-#endif
-                        if ((j & (MFMA_COMB_GROUP - 1)) == MFMA_COMB_GROUP - 1) __builtin_amdgcn_sched_barrier(0);   // so many planes' LDS reads in flight at a time
+                        if (j & 1) __builtin_amdgcn_sched_barrier(0);   // two planes' LDS reads in flight at a time
                     }
 #ifdef MFMA_REP_COMB
                     }
@@ -746,11 +723,7 @@ __global__ __launch_bounds__(256, MFMA_OCC) void sweep_mfma_kernel(SweepArgs a, 
     if (threadIdx.x == 0) s_item[slot ^ 1] = one_each ? -1 : resolve(got_own);
     // the next tile is published, everybody is done with this one's slot.  (A raw barrier: __syncthreads() would also wait
     // for this tile's output stores to be acknowledged.)
-#ifdef MFMA_ABL_NOBAR   // timing experiment (races on s_item): what does the per-tile barrier cost?
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
     slot ^= 1;
     item = __builtin_amdgcn_readfirstlane(*(volatile int*)&s_item[slot]);
     if (item >= 0) load_pixel(item, Rr, ray);   // (the next tile's pixel loads fly over its setup)
