@@ -178,6 +178,37 @@ def test_upsample_mode_fuses_sparse_depth():
 
 
 
+@pytest.mark.gpu
+def test_upsample_mode_matches_reference_capture():
+    """nmode default_upsample end to end against the reference's own run (fixture g20, tests/golden/make_golden_r3c.py):
+    both low-resolution log-DPVs (fused with the sparse depth's soft label / plain), their depth maps and the refined one.
+    Bounds as for the default mode (no 3-D convolutions on this path): 2e-4 on the log-DPVs, 1e-4 m on the depth maps."""
+    g = golden("g20_upsample_model.npz")
+    seed_input, seed_sparse, seed_weights = (int(v) for v in g["seeds"])
+    dev = torch.device("cuda:0")
+    torch.backends.cudnn.benchmark = False
+    model = get_model(synth.default_cfg("default_upsample"), 0)
+    synth.seed_weights(model, seed=seed_weights)
+    model = model.to(dev).eval()
+    model.sweep_blas = golden_blas(g)
+    inp = synth.make_model_input(seed_input, B=1, V=1, H=256, W=256, D=64, pose="mono")
+    gen = torch.Generator().manual_seed(seed_sparse)     # (the generator of make_golden_r3c.sparse_depth, restated: data, not code)
+    masks = (torch.rand(1, 1, 64, 64, generator=gen) > 0.7).float()
+    inp["dmaps"] = (torch.rand(1, 64, 64, generator=gen) * 30 + 6) * masks[:, 0]
+    inp["masks"] = masks
+    with torch.no_grad():
+        out = model([harness.move_input(inp, dev)])[0]
+    fused, plain = out["output"]
+    from pdepth_amd.utils import img_utils
+    e_f = np.abs(fused.cpu().numpy()[:, ::2, ::2, ::2] - g["fused_logdpv_sub"]).max()
+    e_p = np.abs(plain.cpu().numpy()[:, ::4, ::2, ::2] - g["plain_logdpv_sub"]).max()
+    d_f = np.abs(img_utils.dpv_to_depthmap(fused, inp["d_candi"], BV_log=True).cpu().numpy() - g["depth_fused"]).max()
+    d_p = np.abs(img_utils.dpv_to_depthmap(plain, inp["d_candi"], BV_log=True).cpu().numpy() - g["depth_plain"]).max()
+    d_r = np.abs(img_utils.dpv_to_depthmap(out["output_refined"][0], inp["d_candi"], BV_log=True).cpu().numpy() - g["depth_refined"]).max()
+    print(f"[default_upsample] max|dlogDPV| fused {e_f:.3e} plain {e_p:.3e}; max|ddepth| fused {d_f:.3e} plain {d_p:.3e} refined {d_r:.3e}")
+    assert e_f < 2e-4 and e_p < 2e-4 and d_f < 1e-4 and d_p < 1e-4 and d_r < 1e-4
+
+
 def test_config_loader_reads_the_reference_schema(tmp_path):
     """synth.cfg_from_json: the experiment files of the reference (train.py:34-37: json -> EasyDict with sections data / var /
     ...) -- a hand-written file with the hot-path keys, a stereo variant, and the errors for missing keys."""
