@@ -1,11 +1,15 @@
-"""Round-3 golden fixture g20: the reference's BaseModel in nmode=default_upsample (models/models.py:658-678: the DPV of the
+"""Round-3 golden fixtures g20 and g21.  g20: the reference's BaseModel in nmode=default_upsample (models/models.py:658-678: the DPV of the
 sweep fused with the Gaussian soft label of a sparse depth map, img_utils.gen_dpv_withmask) -- the one nmode fixture g8 does
 not hold.  Build container only (imports /root/reference):
 
     python tests/golden/make_golden_r3c.py
 
 Seeded inputs (synth.make_model_input + a seeded sparse depth map and mask) and weights; stored: sub-sampled fused / plain
-low-resolution log-DPVs and the three depth maps.  Data only.
+low-resolution log-DPVs and the three depth maps.
+
+g21: BaseModel nmode=default on a batch of TWO items with TWO source views each (the reference loops over the items and, per
+item, over the views: models/models.py:522-545, warping/homography.py:124-131; this package makes one batched call) -- the
+same captures per item.  Data only.
 """
 import os
 import sys
@@ -60,5 +64,31 @@ def main():
           "fused depth range", float(img_utils.dpv_to_depthmap(fused, d, BV_log=True).min()), float(img_utils.dpv_to_depthmap(fused, d, BV_log=True).max()))
 
 
+def main_b2v2():
+    homo, view, img_utils = _import_reference()
+    import pdepth_amd
+    from pdepth_amd import _native, synth as S
+    from util_host import cpu_vendor
+    import models.get_model as gm
+    meta = dict(meta_torch=torch.__version__, meta_cpu_capability=torch.backends.cpu.get_cpu_capability(),
+                meta_cpu_vendor=cpu_vendor(), meta_blas_mode=np.int32(_native.host_blas_mode()))
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.manual_seed(0)
+    model = gm.get_model(S.default_cfg("default"), 0)
+    S.seed_weights(model, seed=21)
+    model.eval()
+    inp = S.make_model_input(21000, B=2, V=2, H=256, W=256, D=64, pose="mono")
+    with torch.no_grad():
+        out = model([inp])[0]
+    low, refined = out["output"][-1], out["output_refined"][-1]
+    d = inp["d_candi"]
+    depth_low = np.stack([img_utils.dpv_to_depthmap(low[b:b + 1], d, BV_log=True).numpy()[0] for b in range(2)])
+    depth_ref = np.stack([img_utils.dpv_to_depthmap(refined[b:b + 1], d, BV_log=True).numpy()[0] for b in range(2)])
+    np.savez_compressed(os.path.join(HERE, "g21_model_b2v2.npz"), seeds=np.int32([21000, 21]), logdpv_sub=low.numpy()[:, ::4, ::2, ::2],
+                        depth_low=depth_low, depth_refined=depth_ref, **meta)
+    print("g21_model_b2v2.npz", os.path.getsize(os.path.join(HERE, "g21_model_b2v2.npz")), "bytes; depth range", float(depth_low.min()), float(depth_low.max()))
+
+
 if __name__ == "__main__":
     main()
+    main_b2v2()

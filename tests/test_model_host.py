@@ -209,6 +209,30 @@ def test_upsample_mode_matches_reference_capture():
     assert e_f < 2e-4 and e_p < 2e-4 and d_f < 1e-4 and d_p < 1e-4 and d_r < 1e-4
 
 
+@pytest.mark.gpu
+def test_batched_two_view_model_matches_reference_capture():
+    """Two batch items with two source views each (fixture g21): the reference walks the items and, per item, the views
+    (models/models.py:522-545, homography.py:124-131); here ONE batched sweep over [B, V, ...] -- same low-resolution log-DPV
+    (2e-4) and depth maps (1e-4 m) per item."""
+    g = golden("g21_model_b2v2.npz")
+    seed_input, seed_weights = (int(v) for v in g["seeds"])
+    dev = torch.device("cuda:0")
+    torch.backends.cudnn.benchmark = False
+    model = get_model(synth.default_cfg("default"), 0)
+    synth.seed_weights(model, seed=seed_weights)
+    model = model.to(dev).eval()
+    model.sweep_blas = golden_blas(g)
+    inp = harness.move_input(synth.make_model_input(seed_input, B=2, V=2, H=256, W=256, D=64, pose="mono"), dev)
+    r = harness.eval_step(model, inp, None)
+    low = r["output"]["output"][-1]
+    assert low.shape == (2, 64, 64, 64) and r["output"]["output_refined"][-1].shape == (2, 64, 256, 256)
+    e_dpv = np.abs(low.cpu().numpy()[:, ::4, ::2, ::2] - g["logdpv_sub"]).max()
+    e_low = np.abs(r["depth_lowres"].cpu().numpy() - g["depth_low"]).max()
+    e_ref = np.abs(r["depth_refined"].cpu().numpy() - g["depth_refined"]).max()
+    print(f"[B=2 V=2] max|dlogDPV|={e_dpv:.3e} max|ddepth_low|={e_low:.3e} max|ddepth_refined|={e_ref:.3e}")
+    assert e_dpv < 2e-4 and e_low < 1e-4 and e_ref < 1e-4
+
+
 def test_config_loader_reads_the_reference_schema(tmp_path):
     """synth.cfg_from_json: the experiment files of the reference (train.py:34-37: json -> EasyDict with sections data / var /
     ...) -- a hand-written file with the hot-path keys, a stereo variant, and the errors for missing keys."""
