@@ -31,10 +31,11 @@ def algorithmic_bytes_per_volume(C, V, D, H, W):
     return 4 * H * W * (C * (1 + V) + D + 1)
 
 
-def cpu_baseline(cfg, budget_s=45.0):
+def cpu_baseline(cfg, budget_s=45.0, gpu_depth0=None):
     """Oracle (CPU restatement of the reference) timed on the host cores: a bounded sample -- ONE volume of the same
     workload per thread count -- at all, 64, 32, 8 and 1 threads (a leg is skipped once the budget is spent; the
-    1-thread leg alone takes ~20 s).  value = the best of them, value_1t = one thread."""
+    1-thread leg alone takes ~20 s).  value = the best of them, value_1t = one thread.  The volume is the first item of
+    the timed batch: its depth map doubles as a check of what the GPU produced for it (`gpu_depth0`, a CPU tensor)."""
     import torch
     from pdepth_amd import synth
     from oracle import ref_cpu as O
@@ -49,12 +50,15 @@ def cpu_baseline(cfg, budget_s=45.0):
             continue
         torch.set_num_threads(n)
         t0 = time.perf_counter()
-        O.sweep_dpv(*args)
+        odepth = O.sweep_dpv(*args)[2]
         dt = time.perf_counter() - t0
         t_used += dt
         by_threads[str(n)] = 1.0 / dt
     best = max(by_threads, key=by_threads.get)
-    return {"value": by_threads[best], "unit": "depth-volumes/s", "cores": int(best), "threads_best": int(best),
+    check = None
+    if gpu_depth0 is not None and by_threads:
+        check = float((odepth.reshape(gpu_depth0.shape) - gpu_depth0).abs().max())
+    return {"max_abs_depth_diff_gpu_vs_port_item0": check, "value": by_threads[best], "unit": "depth-volumes/s", "cores": int(best), "threads_best": int(best),
             "value_1t": by_threads.get("1"), "by_threads": by_threads, "host_cores": cores, "kind": "port",
             "sample": f"1 volume per thread count of the same workload (1 item, V={cfg['V']}, C={cfg['C']}, "
                       f"D={cfg['D']}, {cfg['H']}x{cfg['W']}) through oracle/ref_cpu.py, torch CPU; "
@@ -233,7 +237,8 @@ def main():
                      f"C={cfg['C']}, D={cfg['D']}, {cfg['H']}x{cfg['W']}, pose={a.pose}, algo={a.algo}" + (", peaked features" if a.peaked else ""),
             bytes_per_volume=bpv, hbm_peak_gbs=HBM_PEAK_GBS, extras=extras)
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg)
+            # (with --config the depth candidates / sigma come from the file, the port's sample keeps the defaults: timing only)
+            line["cpu_baseline"] = cpu_baseline(cfg, gpu_depth0=None if a.config else depth[0].cpu())
         print(json.dumps(line), flush=True)
     pdist.barrier()
     if world > 1:
