@@ -177,7 +177,7 @@ def main():
     fallback = pdepth_amd._native.fallback_tiles(hi - lo, cfg["H"], cfg["W"], gather_flag=2 if a.algo == "cells" else 1)
     # which sweep kernel ran: the selector, or -- ALGO_AUTO on this shape class -- the device-side choice of the pre-pass
     tiled_class = cfg["V"] == 1 and cfg["D"] <= 64 and cfg["H"] * cfg["W"] >= 96 * 1024
-    impl = a.algo if a.algo != "auto" else (pdepth_amd._native.sweep_choice(hi - lo, cfg["H"], cfg["W"]) if tiled_class else "mfma")
+    impl = a.algo if a.algo != "auto" else ("corr" if cfg["C"] <= 72 and cfg["D"] <= 128 else "tiled")
     if os.environ.get("PDEPTH_SWEEP_IMPL") and a.algo == "auto":
         impl = os.environ["PDEPTH_SWEEP_IMPL"]
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PDEPTH_ABI_VERSION 3   /* 3: matrix-pipe sweep selector, general + fp16 correlation, packed encoder epilogue */
+#define PDEPTH_ABI_VERSION 4   /* 4: PDEPTH_ALGO_CORR, pdepth_sweep_centres_source, workspace tail with channel statistics */
 
 enum {
     PDEPTH_OK = 0,
@@ -64,8 +64,10 @@ enum {
     /* implementation selectors (parity tests, A/B timing): what AUTO may pick, forced.  Same workspace as AUTO. */
     PDEPTH_ALGO_TILED_1 = 2, /* LDS-tiled band kernel, one 16x4 tile per block                          */
     PDEPTH_ALGO_TILED_2 = 3, /* LDS-tiled band kernel, two tiles per block (D <= 64)                    */
-    PDEPTH_ALGO_CELLS = 4,   /* cell-list kernels (L2 metric, D <= 128; other inputs: PDEPTH_E_ARG)     */
-    PDEPTH_ALGO_MFMA = 5     /* matrix-pipe kernel (L2 metric, D <= 128, C <= 72; other inputs: PDEPTH_E_ARG)   */
+    PDEPTH_ALGO_CELLS = 4,   /* lab builds only (make LAB=1): cell-list kernels of round 2 (L2, D <= 128)           */
+    PDEPTH_ALGO_MFMA = 5,    /* lab builds only: matrix-pipe kernel of round 3 (L2, D <= 128, C <= 72)              */
+    PDEPTH_ALGO_CORR = 6     /* correlation form on mean-centred features, matrix pipe (L2 metric, D <= 128, C <= 72;
+                                other inputs: PDEPTH_E_ARG): what AUTO runs on those shapes                      */
 };
 
 /* Geometry + layout of one batched sweep call. */
@@ -160,6 +162,13 @@ int pdepth_sweep_dpv_packed_f32(const pdepth_sweep_desc *desc, const pdepth_came
  * plus their Gram planes (B*V*(ceil(C/4)+2)*H*W*16 bytes, written by a pre-pass of every call) -- size it once per shape and reuse it.  A call
  * rewrites all of it: do not share one workspace between calls that may run concurrently (different streams). */
 size_t pdepth_sweep_workspace_bytes(const pdepth_sweep_desc *desc);
+
+/* 1 if the packing entry points (pdepth_pack_source_f32, pdepth_pack_views_f32) subtract the channel means from the
+ * packed source for `desc` -- i.e. the sweep it selects is PDEPTH_ALGO_CORR, directly or through PDEPTH_ALGO_AUTO --,
+ * else 0.  A packed workspace must be swept with a descriptor for which this answer is the same (the centred and the
+ * plain layout differ; the library cannot tell them apart from the host).  No reference counterpart: the reference
+ * never re-lays its features (warping/homography.py:123-129 works on the NCHW tensors). */
+int pdepth_sweep_centres_source(const pdepth_sweep_desc *desc);
 
 /*
  * DPV reduction: logits [B,D,H,W] -> logp [B,D,H,W] (may alias logits, may be NULL) and

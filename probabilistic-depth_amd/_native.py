@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpdepth_hip.so")
 
 METRIC_L2, METRIC_L1 = 0, 1
-ALGO_AUTO, ALGO_DIRECT, ALGO_TILED_1, ALGO_TILED_2, ALGO_CELLS, ALGO_MFMA = 0, 1, 2, 3, 4, 5
+ALGO_AUTO, ALGO_DIRECT, ALGO_TILED_1, ALGO_TILED_2, ALGO_CELLS, ALGO_MFMA, ALGO_CORR = 0, 1, 2, 3, 4, 5, 6
 BLAS_FMA, BLAS_SEPARATE = 0, 1
 
 # every symbol include/pdepth.h declares (tests check the library exports all of them)
@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "pdepth_pack_source_f32", "pdepth_sweep_dpv_packed_f32", "pdepth_dpv_reduce_ex_f32",
     "pdepth_ufield_workspace_bytes", "pdepth_ufield_f32",
     "pdepth_correlation_output_size", "pdepth_correlation_forward_f16", "pdepth_correlation_backward_f16",
-    "pdepth_pack_views_f32",
+    "pdepth_pack_views_f32", "pdepth_sweep_centres_source",
 )
 
 
@@ -146,15 +146,25 @@ def load():
                "pdepth_dpv_moments_f32", "pdepth_correlation_backward_f32", "pdepth_correlation_output_size",
                "pdepth_correlation_forward_f16", "pdepth_correlation_backward_f16"):
         getattr(lib, fn).restype = c_int
-    if lib.pdepth_abi_version() != 3:
+    lib.pdepth_sweep_centres_source.restype = c_int
+    lib.pdepth_sweep_centres_source.argtypes = [POINTER(SweepDesc)]
+    if lib.pdepth_abi_version() != 4:
         raise RuntimeError("libpdepth_hip.so ABI version mismatch")
     _lib = lib
     return lib
 
 
+class UnsupportedShape(RuntimeError):
+    """The packed entry points do not take this shape: callers use the plain NCHW path instead (every other failure of a
+    native call -- launch errors, out of memory -- is a plain RuntimeError and must propagate)."""
+
+
 def _check(rc, lib):
     if rc != 0:
-        raise RuntimeError(lib.pdepth_last_error().decode())
+        msg = lib.pdepth_last_error().decode()
+        if rc == 1 and "does not run on a packed source" in msg:   # PDEPTH_E_ARG of the packing entry points for such a shape
+            raise UnsupportedShape(msg)
+        raise RuntimeError(msg)
 
 
 def _dev(t: torch.Tensor, name: str) -> int:
@@ -200,12 +210,14 @@ class PackedSource:
     sweep() in place of src, for callers that sweep the same source features more than once or write them once per
     frame.  Owns its device memory; do not use it from two streams at once."""
 
-    def __init__(self, ws, shape):
+    def __init__(self, ws, shape, centred=False):
         self.ws, self.shape = ws, tuple(shape)   # shape = (B, V, C, H, W)
+        self.centred = bool(centred)             # the channel means were subtracted (pdepth_sweep_centres_source)
 
 
-def pack_source(src, n_planes=64):
-    """src [B,V,C,H,W] fp32 device tensor -> PackedSource (n_planes only selects the algorithm, like desc.D)."""
+def pack_source(src, n_planes=64, algo=ALGO_AUTO):
+    """src [B,V,C,H,W] fp32 device tensor -> PackedSource (n_planes and algo only select the kernel that will sweep it, like
+    desc.D and desc.algo: the layout the correlation-form kernel takes is mean-centred, the LDS-tiled kernel's is not)."""
     lib = load()
     _no_autograd("pack_source", src)
     _dev(src, "src")
@@ -214,14 +226,14 @@ def pack_source(src, n_planes=64):
     B, V, C, H, W = src.shape
     if not _inner_contiguous(src, 3) or (V > 1 and src.stride(1) < C * H * W):
         src = src.contiguous()
-    desc = SweepDesc(B, V, C, int(n_planes), H, W, METRIC_L2, ALGO_AUTO, BLAS_FMA, 1.0, C * H * W,
+    desc = SweepDesc(B, V, C, int(n_planes), H, W, METRIC_L2, int(algo), BLAS_FMA, 1.0, C * H * W,
                      src.stride(0) if B > 1 else V * C * H * W, src.stride(1) if V > 1 else C * H * W)
     ws_bytes = lib.pdepth_sweep_workspace_bytes(ctypes.byref(desc))
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=src.device)
     with torch.cuda.device(src.device):
         rc = lib.pdepth_pack_source_f32(ctypes.byref(desc), _dev(src, "src"), ws.data_ptr(), ws_bytes, _stream(src.device))
     _check(rc, lib)
-    return PackedSource(ws, (B, V, C, H, W))
+    return PackedSource(ws, (B, V, C, H, W), lib.pdepth_sweep_centres_source(ctypes.byref(desc)))
 
 
 def pack_views(feat, rgb, n_views, n_planes=64):
@@ -236,9 +248,11 @@ def pack_views(feat, rgb, n_views, n_planes=64):
         raise RuntimeError("pack_views: feat [B*V1,Cf,h,w] and rgb [B*V1,3,H,W] expected")
     feat, rgb = feat.contiguous(), rgb.contiguous()
     N, Cf, h, w = feat.shape
-    rate = int(rgb.shape[3] / w)
-    if rate < 1 or rgb.shape[2] // rate != h or rgb.shape[3] // rate != w or n_views < 2:
-        raise RuntimeError("pack_views: the image must be an integral multiple of the feature map, with at least one source view")
+    rate = rgb.shape[3] // w if w else 0
+    if rate < 1 or rgb.shape[2] != h * rate or rgb.shape[3] != w * rate or n_views < 2:
+        raise UnsupportedShape("pack_views: the image must be an exact integral multiple of the feature map "
+                               "(got image %dx%d for a %dx%d map), with at least one source view"
+                               % (rgb.shape[2], rgb.shape[3], h, w))
     B, V, C = N // n_views, n_views - 1, Cf + 3
     desc = SweepDesc(B, V, C, int(n_planes), h, w, METRIC_L2, ALGO_AUTO, BLAS_FMA, 1.0, C * h * w, V * C * h * w, C * h * w)
     ws_bytes = lib.pdepth_sweep_workspace_bytes(ctypes.byref(desc))
@@ -250,7 +264,7 @@ def pack_views(feat, rgb, n_views, n_planes=64):
         rc = lib.pdepth_pack_views_f32(ctypes.byref(desc), feat.data_ptr(), rgb.data_ptr(), rate, ref.data_ptr(), ws.data_ptr(),
                                        ws_bytes, _stream(feat.device))
     _check(rc, lib)
-    return PackedSource(ws, (B, V, C, h, w)), ref
+    return PackedSource(ws, (B, V, C, h, w), lib.pdepth_sweep_centres_source(ctypes.byref(desc))), ref
 
 
 def sweep(ref, src, K, R, t, rays, cxcy, d_candi, sigma, metric=METRIC_L2, algo=ALGO_AUTO,
@@ -297,6 +311,9 @@ def sweep(ref, src, K, R, t, rays, cxcy, d_candi, sigma, metric=METRIC_L2, algo=
     if packed:
         if ws_bytes == 0 or packed.ws.numel() < ws_bytes:
             raise RuntimeError("sweep: this shape / algorithm does not run on a packed source")
+        if bool(lib.pdepth_sweep_centres_source(ctypes.byref(desc))) != packed.centred:
+            raise RuntimeError("sweep: the source was packed for another kernel family (centred: %s); pack it with the "
+                               "algo / n_planes / metric it will be swept with" % packed.centred)
         ws = packed.ws
     else:
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev) if ws_bytes else None
@@ -325,25 +342,26 @@ def sweep(ref, src, K, R, t, rays, cxcy, d_candi, sigma, metric=METRIC_L2, algo=
 _last_workspace = None
 
 
-def sweep_choice(B, H, W):
-    """Diagnostics: which kernel the device-side choice of the last ALGO_AUTO sweep picked -- 'mfma' / 'tiled' -- for the
-    shape class where both are launched (single view, <= 64 planes, large image: csrc/pick.hpp); the slot is 0 ('tiled')
-    after every other call."""
-    if _last_workspace is None:
-        return None
+def _queue_slot(B, H, W, slot):
     n = B * ((W + 15) // 16) * ((H + 3) // 4)
     flag_only = (4 * n + 255) & ~255
-    return "mfma" if int(_last_workspace[flag_only + 200: flag_only + 204].view(torch.int32).item()) == 1 else "tiled"
+    return int(_last_workspace[flag_only + 4 * slot: flag_only + 4 * slot + 4].view(torch.int32).item())
+
+
+def noncentred_guard(B, H, W):
+    """Diagnostics: did the pre-pass of the last sweep on a NOT centred source (LDS-tiled kernel) find channel offsets larger
+    than the spread of the features -- the tiled kernel then evaluated every plane directly (csrc/sweep_pack.hip)."""
+    return None if _last_workspace is None else _queue_slot(B, H, W, 51) != 0
 
 
 def fallback_tiles(B, H, W, gather_flag=1):
-    """Diagnostics: how many 16x4 tiles of the last sweep were left to the gather kernel.  A tile's flag is the value the
-    gather kernel is launched for: 1 after the tiled and the matrix-pipe kernels; the cell-list path flags 1 = redone by
-    its generic kernel and 2 = gather kernel (pass gather_flag=2 after algo='cells')."""
+    """Diagnostics: how much of the last sweep left the fast path.  After the correlation-form kernel (ALGO_AUTO / 'corr' on
+    its shapes): pixel blocks of 16 pixels it evaluated directly; after the LDS-tiled kernel: 16x4 tiles left to the gather
+    kernel (flag 1; lab builds: the cell-list path flags 1 = redone by its generic kernel, 2 = gather kernel)."""
     if _last_workspace is None:
         return 0
     n = B * ((W + 15) // 16) * ((H + 3) // 4)
-    return int((_last_workspace[: 4 * n].view(torch.int32) == gather_flag).sum().item())
+    return int((_last_workspace[: 4 * n].view(torch.int32) == gather_flag).sum().item()) + _queue_slot(B, H, W, 54)
 
 
 def dpv_reduce(logits, d_candi, want_logp=True, want_depth=True, inplace=False):

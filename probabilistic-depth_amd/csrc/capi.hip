@@ -51,18 +51,20 @@ pdepth::SweepArgs make_args(const pdepth_sweep_desc* d, const pdepth_camera* cam
     return a;
 }
 
-// Implementation behind ALGO_AUTO for the L2 metric.  Default: the matrix-pipe kernel (sweep_mfma.hip) wherever it is built
-// for the shape, except single-view sweeps of at most 64 planes over large images, where the LDS-tiled band kernel
-// (sweep_tiled.hip) is the faster one on a forward-motion pose (measured, tools/dbg/mfma_matrix.py: the matrix-pipe kernel
-// is 8-30 % faster on 20 of 24 shape x pose combinations, 6-15 % slower on that class with a forward motion).
-// PDEPTH_SWEEP_IMPL=tiled | mfma | cells (read once per process) forces one for AUTO: A/B timing, and the parity suite
-// runs the cell-list kernels as an independent implementation that way.
+// Implementation behind ALGO_AUTO.  L2 metric, C <= 72, D <= 128: the correlation-form kernel on mean-centred features
+// (sweep_corr.hip).  Everything else that fits the packed layout (L1 has no correlation form; wider features; more planes):
+// the LDS-tiled kernel (sweep_tiled.hip).  PDEPTH_SWEEP_IMPL=tiled (read once per process) forces the tiled kernel for AUTO
+// (A/B timing); lab builds (-DPDEPTH_LAB) also know mfma | cells, the kernels of earlier rounds kept as independent checks.
 enum { IMPL_DEFAULT = 0, IMPL_CELLS = 1, IMPL_TILED = 2, IMPL_MFMA = 3 };
 int sweep_impl() {
     static const int impl = [] {
         const char* f = getenv("PDEPTH_SWEEP_IMPL");
         if (!f) return (int)IMPL_DEFAULT;
-        return f[0] == 'c' ? (int)IMPL_CELLS : f[0] == 't' ? (int)IMPL_TILED : f[0] == 'm' ? (int)IMPL_MFMA : (int)IMPL_DEFAULT;
+#ifdef PDEPTH_LAB
+        if (f[0] == 'c' && f[1] == 'e') return (int)IMPL_CELLS;
+        if (f[0] == 'm') return (int)IMPL_MFMA;
+#endif
+        return f[0] == 't' ? (int)IMPL_TILED : (int)IMPL_DEFAULT;
     }();
     return impl;
 }
@@ -84,6 +86,16 @@ bool uses_packed_source(const pdepth_sweep_desc* d) {
            (long long)((d->C + 3) / 4 + 2) * d->H * d->W * 16 < (1ll << 31);
 }
 
+// does this call run the correlation-form kernel (and its pre-pass centre the packed source)?  A pure function of the
+// descriptor: the packing entry points and the sweep that follows decide alike.
+bool uses_corr(const pdepth_sweep_desc* d) {
+    if (!uses_packed_source(d) || d->metric != PDEPTH_METRIC_L2) return false;
+    if (d->algo != PDEPTH_ALGO_CORR && !(d->algo == PDEPTH_ALGO_AUTO && sweep_impl() == IMPL_DEFAULT)) return false;
+    pdepth::SweepArgs a{};
+    a.B = d->B; a.V = d->V; a.C = d->C; a.D = d->D; a.H = d->H; a.W = d->W; a.metric = d->metric;
+    return pdepth::sweep_corr_supports(a);
+}
+
 // packed_ready: src is NULL and the workspace already holds the packed source (pdepth_pack_source_f32)
 int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const float* ref,
                  const float* src, const float* d_candi, float* cost, float* logp, float* depth,
@@ -95,8 +107,9 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
     if (!cost && !logp && !depth) return fail(PDEPTH_E_ARG, "%s: no output requested", who);
     if (d->metric != PDEPTH_METRIC_L2 && d->metric != PDEPTH_METRIC_L1)
         return fail(PDEPTH_E_ARG, "%s: undefined metric for feature distance (%d)", who, d->metric);
-    if (d->algo < PDEPTH_ALGO_AUTO || d->algo > PDEPTH_ALGO_MFMA)
+    if (d->algo < PDEPTH_ALGO_AUTO || d->algo > PDEPTH_ALGO_CORR)
         return fail(PDEPTH_E_ARG, "%s: unknown algo %d", who, d->algo);
+#ifdef PDEPTH_LAB
     if (d->algo == PDEPTH_ALGO_CELLS && (d->metric != PDEPTH_METRIC_L2 || d->D > pdepth::sweep_cells_max_planes()))
         return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_CELLS needs the L2 metric and D <= %d", who, pdepth::sweep_cells_max_planes());
     if (d->algo == PDEPTH_ALGO_MFMA) {
@@ -104,6 +117,12 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
         if (!pdepth::sweep_mfma_supports(probe))
             return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_MFMA needs the L2 metric, D <= 128 and C <= 72", who);
     }
+#else
+    if (d->algo == PDEPTH_ALGO_CELLS || d->algo == PDEPTH_ALGO_MFMA)
+        return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_CELLS / PDEPTH_ALGO_MFMA exist in lab builds only (make LAB=1)", who);
+#endif
+    if (d->algo == PDEPTH_ALGO_CORR && !uses_corr(d))
+        return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_CORR needs the L2 metric, D <= 128 and C <= 72", who);
     if (d->algo == PDEPTH_ALGO_TILED_2 && d->D > 64)
         return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_TILED_2 needs D <= 64", who);
     if (d->algo >= PDEPTH_ALGO_TILED_1 && !uses_packed_source(d))
@@ -128,25 +147,14 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
             return launched(pdepth::launch_sweep_tiled_n1(a, workspace, (hipStream_t)stream, packed_ready), who);
         if (d->algo == PDEPTH_ALGO_TILED_2)
             return launched(pdepth::launch_sweep_tiled_n2(a, workspace, (hipStream_t)stream, packed_ready), who);
-        const bool tiled_class = d->V == 1 && d->D <= 64 && (long long)d->H * d->W >= 96 * 1024;
-        if (d->algo == PDEPTH_ALGO_AUTO && sweep_impl() == IMPL_DEFAULT && tiled_class && pdepth::sweep_mfma_supports(a)) {
-            // The one shape class where the faster kernel depends on the pose (forward motion: the tiled band kernel; lines
-            // along the source rows, e.g. a rectified pair: the matrix-pipe kernel, 13 % faster).  The poses live on the
-            // device: the pre-pass decides (pick.hpp), both kernels are launched, the one not chosen leaves at once.
-            pdepth::SweepArgs ap = a;
-            ap.pick = pdepth::PICK_SKIP_IF_SET;
-            if (int rc = launched(pdepth::launch_sweep_tiled(ap, workspace, (hipStream_t)stream, packed_ready, pdepth::PH_PRE | pdepth::PH_KERNEL), who)) return rc;
-            ap.pick = pdepth::PICK_RUN_IF_SET;
-            return launched(pdepth::launch_sweep_mfma(ap, workspace, (hipStream_t)stream, packed_ready, pdepth::PH_KERNEL | pdepth::PH_GATHER), who);
-        }
-        if (d->algo == PDEPTH_ALGO_MFMA ||
-            (d->algo == PDEPTH_ALGO_AUTO && pdepth::sweep_mfma_supports(a) &&
-             (sweep_impl() == IMPL_MFMA || (sweep_impl() == IMPL_DEFAULT && !tiled_class))))
+        if (uses_corr(d)) return launched(pdepth::launch_sweep_corr(a, workspace, (hipStream_t)stream, packed_ready), who);
+#ifdef PDEPTH_LAB
+        if (d->algo == PDEPTH_ALGO_MFMA || (d->algo == PDEPTH_ALGO_AUTO && sweep_impl() == IMPL_MFMA && pdepth::sweep_mfma_supports(a)))
             return launched(pdepth::launch_sweep_mfma(a, workspace, (hipStream_t)stream, packed_ready), who);
-        // (L1 has no correlation form: always the tiled kernel)
-        if (d->algo == PDEPTH_ALGO_CELLS || (d->metric == PDEPTH_METRIC_L2 && d->D <= pdepth::sweep_cells_max_planes() &&
-                                             sweep_impl() == IMPL_CELLS))
+        if (d->algo == PDEPTH_ALGO_CELLS || (d->algo == PDEPTH_ALGO_AUTO && d->metric == PDEPTH_METRIC_L2 &&
+                                             d->D <= pdepth::sweep_cells_max_planes() && sweep_impl() == IMPL_CELLS))
             return launched(pdepth::launch_sweep_cells(a, workspace, (hipStream_t)stream, packed_ready), who);
+#endif
         return launched(pdepth::launch_sweep_tiled(a, workspace, (hipStream_t)stream, packed_ready), who);
     }
     return launched(pdepth::launch_sweep_direct(a, (hipStream_t)stream), who);
@@ -163,6 +171,11 @@ size_t pdepth_sweep_workspace_bytes(const pdepth_sweep_desc* desc) {
     if (!desc || desc->algo == PDEPTH_ALGO_DIRECT) return 0;
     if (desc->B <= 0 || desc->D <= 0 || desc->H <= 0 || desc->W <= 0) return 0;
     return tiled_ws_bytes(desc);
+}
+
+int pdepth_sweep_centres_source(const pdepth_sweep_desc* desc) {
+    if (!desc || desc->B <= 0 || desc->V <= 0 || desc->C <= 0 || desc->D <= 0 || desc->H <= 0 || desc->W <= 0) return 0;
+    return uses_corr(desc) ? 1 : 0;
 }
 
 int pdepth_sweep_cost_f32(const pdepth_sweep_desc* desc, const pdepth_camera* cam, const float* ref,
@@ -199,7 +212,7 @@ int pdepth_pack_source_f32(const pdepth_sweep_desc* desc, const float* src, void
     a.src = src;
     a.B = desc->B; a.V = desc->V; a.C = desc->C; a.D = desc->D; a.H = desc->H; a.W = desc->W;
     a.src_bstride = desc->src_bstride; a.src_vstride = desc->src_vstride;
-    return launched(pdepth::launch_pack_c4(a, workspace, (hipStream_t)stream), who);
+    return launched(pdepth::launch_pack_c4(a, workspace, (hipStream_t)stream, uses_corr(desc)), who);
 }
 
 int pdepth_pack_views_f32(const pdepth_sweep_desc* desc, const float* feat, const float* rgb, int32_t pool_rate, float* ref_out,
@@ -219,7 +232,8 @@ int pdepth_pack_views_f32(const pdepth_sweep_desc* desc, const float* feat, cons
         return fail(PDEPTH_E_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
     pdepth::SweepArgs a{};
     a.B = desc->B; a.V = desc->V; a.C = desc->C; a.D = desc->D; a.H = desc->H; a.W = desc->W;
-    return launched(pdepth::launch_pack_views(a, feat, rgb, pool_rate, ref_out, workspace, (hipStream_t)stream), who);
+    return launched(pdepth::launch_pack_views(a, feat, rgb, pool_rate, desc->H * pool_rate, desc->W * pool_rate, ref_out, workspace,
+                                              (hipStream_t)stream, uses_corr(desc)), who);
 }
 
 int pdepth_sweep_dpv_packed_f32(const pdepth_sweep_desc* desc, const pdepth_camera* cam, const float* ref,

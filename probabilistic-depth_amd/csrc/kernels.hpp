@@ -35,6 +35,14 @@ struct SweepArgs {
     int pick;
 };
 constexpr int PICK_SLOT = 50, PICK_MFMA = 1;          // workspace int behind the tile flags (cleared with them)
+// more of the 64 workspace ints behind the tile flags:
+constexpr int NONCENTRED_SLOT = 51;        // set by the pre-pass of a NOT centred source whose channel offsets exceed the spread (sweep_pack.hip)
+constexpr int CORR_DONE_SLOT = 52;         // sweep_corr.hip: workgroups that have left (the last one zeroes the queue counters)
+constexpr int CORR_DIRECT_SLOT = 53;       // ... pixel blocks evaluated directly, this call so far / of the last finished call
+constexpr int CORR_DIRECT_LAST_SLOT = 54;
+// channel statistics of the source (workspace tail, sweep_pack.hip): per batch item mu[c] at +0, var[c] at +STATS_VAR, the
+// squared offset that was NOT subtracted at +STATS_OFF
+constexpr int STATS_VAR = 80, STATS_OFF = 160, STATS_STRIDE = 240;
 constexpr int PICK_SKIP_IF_SET = 1, PICK_RUN_IF_SET = 2;
 constexpr int PH_PRE = 1, PH_KERNEL = 2, PH_GATHER = 4, PH_ALL = 7;   // phases of a sweep launcher: pre-pass / flag clear, kernel, gather
 
@@ -54,15 +62,23 @@ int sweep_tiled_max_planes();
 hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false, int phases = PH_ALL);     // picks a variant
 hipError_t launch_sweep_tiled_n1(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false, int phases = PH_ALL);  // one 16x4 tile per block
 hipError_t launch_sweep_tiled_n2(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false, int phases = PH_ALL);  // two tiles per block
-hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t stream);          // pre-pass of both (also clears flags + queues)
+
+// sweep_pack.hip: pre-pass of the packed-source kernels (channel statistics + packed source + Gram planes; clears flags and
+// queue counters).  centre: subtract the channel means (sweep_corr.hip); else the plain layout (mu = 0)
+hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t stream, bool centre);
 hipError_t clear_sweep_flags(const SweepArgs& a, void* workspace, hipStream_t stream);
 // encoder epilogue: cat(feat, avg_pool2d(rgb)) -> packed source views + NCHW reference view, in one pass (a.C = Cf + 3)
-hipError_t launch_pack_views(const SweepArgs& a, const float* feat, const float* rgb, int rate, float* ref_out, void* workspace,
-                             hipStream_t stream);
+hipError_t launch_pack_views(const SweepArgs& a, const float* feat, const float* rgb, int rate, int img_h, int img_w, float* ref_out,
+                             void* workspace, hipStream_t stream, bool centre);
 int sweep_device_cus();
-// workspace head shared by the packed-source kernels: tile flags (+ the 64 queue / counter ints behind them)
+// workspace head shared by the packed-source kernels: tile flags (+ the 64 queue / counter ints behind them); its tail
 size_t sweep_ws_flag_only_bytes(int B, int H, int W);
 size_t sweep_ws_flag_bytes(int B, int H, int W);
+size_t sweep_ws_stats_offset(int B, int V, int C, int H, int W);
+
+// sweep_corr.hip (L2 only): correlation form on mean-centred features, one workgroup per block of 16 pixels
+bool sweep_corr_supports(const SweepArgs& a);
+hipError_t launch_sweep_corr(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false);
 
 // sweep_mfma.hip (L2 only; same workspace as the tiled kernel): the channel contraction on the matrix pipe
 bool sweep_mfma_supports(const SweepArgs& a);

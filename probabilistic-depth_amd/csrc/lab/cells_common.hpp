@@ -3,7 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "kernels.hpp"
+#include "../kernels.hpp"
 
 namespace pdepth {
 namespace {

@@ -27,8 +27,8 @@
 #include <hip/hip_runtime.h>
 
 #include "cells_common.hpp"
-#include "geometry.hpp"
-#include "kernels.hpp"
+#include "../geometry.hpp"
+#include "../kernels.hpp"
 
 namespace pdepth {
 

@@ -40,9 +40,9 @@
 
 #include <climits>
 
-#include "geometry.hpp"
-#include "kernels.hpp"
-#include "pick.hpp"
+#include "../geometry.hpp"
+#include "../kernels.hpp"
+#include "../pick.hpp"
 
 namespace pdepth {
 

@@ -1,0 +1,851 @@
+// Plane sweep in the correlation form of the L2 distance, on mean-centred features, one workgroup per block of 16 pixels:
+// the default path of pdepth_sweep_{cost,dpv}_f32 for the L2 metric (C <= 72, D <= 128).
+//
+//   what is computed.  est_swp_volume_v4 (warping/homography.py:98-135) evaluates, per pixel p and plane k,
+//           cost = sum_c ( sum_t w_t s_t[c] - r[c] )^2          (img_dis_L2_pard, :80-82; t = the four bilinear taps, :197)
+//       with taps outside the image reading zero.  With mu[c] a per-channel constant, s' = s - mu, r' = r - mu and
+//       Win = the weight of the taps inside the image,
+//           sum_t w_t s_t - r = a - (1 - Win) mu,     a = sum_{t inside} w_t s'_t - r',
+//           cost = |a|^2 - 2 (1 - Win) <a, mu> + (1 - Win)^2 |mu|^2,
+//           |a|^2 = w^T G' w - 2 sum_t w_t X'_t + |r'|^2,     X'_t = <r', s'_t>,  G' = Gram terms of neighbouring s'.
+//       mu = an estimate of the channel means of the source view (feature_stats_kernel, sweep_pack.hip): the terms of the
+//       correlation form are then of the size of the cost itself, whatever offset the encoder's features carry (with mu = 0
+//       the three terms are (mean/std)^2 times larger than their sum and cancel: tests/test_offset_features.py).  Inside the
+//       image Win = 1 and the second line is the first; the correction only runs for cells on the image border
+//       (<a, mu> = sum_t w_t m_t - <r', mu>, m_t = <s'_t, mu> from the pre-pass).
+//
+//   how.  X' for 16 neighbouring pixels x 16 consecutive texels of a source row is a 16 x 16 x C matrix product:
+//       v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation).  The 64 (128) planes of the 16 pixels are spread
+//       over the 256 threads of a workgroup -- thread (pixel n, tq) owns PPT = 4 (8) consecutive planes -- so every
+//       phase of a pixel block is a few instructions long per wave, and four to five workgroups per CU interleave:
+//         positions   bit-faithful sample positions (geometry.hpp), two planes per packed instruction;
+//         row table   per source row the run of texels any sample touches: LDS min / max, rows indexed modulo 64; one
+//                     barrier; every wave then cuts the runs into blocks of 16 texels (same result in every wave);
+//         X           wave w multiplies blocks w, w + 4, ...: texel features by buffer_load_dwordx4 from the packed
+//                     source (out-of-image texels: out-of-range offset = 0), the pixels' reference features held in
+//                     registers as the B operand, X[pixel][slot] and the Gram records of the slots to LDS; one barrier;
+//         combine     per (pixel, plane): 4 X values, the Gram terms of the cell, the bilinear weights;
+//         epilogue    cost store; log-softmax over D and E[d]: per wave partial (max, sum, sum d) of each pixel, merged
+//                     across the four waves through LDS (one barrier).
+//       A pixel block whose planes need more than MAXB blocks is split into passes over plane ranges; one that does not
+//       fit even plane by plane (extreme poses) is evaluated directly by the same workgroup (direct_block): the kernel
+//       needs no tile flags and no second launch.
+//   scheduling.  Persistent workgroups pull 16x4 tiles (four pixel blocks; single blocks on small problems) from per-XCD
+//       queues, balanced partition as described at decode(); the last workgroup to leave zeroes the queue counters, so a
+//       call on an already packed source is this one launch.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+#include "geometry.hpp"
+#include "kernels.hpp"
+#include "pick.hpp"
+
+namespace pdepth {
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#ifndef CORR_OCC1   // waves per SIMD the register allocation must allow: D <= 64 / D <= 128
+#define CORR_OCC1 4
+#endif
+#ifndef CORR_OCC2
+#define CORR_OCC2 3
+#endif
+#ifndef CORR_MAXB1   // blocks of 16 texels a pass can take, D <= 64 (LDS: 4 workgroups per CU)
+#define CORR_MAXB1 23
+#endif
+constexpr int MAXROWS = 64;            // source rows per pass (row tables are indexed modulo 64)
+constexpr int BLK_PAD = 12;            // empty entries behind the block list (loads issued beyond it fetch nothing)
+constexpr int OOB = 0x7fffffff;        // buffer offset beyond every descriptor: the load returns 0
+constexpr int NO_CELL = INT_MIN;
+constexpr int EMPTY_BLOCK = (int)0xfffe0000;   // row -2: every texel out of range
+// a plane's two X / Gram slots and what the combine needs to know about its cell, in one register
+constexpr int SL_BITS = 10, SL_MASK = (1 << SL_BITS) - 1;
+constexpr int SL_VALID = 1 << 20, SL_XLO = 1 << 21, SL_XHI = 1 << 22, SL_YLO = 1 << 23, SL_YHI = 1 << 24;
+constexpr int SL_BORDER = SL_XLO | SL_XHI | SL_YLO | SL_YHI;
+
+__device__ __forceinline__ int opaque_v(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
+
+// every earlier LDS operation of this wave is done (LDS operations of one wave complete in order)
+#define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// workgroup barrier that waits for this wave's LDS traffic only: global loads and stores stay in flight
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// LDS-DMA (buffer_load ... lds): a wave-instruction moves 64 x 16 (4) bytes from memory to LDS address m0 + 16 (4) * lane, no
+// registers in between.  Issued from inline asm (the compiler must not know that these loads write LDS, or it drains them
+// in front of the next LDS read); counted in vmcnt like every load: the issuing wave waits for them by hand.
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma_b128(v4i rsrc, unsigned lds_addr, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ void dma_b32(v4i rsrc, unsigned lds_addr, int voff, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside the rows of 16 (DPP row_shr), then the row totals
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+#define CORR_DPP_STEP(OP, ctrl) v = OP(v, __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false))
+__device__ __forceinline__ int wave_min_i(int v) {
+    CORR_DPP_STEP(min, 0xB1); CORR_DPP_STEP(min, 0x4E); CORR_DPP_STEP(min, 0x141); CORR_DPP_STEP(min, 0x140);
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+    CORR_DPP_STEP(max, 0xB1); CORR_DPP_STEP(max, 0x4E); CORR_DPP_STEP(max, 0x141); CORR_DPP_STEP(max, 0x140);
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+#undef CORR_DPP_STEP
+
+// plane_sample_pos_fast() of geometry.hpp for two planes at a time in packed fp32 (v_pk_mul / v_pk_add / v_pk_fma_f32:
+// each component rounds exactly like the scalar instruction, so the positions are bit-identical)
+__device__ __forceinline__ v2f splat2(float x) { return v2f{x, x}; }
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f div_core2(v2f n, v2f d, v2f y) {
+    const v2f q0 = n * y;
+    const v2f r0 = fma2(-d, q0, n);
+    const v2f q1 = fma2(r0, y, q0);
+    const v2f r1 = fma2(-d, q1, n);
+    return fma2(r1, y, q1);
+}
+__device__ __forceinline__ void plane_sample_pos_fast2(const ViewXform& x, float t2a, float t2b, float t2c, v2f d, float cx, float cy,
+                                                       float rcx, float rcy, float half_w, float half_h, v2f& ix, v2f& iy) {
+    const v2f px = splat2(x.kt[0]) + splat2(t2a) * d;
+    const v2f py = splat2(x.kt[1]) + splat2(t2b) * d;
+    const v2f pz = splat2(x.kt[2]) + splat2(t2c) * d;
+    const v2f den = pz + splat2(1e-10f);
+    const v2f y0 = v2f{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    const v2f e = fma2(-den, y0, splat2(1.0f));
+    const v2f y = fma2(e, y0, y0);
+    const v2f u = div_core2(px, den, y);
+    const v2f v = div_core2(py, den, y);
+    const v2f gx = div_core2(u - splat2(cx), splat2(cx), splat2(rcx));
+    const v2f gy = div_core2(v - splat2(cy), splat2(cy), splat2(rcy));
+    ix = fma2(gx + splat2(1.0f), splat2(half_w), splat2(-0.5f));
+    iy = fma2(gy + splat2(1.0f), splat2(half_h), splat2(-0.5f));
+}
+
+// Footprint of a sample position as make_footprint() (geometry.hpp) computes it, packed: (y0 << 16) | (x0 & 0xffff) of the
+// top-left texel, or NO_CELL when no tap lies inside the image (NaN positions included); fw, fn = the fractions.
+__device__ __forceinline__ int cell_of(float ix, float iy, int W, int H, float& fw, float& fn) {
+    const float xfl = floorf(ix), yfl = floorf(iy);
+    fw = ix - xfl;
+    fn = iy - yfl;
+    const int x0 = (int)fminf(fmaxf(xfl, -2.0f), (float)(W + 1));
+    const int y0 = (int)fminf(fmaxf(yfl, -2.0f), (float)(H + 1));
+    const bool any = ix == ix && iy == iy && (unsigned)(x0 + 1) < (unsigned)(W + 1) && (unsigned)(y0 + 1) < (unsigned)(H + 1);
+    return any ? (y0 << 16) | (x0 & 0xffff) : NO_CELL;
+}
+__device__ __forceinline__ int cell_x(int xy) { return (int)(short)(xy & 0xffff); }
+__device__ __forceinline__ int cell_y(int xy) { return xy >> 16; }
+
+// Everything the kernel is given, in one struct that is its only argument: fields that are used once per item or pixel block
+// are re-read from the kernarg segment at the point of use (KARG) instead of occupying scalar registers for the whole
+// kernel, which runs out of them.
+struct CorrArgs {
+    SweepArgs a;
+    const float4* packed;
+    const float* mu_tab;
+    int* queue;
+    int tiles_x, ntile, spi;
+};
+template <typename T>
+__device__ __forceinline__ T cold_arg(size_t offset) {
+    typedef const char __attribute__((address_space(4))) * kptr;
+    typedef const volatile T __attribute__((address_space(4))) * vptr;
+    return *(vptr)((kptr)__builtin_amdgcn_kernarg_segment_ptr() + offset);
+}
+#define KARG(type, field) cold_arg<type>(offsetof(CorrArgs, field))
+
+constexpr int CORR_MAXV = 8;   // source views whose homography terms a workgroup keeps in LDS
+
+// MAXB = blocks of 16 texels a pass can take; NPL = packed feature planes
+template <int MAXB, int NPL>
+struct __attribute__((aligned(16))) CorrLds {
+    static constexpr int XSTRIDE = MAXB * 16 + 4;   // floats per pixel of the X buffer (stride / 4 odd: conflict-free b128 stores)
+    static constexpr int RS_TAIL = (NPL / 4) * 256;  // reference features: [chunk g][kq][pixel][4] floats, then [tail][kq][pixel]
+    float Xs[16 * XSTRIDE];      // X[pixel][slot]
+    float G4s[MAXB * 16 * 4];    // Gram record (N, H, V, D1 + D2) per slot
+    float Ms[MAXB * 16];         // <s', mu> per slot
+    float Rs[RS_TAIL + (NPL % 4) * 64 + 4];   // centred reference features of the block's 16 pixels, in B-operand order
+    float rp[4 * 16 * 2];        // per wave and pixel: partial |r'|^2, <r', mu>
+    float mu[80];                // channel means of the batch item in work; [72] = |mu|^2
+    float xf[CORR_MAXV * 12];    // per view: K@R (9), K@t (3)
+    float cst[8];                // cx, cy, 1/cx, 1/cy, W/2, H/2, sigma, 1/sigma
+    float red[4 * 16 * 4];       // epilogue exchange: (max, sum, sum d) per wave and pixel
+    float dcl[128];              // depth candidates
+    int cmin[2][MAXROWS], cmax[2][MAXROWS];   // per cell row (modulo 64): min / max x0; two sets, alternating by pass
+    int rowoff[MAXROWS + 2];     // per texel row of the pass: slot = x + rowoff
+    int blk[MAXB + BLK_PAD];     // per block: (y << 16) | (x & 0xffff) of its first texel
+    int ired[2][2];              // min / max cell row of the pass; two sets
+    int item[2];                 // work item: current / next
+    unsigned char wide[64];      // per batch item: pixel blocks are 16x1 (else 8x2)
+};
+
+__device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269502162933349609375f); }
+
+// NPL = packed feature planes of a source view (ceil(C / 4)); NH = groups of 64 planes (ceil(D / 64): 1 or 2), each a pass
+// of its own per view: thread (n, tq) owns planes 64 h + 4 tq .. + 3 of pass h.
+template <int NPL, int NH>
+__global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_corr_kernel(CorrArgs ca) {
+    constexpr int NCH = NPL / 4, NTL = NPL % 4;   // chunks of 16 channels (4 MFMAs per 16-byte load), left-over planes of 4
+    constexpr int LA = (NCH + 1) / 2, LB = NCH - LA;   // a block's loads in two halves: chunks [0, LA) | chunks [LA, NCH) + left-overs
+    constexpr int MCH = (4 * NPL + 15) / 16;      // channels per thread of the cooperative reference load
+    constexpr int MAXB = NH == 1 ? CORR_MAXB1 : 32;
+    constexpr int BPW = (MAXB + 3) / 4;           // blocks per wave and pass
+    constexpr int NC = 4 * NH;                    // planes (costs) per thread
+    typedef CorrLds<MAXB, NPL> Lds;
+    constexpr int XSTRIDE = Lds::XSTRIDE;
+    static_assert(MAXB * 16 + 16 <= (1 << SL_BITS), "slot bits");
+    __shared__ Lds L;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = KARG(int, a.D), H = KARG(int, a.H), W = KARG(int, a.W), V = KARG(int, a.V), C = KARG(int, a.C);
+
+    {
+        const float* dc = KARG(const float*, a.d_candi);
+        for (int k = tid; k < 64 * NH; k += 256) L.dcl[k] = dc[min(k, D - 1)];
+    }
+    if (tid < 64) {
+        L.cmin[0][tid] = INT_MAX; L.cmax[0][tid] = INT_MIN;
+        L.cmin[1][tid] = INT_MAX; L.cmax[1][tid] = INT_MIN;
+        L.wide[tid] = 1;
+    }
+    if (tid < 2) { L.ired[tid][0] = INT_MAX; L.ired[tid][1] = INT_MIN; }
+    __syncthreads();
+    // Shape of the pixel blocks of a batch item: 16x1 where the epipolar lines of view 0 run along the source rows (a
+    // rectified pair: the 16 pixels of a row share two source rows), else 8x2 (pick.hpp; any choice is correct).
+    if ((int)(tid >> 2) < min(KARG(int, a.B), 64) && epipolar_probe_is_steep(ca.a, tid >> 2, tid & 3)) L.wide[tid >> 2] = 0;
+
+    // ---- work queue (per XCD, as the other persistent kernels of this library) ----------------------------------------
+    // Workgroups are dealt round-robin over the 8 XCDs; XCD q owns the tiles of band q (its own queue counter), so that
+    // neighbouring tiles, whose source texels overlap, meet in that XCD's L2.  A workgroup whose queue is exhausted takes
+    // items of the others.  m = items per tile (1: a tile's four pixel blocks in sequence; 4: one block per item).
+    const int xcd = blockIdx.x & 7;
+    auto band_tiles_of = [&](int q) { const int nt = KARG(int, ntile); return (nt >> 3) + (q < (nt & 7) ? 1 : 0); };
+    auto band_first_of = [&](int q) {
+        const int nt = KARG(int, ntile), qq = nt >> 3, rr8 = nt & 7;
+        return q < rr8 ? q * (qq + 1) : rr8 * (qq + 1) + (q - rr8) * qq;
+    };
+    bool own_done = false;
+    auto steal = [&]() -> int {   // (queue << 28) | index in the queue, or -1: every queue is exhausted
+        int* queue = KARG(int*, queue);
+        const int mB = (4 / KARG(int, spi)) * KARG(int, a.B);
+        for (int j = 1; j < 8; ++j) {
+            const int q = (xcd + j) & 7, nq = band_tiles_of(q) * mB;
+            if (*(volatile int*)&queue[q] >= nq) continue;
+            const int got = atomicAdd(&queue[q], 1);
+            if (got < nq) return (q << 28) | got;
+        }
+        return -1;
+    };
+    auto resolve = [&](int got) -> int {
+        const int n_own = band_tiles_of(xcd) * (4 / KARG(int, spi)) * KARG(int, a.B);
+        if (!own_done && got < n_own) return (xcd << 28) | got;
+        own_done = true;
+        return steal();
+    };
+    // floor(nn / dd) for 0 <= nn < 2^22, 0 < dd (an integer divide costs ~40 dependent instructions)
+    auto fdiv = [](int nn, int dd) { return (int)(((float)nn + 0.5f) * __builtin_amdgcn_rcpf((float)dd)); };
+    auto decode = [&](int item, int& b_, int& tx_, int& ty_, int& sub0_) {
+        const int ntile = KARG(int, ntile), tiles_x = KARG(int, tiles_x), spi = KARG(int, spi);
+        const int m = 4 / spi, msh = spi == 1 ? 2 : 0, qq = ntile >> 3, rr8 = ntile & 7;
+        const bool small_idx = (long long)ntile * m * KARG(int, a.B) < (1ll << 22);
+        const int tiles_y_ = (H + 3) / 4;
+        const int q_ = item >> 28, iq = item & 0x0fffffff, band_tiles = band_tiles_of(q_), per_b = band_tiles * m;
+        b_ = small_idx ? fdiv(iq, per_b) : iq / per_b;
+        const int rem = iq - b_ * per_b, ti = rem >> msh;
+        sub0_ = (rem & (m - 1)) * spi;
+        int tile = band_first_of(q_) + ti;
+        if (rr8 == 0 && tiles_y_ % 16 == 0 && tiles_y_ * tiles_x == ntile) {
+            // XCD q owns half-bands q and 8 + q of the image's 16: on a forward motion the cost of a tile grows with its
+            // distance from the image centre, and this way every XCD gets the same mix; the heavier half first and, inside
+            // a half, columns from both image borders inwards.  (Any static partition is valid: dry queues steal.)
+            const int hb_rows = tiles_y_ / 16, half_tiles = hb_rows * tiles_x;
+            const int second = ti >= half_tiles ? 1 : 0, tih = ti - second * half_tiles;
+            const int hbi = (q_ < 4) == (second == 0) ? q_ : 8 + q_;
+            const int cc = small_idx ? fdiv(tih, hb_rows) : tih / hb_rows, r_ = tih - cc * hb_rows;
+            const int col = (cc & 1) ? tiles_x - 1 - (cc >> 1) : (cc >> 1);
+            tile = (hbi * hb_rows + r_) * tiles_x + col;
+        } else if (rr8 == 0 && qq % tiles_x == 0) {   // the band is a whole number of tile rows: column by column
+            const int band_rows = qq / tiles_x, tc = small_idx ? fdiv(ti, band_rows) : ti / band_rows;
+            tile = (q_ * band_rows + (ti - tc * band_rows)) * tiles_x + tc;
+        }
+        ty_ = small_idx ? fdiv(tile, tiles_x) : tile / tiles_x;
+        tx_ = tile - ty_ * tiles_x;
+    };
+    // (when the grid covers every item -- small problems -- workgroup i takes item i of its XCD's band: no atomics)
+    const bool one_each = (long long)gridDim.x >= 8ll * ((KARG(int, ntile) + 7) / 8) * (4 / KARG(int, spi)) * KARG(int, a.B);
+    __syncthreads();
+    int slot_par = 0;
+    int pt = 0;           // running pass counter: selects the set of row-table arrays
+    int n_direct = 0;     // (thread 0) pixel blocks evaluated directly
+    // (thread 0) the atomic on the own queue is issued at the top of an item and its result looked at when the item is done
+    int got_own = (tid == 0 && !one_each) ? atomicAdd(&KARG(int*, queue)[xcd], 1) : (int)(blockIdx.x >> 3);
+    bool first = true;
+
+    for (;;) {
+        if (tid == 0) {
+            const int n_own = band_tiles_of(xcd) * (4 / KARG(int, spi)) * KARG(int, a.B);
+            L.item[slot_par] = one_each ? (first && got_own < n_own ? (xcd << 28) | got_own : -1) : resolve(got_own);
+        }
+        first = false;
+        LDS_BARRIER();   // the item is published; every wave is done with the previous one's LDS
+        const int item = __builtin_amdgcn_readfirstlane(*(volatile int*)&L.item[slot_par]);
+        slot_par ^= 1;
+        if (item < 0) break;
+        if (tid == 0 && !one_each && !own_done) got_own = atomicAdd(&KARG(int*, queue)[xcd], 1);
+        int b, tx, ty, sub0;
+        decode(item, b, tx, ty, sub0);
+        // per item, for every wave: channel means, the views' homography terms, the camera constants (visible behind the
+        // barrier in front of the first block's centring)
+        if (tid < 72) L.mu[tid] = KARG(const float*, mu_tab)[b * STATS_STRIDE + tid];
+        else if (tid < 80 && tid != 72) L.mu[tid] = 0.0f;
+        if (wave == 1) {   // |mu|^2
+            const float* mt = KARG(const float*, mu_tab) + b * STATS_STRIDE;
+            float m2 = 0.0f;
+            if (lane < 36) { const float u0 = mt[lane], u1 = mt[lane + 36]; m2 = __builtin_fmaf(u0, u0, u1 * u1); }
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) m2 = m2 + __shfl_xor(m2, sh);
+            if (lane == 0) L.mu[72] = m2;
+        }
+        if (tid >= 128 && tid < 128 + V) {
+            const int v = tid - 128;
+            ViewXform xf;
+            make_view_xform(KARG(const float*, a.K) + b * 9, KARG(const float*, a.R) + ((size_t)b * V + v) * 9,
+                            KARG(const float*, a.t) + ((size_t)b * V + v) * 3, KARG(int, a.blas_mode), xf);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) L.xf[v * 12 + i] = xf.kr[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) L.xf[v * 12 + 9 + i] = xf.kt[i];
+        }
+        if (tid == 255) {
+            const float* const cxcy_ = KARG(const float*, a.cxcy);
+            const float cx = cxcy_[b * 2 + 0], cy = cxcy_[b * 2 + 1], sg = KARG(float, a.sigma);
+            L.cst[0] = cx; L.cst[1] = cy; L.cst[2] = refined_rcp(cx); L.cst[3] = refined_rcp(cy);
+            L.cst[4] = (float)W / 2.0f; L.cst[5] = (float)H / 2.0f; L.cst[6] = sg; L.cst[7] = refined_rcp(sg);
+        }
+        const bool wide = b < 64 ? L.wide[b] != 0 : false;
+        bool item_ready = false;
+        const int spi = KARG(int, spi);
+
+        for (int sub = sub0; sub < sub0 + spi; ++sub) {
+            if ((wide ? ty * 4 + sub : ty * 4 + 2 * (sub >> 1)) >= H) continue;   // the block lies below the image (uniform)
+            // lane roles: in the vector phases thread (n, tq) owns pixel n of the block and planes 64 h + 4 tq .. + 3; in the
+            // matrix phase lane (n, kq) of a wave feeds texel / pixel n and channel slice kq.  (opaque: the optimiser
+            // otherwise hoists every lane-derived invariant of the phases -- masks, LDS addresses, offsets -- to the top of
+            // the kernel and spills them)
+            const int n = opaque_v(lane & 15), kq = opaque_v(lane >> 4), tq = wave * 4 + kq;
+            const int HW = opaque_s(H * W);
+            const int x = wide ? tx * 16 + n : tx * 16 + 8 * (sub & 1) + (n & 7);
+            const int y = wide ? ty * 4 + sub : ty * 4 + 2 * (sub >> 1) + (n >> 3);
+            const bool xlive = x < W && y < H;
+            const int p = min(y, H - 1) * W + min(x, W - 1);
+            // the pixel's ray, and this thread's share of the block's reference features: channels tq, tq + 16, ... of pixel n
+            // (buffer loads: 32-bit offsets, the channel as the scalar offset; channels beyond C = 0)
+            float ray[3], rv[MCH];
+            {
+                const __amdgpu_buffer_rsrc_t rray =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(KARG(const float*, a.rays) + (size_t)b * 3 * HW), 0, 3 * HW * 4, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) ray[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rray, p * 4, i * HW * 4, 0));
+                const __amdgpu_buffer_rsrc_t rref =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(KARG(const float*, a.ref) + (size_t)b * KARG(long long, a.ref_bstride)), 0,
+                                                      C * HW * 4, 0x00020000);
+#pragma unroll
+                for (int mm = 0; mm < MCH; ++mm)
+                    rv[mm] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rref, tq + 16 * mm < C ? (tq * HW + p) * 4 : OOB, 16 * mm * HW * 4, 0));
+            }
+            float Rr[NPL];                 // the pixels' centred reference features, the B operands of every MFMA of the block
+            float rr = 0.0f, rho = 0.0f;   // |r'|^2 and <r', mu> of the pixel (set with the first pass)
+            bool centred = false;
+            bool failed = false;           // uniform over the workgroup: some pass of the block did not fit the row tables
+
+            float cost[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) cost[j] = 0.0f;
+
+            for (int v = 0; v < V; ++v) {
+                const float4* srcv = KARG(const float4*, packed) + ((size_t)b * V + v) * (NPL + 2) * HW;
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)srcv, 0, (NPL + 2) * HW * 16, 0x00020000);
+
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const int par = pt & 1;
+                    if (!item_ready) { LDS_BARRIER(); item_ready = true; }   // (the item's tables above are in LDS)
+                    // ---- sample positions of this thread's planes of the pass (NO_CELL: no tap in the image, plane beyond D,
+                    //      pixel beyond the image)
+                    int cell[4];
+                    float fw[4], fn[4];
+                    {
+                        ViewXform xf;
+                        float t2a, t2b, t2c;
+                        {
+                            const v4f k0 = *reinterpret_cast<const v4f*>(&L.xf[v * 12]), k1 = *reinterpret_cast<const v4f*>(&L.xf[v * 12 + 4]),
+                                      k2 = *reinterpret_cast<const v4f*>(&L.xf[v * 12 + 8]);
+                            xf.kr[0] = k0.x; xf.kr[1] = k0.y; xf.kr[2] = k0.z; xf.kr[3] = k0.w; xf.kr[4] = k1.x; xf.kr[5] = k1.y;
+                            xf.kr[6] = k1.z; xf.kr[7] = k1.w; xf.kr[8] = k2.x; xf.kt[0] = k2.y; xf.kt[1] = k2.z; xf.kt[2] = k2.w;
+                            xf.separate = KARG(int, a.blas_mode);
+                            ray_term2(xf, ray[0], ray[1], ray[2], t2a, t2b, t2c);
+                        }
+                        const v4f c0 = *reinterpret_cast<const v4f*>(&L.cst[0]);
+                        const v2f c1 = *reinterpret_cast<const v2f*>(&L.cst[4]);
+#pragma unroll
+                        for (int j = 0; j < 4; j += 2) {
+                            const int k = 64 * h + 4 * tq + j;
+                            v2f ix, iy;
+                            plane_sample_pos_fast2(xf, t2a, t2b, t2c, v2f{L.dcl[k], L.dcl[k + 1]}, c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ix, iy);
+                            cell[j] = cell_of(ix.x, iy.x, W, H, fw[j], fn[j]);
+                            cell[j + 1] = cell_of(ix.y, iy.y, W, H, fw[j + 1], fn[j + 1]);
+                            if (k >= D || !xlive) cell[j] = NO_CELL;
+                            if (k + 1 >= D || !xlive) cell[j + 1] = NO_CELL;
+                        }
+                    }
+                    // ---- row table: contributions of this thread's planes --------------------------------------------------
+                    {
+                        int lmin = INT_MAX, lmax = INT_MIN;
+                        int run = INT_MIN, rmin = 0, rmax = 0;   // consecutive planes of equal row are folded first
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (cell[j] != NO_CELL) {
+                                const int cyy = cell_y(cell[j]), cxx = cell_x(cell[j]);
+                                lmin = min(lmin, cyy); lmax = max(lmax, cyy);
+                                if (cyy != run) {
+                                    if (run != INT_MIN) { atomicMin(&L.cmin[par][run & 63], rmin); atomicMax(&L.cmax[par][run & 63], rmax); }
+                                    run = cyy; rmin = cxx; rmax = cxx;
+                                } else {
+                                    rmin = min(rmin, cxx); rmax = max(rmax, cxx);
+                                }
+                            }
+                        }
+                        if (run != INT_MIN) { atomicMin(&L.cmin[par][run & 63], rmin); atomicMax(&L.cmax[par][run & 63], rmax); }
+                        const int wmin = wave_min_i(lmin), wmax = wave_max_i(lmax);
+                        if (lane == 0 && wmin <= wmax) { atomicMin(&L.ired[par][0], wmin); atomicMax(&L.ired[par][1], wmax); }
+                    }
+                    if (!centred) {
+                        // (first pass of the block) this thread's channels of pixel n, centred, into the B-operand image of the
+                        // block: channel c = 16 g + 4 kq' + i belongs to lane (n, kq') of every wave, component i of chunk g --
+                        // for c = tq + 16 mm that is g = mm, kq' = wave, i = kq; and its share of |r'|^2 and <r', mu>
+                        float pr = 0.0f, ph = 0.0f;
+#pragma unroll
+                        for (int mm = 0; mm < MCH; ++mm) {
+                            // (the last round only covers the left-over planes; channels beyond C: 0 - 0)
+                            const bool has = mm < NCH || tq < 4 * NTL;
+                            const float u = has ? L.mu[min(tq + 16 * mm, 71)] : 0.0f;
+                            const float r = has ? rv[mm] - u : 0.0f;
+                            pr = __builtin_fmaf(r, r, pr);
+                            ph = __builtin_fmaf(r, u, ph);
+                            if (mm < NCH) L.Rs[((mm * 4 + wave) * 16 + n) * 4 + kq] = r;
+                            else if (wave < NTL) L.Rs[Lds::RS_TAIL + (wave * 4 + kq) * 16 + n] = r;
+                        }
+                        pr = pr + __shfl_xor(pr, 16); pr = pr + __shfl_xor(pr, 32);
+                        ph = ph + __shfl_xor(ph, 16); ph = ph + __shfl_xor(ph, 32);
+                        if (kq == 0) *reinterpret_cast<v2f*>(&L.rp[(wave * 16 + n) * 2]) = v2f{pr, ph};
+                    }
+                    LDS_BARRIER();
+                    const int ybase = __builtin_amdgcn_readfirstlane(L.ired[par][0]), ytop = __builtin_amdgcn_readfirstlane(L.ired[par][1]);
+                    int nb = 0;
+                    bool fits = true;
+                    if (ybase <= ytop) {
+                        const int ncell = ytop - ybase + 1;
+                        if (ncell + 1 > MAXB) {   // (every texel row takes a block; also keeps the modulo-64 rows apart)
+                            fits = false;
+                        } else {
+                            // lane = texel row ybase + lane: the cells of rows lane - 1 and lane touch it (every wave computes the
+                            // same table and writes the same values)
+                            int lo = INT_MAX, hi = INT_MIN;
+                            if (lane < ncell) { lo = L.cmin[par][(ybase + lane) & 63]; hi = L.cmax[par][(ybase + lane) & 63]; }
+                            if (lane >= 1 && lane <= ncell) {
+                                lo = min(lo, L.cmin[par][(ybase + lane - 1) & 63]);
+                                hi = max(hi, L.cmax[par][(ybase + lane - 1) & 63]);
+                            }
+                            const int nblk = lo <= hi ? (hi - lo + 2 + 15) >> 4 : 0;   // texels lo .. hi + 1
+                            const int incl = wave_scan_incl(nblk);
+                            nb = __builtin_amdgcn_readlane(incl, 63);
+                            fits = nb <= MAXB;
+                            if (fits) {
+                                const int fb = incl - nblk;
+                                if (lane <= ncell) L.rowoff[lane] = 16 * fb - lo;
+                                for (int i = 0; i < nblk; ++i) L.blk[fb + i] = ((ybase + lane) << 16) | ((lo + 16 * i) & 0xffff);
+                                if (lane < BLK_PAD) L.blk[nb + lane] = EMPTY_BLOCK;
+                                WAVE_LDS_SYNC();
+                            }
+                        }
+                    }
+                    // the two X / Gram slots of this thread's planes and the border flags of their cells, one register each
+                    int sl[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        sl[j] = 0;
+                        if (fits && cell[j] != NO_CELL) {
+                            const int cyy = cell_y(cell[j]), cxx = cell_x(cell[j]), r = cyy - ybase;
+                            sl[j] = (cxx + L.rowoff[r]) | ((cxx + L.rowoff[r + 1]) << SL_BITS) | SL_VALID | (cxx < 0 ? SL_XLO : 0) |
+                                    (cxx >= W - 1 ? SL_XHI : 0) | (cyy < 0 ? SL_YLO : 0) | (cyy >= H - 1 ? SL_YHI : 0);
+                        }
+                    }
+                    if (!centred) {
+                        // the block's reference features from LDS, as lane (n, kq) feeds them to the matrix pipe
+#pragma unroll
+                        for (int g = 0; g < NCH; ++g) {
+                            const v4f r4 = *reinterpret_cast<const v4f*>(&L.Rs[((g * 4 + kq) * 16 + n) * 4]);
+                            Rr[4 * g + 0] = r4.x; Rr[4 * g + 1] = r4.y; Rr[4 * g + 2] = r4.z; Rr[4 * g + 3] = r4.w;
+                        }
+#pragma unroll
+                        for (int tp = 0; tp < NTL; ++tp) Rr[4 * NCH + tp] = L.Rs[Lds::RS_TAIL + (tp * 4 + kq) * 16 + n];
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const v2f pp = *reinterpret_cast<const v2f*>(&L.rp[(w * 16 + n) * 2]);
+                            rr = rr + pp.x; rho = rho + pp.y;
+                        }
+                        centred = true;
+                    }
+
+                    // ---- X' = <r', s'> for the blocks of the pass, on the matrix pipe ---------------------------------------
+                    if (fits && nb > 0) {
+                        const int myblk = L.blk[min(lane, MAXB + BLK_PAD - 1)];   // the block list in a register: entry l in lane l
+                        // Gram records (N, H, V, D1 + D2) and <s', mu> of the pass's slots (texel = slot of a block), straight
+                        // from the packed source into LDS: wave w moves slots 64 c .. 64 c + 63 for c = w, w + 4, ...
+                        {
+                            v4i rs4;   // the descriptor of rsrc, spelled out for the inline asm
+                            {
+                                const unsigned long long pa = reinterpret_cast<unsigned long long>(srcv);
+                                rs4.x = (int)(unsigned)pa; rs4.y = (int)(unsigned)(pa >> 32) & 0xffff; rs4.z = (NPL + 2) * HW * 16; rs4.w = 0x00020000;
+                            }
+#pragma unroll
+                            for (int c = 0; c < (MAXB * 16 + 255) / 256; ++c) {
+                                const int c64 = (wave + 4 * c) * 64;
+                                if (c64 < 16 * nb) {   // (uniform per wave)
+                                    const int slot = c64 + lane;
+                                    const int be = L.blk[min(slot >> 4, MAXB + BLK_PAD - 1)];
+                                    const int yy = be >> 16, xx = (int)(short)(be & 0xffff) + (slot & 15);
+                                    const bool ok = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && slot < 16 * nb;
+                                    const int vg = ok ? (yy * W + xx) * 16 : OOB;
+                                    dma_b128(rs4, lds_addr_of(&L.G4s[c64 * 4]), vg, NPL * HW * 16);
+                                    dma_b32(rs4, lds_addr_of(&L.Ms[c64]), vg, (NPL + 1) * HW * 16);
+                                }
+                            }
+                        }
+                        // a block's texel features in two halves (chunks [0, LA) | chunks [LA, NCH) + left-overs): while one half is
+                        // multiplied the other half's loads are in flight -- half the staging registers of whole blocks
+                        v4f SA[LA > 0 ? LA : 1], SB[LB > 0 ? LB : 1];
+                        float TB[NTL > 0 ? NTL : 1];
+                        int vo = OOB, vt = OOB;   // lane offsets of the block whose loads are being issued
+                        auto prep = [&](int bi) {
+                            const int be = __builtin_amdgcn_readlane(myblk, bi);
+                            const int yy = be >> 16, xx = (int)(short)(be & 0xffff) + n;
+                            const bool ok = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
+                            const int t16 = (yy * W + xx) * 16;
+                            vo = opaque_v(ok ? t16 + kq * HW * 16 : OOB);   // (opaque: one load with a selected offset, no branch)
+                            if (NTL > 0) vt = opaque_v(ok ? t16 + kq * 4 : OOB);
+                        };
+                        auto load_a = [&]() {
+#pragma unroll
+                            for (int gi = 0; gi < LA; ++gi)
+                                SA[gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, gi * 4 * HW * 16, 0));
+                        };
+                        auto load_b = [&]() {
+#pragma unroll
+                            for (int gi = 0; gi < LB; ++gi)
+                                SB[gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, (LA + gi) * 4 * HW * 16, 0));
+#pragma unroll
+                            for (int tp = 0; tp < NTL; ++tp)
+                                TB[tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vt, (4 * NCH + tp) * HW * 16, 0));
+                        };
+                        // ceil(C/4) MFMAs per block in two alternating accumulator chains (a dependent f32 MFMA waits 40 cycles, an
+                        // independent one issues after 32)
+                        v4f acc0, acc1;
+                        auto mul_a = [&]() {
+#pragma unroll
+                            for (int gi = 0; gi < LA; ++gi) {
+                                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(SA[gi][0], Rr[4 * gi + 0], acc0, 0, 0, 0);
+                                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(SA[gi][1], Rr[4 * gi + 1], acc1, 0, 0, 0);
+                                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(SA[gi][2], Rr[4 * gi + 2], acc0, 0, 0, 0);
+                                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(SA[gi][3], Rr[4 * gi + 3], acc1, 0, 0, 0);
+                            }
+                        };
+                        auto mul_b = [&]() {
+#pragma unroll
+                            for (int gi = 0; gi < LB; ++gi) {
+                                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(SB[gi][0], Rr[4 * (LA + gi) + 0], acc0, 0, 0, 0);
+                                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(SB[gi][1], Rr[4 * (LA + gi) + 1], acc1, 0, 0, 0);
+                                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(SB[gi][2], Rr[4 * (LA + gi) + 2], acc0, 0, 0, 0);
+                                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(SB[gi][3], Rr[4 * (LA + gi) + 3], acc1, 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int tp = 0; tp < NTL; ++tp) {
+                                if (tp & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(TB[tp], Rr[4 * NCH + tp], acc1, 0, 0, 0);
+                                else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(TB[tp], Rr[4 * NCH + tp], acc0, 0, 0, 0);
+                            }
+                        };
+                        // wave w: blocks w, w + 4, ... (unrolled with forward exits; loads beyond the list hit the empty entries behind
+                        // it and fetch nothing)
+                        prep(wave);
+                        load_a();
+                        load_b();
+#pragma unroll
+                        for (int i = 0; i < BPW; ++i) {
+                            const int bi = wave + 4 * i;
+                            if (bi >= nb) break;
+                            acc0 = v4f{0.f, 0.f, 0.f, 0.f}; acc1 = v4f{0.f, 0.f, 0.f, 0.f};
+                            if (i + 1 < BPW) prep(bi + 4);
+                            mul_a();
+                            if (i + 1 < BPW) load_a();
+                            mul_b();
+                            if (i + 1 < BPW) load_b();
+                            *reinterpret_cast<v4f*>(&L.Xs[n * XSTRIDE + 16 * bi + 4 * kq]) = acc0 + acc1;   // X[texel][pixel] of the block
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's Gram records have landed in LDS
+                    }
+                    LDS_BARRIER();   // X and the Gram records of the pass are complete (or: every wave has seen that it does not fit)
+                    if (tid < 64) { L.cmin[par][tid] = INT_MAX; L.cmax[par][tid] = INT_MIN; }   // (this pass's tables are dead)
+                    if (tid == 0) { L.ired[par][0] = INT_MAX; L.ired[par][1] = INT_MIN; }
+                    ++pt;
+                    failed = failed || !fits;
+
+                    // ---- combine: cost of this thread's planes of the pass ------------------------------------------------
+                    if (fits) {
+                        const v2f sg = *reinterpret_cast<const v2f*>(&L.cst[6]);   // sigma, 1 / sigma
+                        const float M2 = L.mu[72];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            // (no tap inside the image: the taps read zero, cost = |r|^2 = |r' + mu|^2 -- and NaN where the
+                            //  position itself is not finite, as the reference's weights inf - floor(inf) make it)
+                            float q = (__builtin_fmaf(2.0f, rho, rr) + M2) + (fw[j] + fn[j]) * 0.0f;
+                            if (sl[j] & SL_VALID) {
+                                const int st = sl[j] & SL_MASK, sb = (sl[j] >> SL_BITS) & SL_MASK;
+                                const float* xr = &L.Xs[n * XSTRIDE];
+                                const float X00 = xr[st], X01 = xr[st + 1], X10 = xr[sb], X11 = xr[sb + 1];
+                                const v4f G00 = *reinterpret_cast<const v4f*>(&L.G4s[st * 4]);
+                                const v4f G01 = *reinterpret_cast<const v4f*>(&L.G4s[(st + 1) * 4]);   // (N, -, V, -)
+                                const v2f G10 = *reinterpret_cast<const v2f*>(&L.G4s[sb * 4]);         // (N, H)
+                                const float G11x = L.G4s[(sb + 1) * 4];
+                                const float fe = 1.0f - fw[j], fs = 1.0f - fn[j];
+                                // |sum_t w_t s'_t|^2, separable in the x weights (e, w) and the y weights (s, n)
+                                const float ee = fe * fe, ww = fw[j] * fw[j], ew2 = 2.0f * (fe * fw[j]);
+                                const float A = __builtin_fmaf(ee, G00.x, __builtin_fmaf(ww, G01.x, ew2 * G00.y));   // top row
+                                const float Bq = __builtin_fmaf(ee, G10.x, __builtin_fmaf(ww, G11x, ew2 * G10.y));   // bottom row
+                                const float Cq = __builtin_fmaf(ee, G00.z, __builtin_fmaf(ww, G01.z, (fe * fw[j]) * G00.w));   // cross rows
+                                const float Q = __builtin_fmaf(fs * fs, A, __builtin_fmaf(fn[j] * fn[j], Bq, (2.0f * (fs * fn[j])) * Cq));
+                                const float XW = __builtin_fmaf(fs * fe, X00, __builtin_fmaf(fs * fw[j], X01,
+                                                 __builtin_fmaf(fn[j] * fe, X10, (fn[j] * fw[j]) * X11)));
+                                q = __builtin_fmaf(-2.0f, XW, Q) + rr;
+                                if (sl[j] & SL_BORDER) {
+                                    // a cell on the image border: the taps outside read zero, not mu (header)
+                                    const float wx = ((sl[j] & SL_XLO) ? 0.0f : fe) + ((sl[j] & SL_XHI) ? 0.0f : fw[j]);
+                                    const float wy = ((sl[j] & SL_YLO) ? 0.0f : fs) + ((sl[j] & SL_YHI) ? 0.0f : fn[j]);
+                                    const float om = 1.0f - wx * wy;
+                                    const float MW = __builtin_fmaf(fs * fe, L.Ms[st], __builtin_fmaf(fs * fw[j], L.Ms[st + 1],
+                                                     __builtin_fmaf(fn[j] * fe, L.Ms[sb], (fn[j] * fw[j]) * L.Ms[sb + 1])));
+                                    q = __builtin_fmaf(om, __builtin_fmaf(om, M2, -2.0f * (MW - rho)), q);
+                                }
+                            }
+                            // q / sigma through the divide chain of geometry.hpp (bit-identical to the IEEE divide for finite operands)
+                            cost[4 * h + j] = cost[4 * h + j] + (fabsf(q) < 1.0e30f ? div_core(q, sg.x, sg.y) : q * sg.y);
+                        }
+                    }
+                }
+            }
+
+            if (failed) {
+                // ---- the geometry of some pass does not fit the row tables (extreme poses): the whole block directly, in the
+                //      reference's form on the centred features
+                if (tid == 0) ++n_direct;
+                const v4f c0 = *reinterpret_cast<const v4f*>(&L.cst[0]), c1 = *reinterpret_cast<const v4f*>(&L.cst[4]);
+#pragma unroll
+                for (int j = 0; j < NC; ++j) cost[j] = 0.0f;
+                const float* refp = KARG(const float*, a.ref) + (size_t)b * KARG(long long, a.ref_bstride) + p;
+                for (int v = 0; v < V; ++v) {
+                    ViewXform xf;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) xf.kr[i] = L.xf[v * 12 + i];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) xf.kt[i] = L.xf[v * 12 + 9 + i];
+                    xf.separate = KARG(int, a.blas_mode);
+                    float t2a, t2b, t2c;
+                    ray_term2(xf, ray[0], ray[1], ray[2], t2a, t2b, t2c);
+                    const float* srcf = reinterpret_cast<const float*>(KARG(const float4*, packed) + ((size_t)b * V + v) * (NPL + 2) * HW);
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) {
+                        const int k = 64 * (j >> 2) + 4 * tq + (j & 3);
+                        float part = 0.0f;
+                        if (k < D && xlive) {
+                            float ix, iy;
+                            plane_sample_pos_fast(xf, t2a, t2b, t2c, L.dcl[k], c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ix, iy);
+                            const Footprint f = make_footprint(ix, iy, W, H);
+                            const float win = ((f.mask & 1u) ? f.nw : 0.0f) + ((f.mask & 2u) ? f.ne : 0.0f) +
+                                              ((f.mask & 4u) ? f.sw : 0.0f) + ((f.mask & 8u) ? f.se : 0.0f);
+                            const float om = f.mask == 15u ? 0.0f : 1.0f - win;
+                            const float* s00 = srcf + (size_t)(f.y0 * W + f.x0) * 4;
+                            part = (f.nw + f.ne + f.sw + f.se) * 0.0f;   // (NaN weights: NaN cost, as the reference)
+#pragma unroll 1
+                            for (int c = 0; c < C; ++c) {
+                                const float* s = s00 + (size_t)(c >> 2) * HW * 4 + (c & 3);
+                                const float vnw = (f.mask & 1u) ? s[0] : 0.0f;
+                                const float vne = (f.mask & 2u) ? s[4] : 0.0f;
+                                const float vsw = (f.mask & 4u) ? s[W * 4] : 0.0f;
+                                const float vse = (f.mask & 8u) ? s[(W + 1) * 4] : 0.0f;
+                                float val = vnw * f.nw;
+                                val = __builtin_fmaf(vne, f.ne, val);
+                                val = __builtin_fmaf(vsw, f.sw, val);
+                                val = __builtin_fmaf(vse, f.se, val);
+                                const float u = L.mu[c];
+                                const float diff = (val - (refp[(size_t)c * HW] - u)) - om * u;
+                                part = __builtin_fmaf(diff, diff, part);
+                            }
+                        }
+                        cost[j] = cost[j] + (fabsf(part) < 1.0e30f ? div_core(part, c1.z, c1.w) : part * c1.w);
+                    }
+                }
+            }
+
+            // ---- epilogue: cost store, log-softmax over D, expectation ----------------------------------------------------
+            // (buffer stores: one 32-bit lane offset, the plane as the scalar offset: plane 64 h + 16 wave + 4 kq + j)
+            const int ovoff = xlive ? (4 * kq * HW + p) * 4 : OOB;
+            float* const cost_out = KARG(float*, a.cost_out);
+            float* const logp_out = KARG(float*, a.logp_out);
+            float* const depth_out = KARG(float*, a.depth_out);
+            if (cost_out) {
+                const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(cost_out + (size_t)b * D * HW), 0, D * HW * 4, 0x00020000);
+#pragma unroll
+                for (int j = 0; j < NC; ++j)   // (planes beyond D lie beyond the descriptor: dropped)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cost[j]), rc, ovoff, (64 * (j >> 2) + 16 * wave + (j & 3)) * HW * 4, 0);
+            }
+            if (logp_out || depth_out) {
+                // per wave: max, sum exp, sum d exp over its planes of pixel n; merged over the four waves through LDS
+                float mx = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < NC; ++j)
+                    if (64 * (j >> 2) + 4 * tq + (j & 3) < D) mx = fmaxf(mx, cost[j]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float ssum = 0.0f, esum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    const int k = 64 * (j >> 2) + 4 * tq + (j & 3);
+                    const float ek = k < D ? exp_nonpos(cost[j] - mx) : 0.0f;
+                    ssum = ssum + ek;
+                    esum = __builtin_fmaf(L.dcl[k], ek, esum);
+                }
+                ssum = ssum + __shfl_xor(ssum, 16); ssum = ssum + __shfl_xor(ssum, 32);
+                esum = esum + __shfl_xor(esum, 16); esum = esum + __shfl_xor(esum, 32);
+                if (kq == 0) *reinterpret_cast<v4f*>(&L.red[(wave * 16 + n) * 4]) = v4f{mx, ssum, esum, 0.0f};
+                LDS_BARRIER();
+                float M = -INFINITY;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) M = fmaxf(M, L.red[(w * 16 + n) * 4]);
+                float S = 0.0f, E = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const v4f part = *reinterpret_cast<const v4f*>(&L.red[(w * 16 + n) * 4]);
+                    // (a wave whose planes all lie beyond D: max -inf, sums 0)
+                    const float sc = part.x == -INFINITY ? 0.0f : exp_nonpos(part.x - M);
+                    S = __builtin_fmaf(part.y, sc, S);
+                    E = __builtin_fmaf(part.z, sc, E);
+                }
+                const float ls = logf(S);
+                if (logp_out) {
+                    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(logp_out + (size_t)b * D * HW), 0, D * HW * 4, 0x00020000);
+#pragma unroll
+                    for (int j = 0; j < NC; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (cost[j] - M) - ls), rl, ovoff,
+                                                              (64 * (j >> 2) + 16 * wave + (j & 3)) * HW * 4, 0);
+                }
+                if (depth_out && xlive && tq == 0) depth_out[(size_t)b * HW + p] = E / S;
+            }
+        }   // pixel blocks of the item
+    }   // items
+
+    // the last workgroup to leave zeroes the queue counters: the next call on this workspace needs no clearing launch
+    if (tid == 0) {
+        int* queue = KARG(int*, queue);
+        if (n_direct) atomicAdd(&queue[CORR_DIRECT_SLOT], n_direct);
+        const int done = atomicAdd(&queue[CORR_DONE_SLOT], 1);
+        if (done == (int)gridDim.x - 1) {
+            const int nd = atomicAdd(&queue[CORR_DIRECT_SLOT], 0);
+            for (int q = 0; q < 8; ++q) queue[q] = 0;
+            queue[CORR_DONE_SLOT] = 0;
+            queue[CORR_DIRECT_SLOT] = 0;
+            queue[CORR_DIRECT_LAST_SLOT] = nd;   // diagnostics: pixel blocks of this call evaluated directly
+        }
+    }
+}
+
+template <int NPL, int NH>
+hipError_t launch_inst(const SweepArgs& a, const float4* packed, const float* mu_tab, int* queue, int tiles_x, int tiles, hipStream_t stream) {
+    auto kern = sweep_corr_kernel<NPL, NH>;
+    // persistent grid: as many workgroups as the chip holds at once (registers and LDS decide: asked once per
+    // instantiation and device), a multiple of 8; fewer when there is less work
+    static int per_cu[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (per_cu[dev] == 0) {
+        int nbk = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, 256, 0) != hipSuccess || nbk <= 0) nbk = 2;
+        per_cu[dev] = nbk > 5 ? 5 : nbk;
+    }
+    long long nblk = ((long long)sweep_device_cus() * per_cu[dev] + 7) & ~7ll;
+    CorrArgs ca;
+    ca.a = a; ca.packed = packed; ca.mu_tab = mu_tab; ca.queue = queue; ca.tiles_x = tiles_x; ca.ntile = tiles;
+    // small problems: one pixel block per item, so that every CU gets work
+    ca.spi = (long long)tiles * a.B < 2 * nblk ? 1 : 4;
+    const long long need = 8ll * ((tiles + 7) / 8) * (4 / ca.spi) * a.B;   // a workgroup per item of the largest XCD band, times 8
+    if (need <= nblk) nblk = need;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, stream, ca);
+    return hipGetLastError();
+}
+
+template <int NPL>
+hipError_t launch_by_npl(int npl, const SweepArgs& a, const float4* packed, const float* mu_tab, int* queue, int tiles_x, int tiles,
+                         hipStream_t stream) {
+    if (npl == NPL)
+        return a.D <= 64 ? launch_inst<NPL, 1>(a, packed, mu_tab, queue, tiles_x, tiles, stream)
+                         : launch_inst<NPL, 2>(a, packed, mu_tab, queue, tiles_x, tiles, stream);
+    if constexpr (NPL > 1) return launch_by_npl<NPL - 1>(npl, a, packed, mu_tab, queue, tiles_x, tiles, stream);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+// shapes the kernel is built for: L2, D <= 128, C <= 72, at most 8 source views (one instantiation per ceil(C/4): the reference features of a
+// pixel and the texel features of a block live in registers)
+constexpr int CORR_MAX_NPL = 18;
+bool sweep_corr_supports(const SweepArgs& a) {
+    const int npl = (a.C + 3) / 4;
+    const long long hw = (long long)a.H * a.W;
+    return a.metric == 0 && a.D <= 128 && npl <= CORR_MAX_NPL && a.V <= CORR_MAXV && a.W <= 32760 && a.H <= 32760 &&
+           hw * a.D * 4 < (1ll << 31) && hw * a.C * 4 < (1ll << 31) && hw * (npl + 2) * 16 < (1ll << 31) && hw * 12 < (1ll << 31);
+}
+
+// Launches the pre-pass (channel means, then the packed centred source; unless the workspace is already packed) and the
+// sweep kernel.
+hipError_t launch_sweep_corr(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready) {
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 3) / 4, tiles = tiles_x * tiles_y;
+    float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + sweep_ws_flag_bytes(a.B, a.H, a.W));
+    int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + sweep_ws_flag_only_bytes(a.B, a.H, a.W));
+    const float* mu_tab = reinterpret_cast<const float*>(static_cast<char*>(workspace) + sweep_ws_stats_offset(a.B, a.V, a.C, a.H, a.W));
+    if (!packed_ready) {
+        hipError_t e = launch_pack_c4(a, workspace, stream, /*centre=*/true);
+        if (e != hipSuccess) return e;
+    }
+    return launch_by_npl<CORR_MAX_NPL>((a.C + 3) / 4, a, packed, mu_tab, queue, tiles_x, tiles, stream);
+}
+
+}  // namespace pdepth

@@ -300,6 +300,9 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
         }
         __syncthreads();
     }
+    // (the pre-pass found channel offsets larger than the spread of the features: the correlation form of the band group would
+    //  cancel -- every plane directly, in the reference's form; sweep_pack.hip)
+    const bool noband = queue[NONCENTRED_SLOT] != 0;
     const int win_lds0 = (int)lds_addr_of(win);
     // work item -> batch item, tile, this lane's pixel
     auto map_item = [&](int item_, int& b_, int& tile_, bool& live_, int& p_) {
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
         int NC = 0, NR = 0;       // block-uniform box size
         int bsh0 = 0, bsh1 = 0;   // per pixel: column offset of box row r (4 bits each, rows 0..7 / 8..15): the box is SHEARED
         int gwx0 = 0, gwy0 = 0, gWC = 0, gWR = 0;  // staged window of the band group
-        if (METRIC == 0) {
+        if (METRIC == 0 && !noband) {
             int t_x0 = 0, t_y0 = 0, t_nc = 0, t_nr = 0, t_wx0 = 0, t_wy0 = 0, t_wc = 0, t_wr = 0, t_sh0 = 0, t_sh1 = 0;
             // one candidate: does the band group [kc, D) fit?  (block-uniform result; contains a barrier for NSUB > 1)
             auto trial = [&](int kc) -> bool {
@@ -1000,141 +1003,6 @@ tile_done:
 
 }  // namespace PDEPTH_VARIANT
 
-#if PDEPTH_NSUB == 1
-// Pre-pass of every call.  NCHW -> channel-group-planar [C/4 + 2][H][W] float4: plane g < C/4 holds channels
-// 4g .. 4g+3 of every texel (channels beyond C are zero) -- what the sweep kernel stages with 16-byte LDS-DMA --
-// and the last two planes hold the Gram terms of the band mode for texel (x, y), with s(.) = 0 outside the image:
-//     plane C/4     : ( <s(x,y),s(x,y)>, <s(x,y),s(x+1,y)>, <s(x,y),s(x,y+1)>, <s(x,y),s(x+1,y+1)> )
-//     plane C/4 + 1 : ( <s(x+1,y),s(x,y+1)>, 0, 0, 0 )
-// One thread per texel, channels in order (sequential fma: deterministic); the neighbours' loads hit L1/L2.
-__global__ __launch_bounds__(256) void pack_c4_kernel(const float* __restrict__ src, long long bstride,
-                                                      long long vstride, int V, int C, int H, int W,
-                                                      float4* __restrict__ out, int* __restrict__ flags, int nflags, SweepArgs pa, int* pick_queue) {
-    const int HW = H * W;
-    // also clears the tile flags of this call (saves a memset launch) -- except the kernel-choice slot, which the first
-    // block writes (cleared or set: pick.hpp)
-    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < nflags; i += gridDim.x * gridDim.y * 256)
-        if (flags + i != pick_queue + PICK_SLOT) flags[i] = 0;
-    if (pick_queue && blockIdx.x == 0 && blockIdx.y == 0) {
-        if (threadIdx.x == 0) pick_queue[PICK_SLOT] = 0;
-        __syncthreads();
-        if (pa.pick != 0) pick_for_launch(pa, pick_queue, threadIdx.x, 256);
-    }
-    // XCD-aware block order (workgroups are dealt round-robin over the 8 XCDs): every XCD packs one contiguous band
-    // of rows, so the row below -- which another block of the same band loads as its own row -- hits that XCD's L2
-    const int nb = gridDim.x, xcd = blockIdx.x & 7, qq = nb >> 3, rr = nb & 7;
-    const int blk = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-    const int pix = blk * 256 + threadIdx.x;
-    if (pix >= HW) return;
-    const int bv = blockIdx.y;
-    const int y = pix / W, x = pix - y * W;
-    const bool hr = x + 1 < W, hd = y + 1 < H;
-    const float* s = src + (size_t)(bv / V) * bstride + (size_t)(bv % V) * vstride + pix;
-    const int ngrp = (C + 3) / 4;
-    float4* o = out + (size_t)bv * (ngrp + 2) * HW + pix;
-    float n = 0.f, h = 0.f, vv = 0.f, d1 = 0.f, d2 = 0.f;
-#pragma unroll 4   // (the loads of four channel groups in flight: -4 % against the rolled loop)
-    for (int g = 0; g < ngrp; ++g) {
-        float c4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = g * 4 + j;
-            float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
-            if (c < C) {  // uniform
-                const float* sc = s + (size_t)c * HW;
-                s00 = sc[0];
-                s01 = hr ? sc[1] : 0.f;
-                s10 = hd ? sc[W] : 0.f;
-                s11 = hr && hd ? sc[W + 1] : 0.f;
-            }
-            c4[j] = s00;
-            n = __builtin_fmaf(s00, s00, n);
-            h = __builtin_fmaf(s00, s01, h);
-            vv = __builtin_fmaf(s00, s10, vv);
-            d1 = __builtin_fmaf(s00, s11, d1);
-            d2 = __builtin_fmaf(s01, s10, d2);
-        }
-        o[(size_t)g * HW] = make_float4(c4[0], c4[1], c4[2], c4[3]);
-    }
-    o[(size_t)ngrp * HW] = make_float4(n, h, vv, d1);
-    o[(size_t)(ngrp + 1) * HW] = make_float4(d2, 0.f, 0.f, 0.f);
-}
-
-
-// Encoder epilogue: what the host model does between its feature encoder and the sweep --
-//     feats = cat(feat, avg_pool2d(rgb, rate))                 models/models.py:518-520, models/packnet.py:355-357
-//     reference view = feats[:, -1], sources = feats[:, :-1]   models/models.py:530-534
-// -- fused with the sweep's pre-pass: ONE pass over the encoder output writes the source views straight into the packed
-// layout (float4 channel groups + Gram planes, as pack_c4_kernel) and the reference view as NCHW [B, Cf+3, H, W].  The
-// concatenated [B, V+1, Cf+3, H, W] tensor is never materialised, and the sweep call that follows runs the packed entry
-// (no pre-pass of its own).  feat [B*(V+1), Cf, H, W]; rgb [B*(V+1), 3, H*rate, W*rate]; view V of every item = reference.
-// avg_pool2d as ATen computes it: window sum in row-major order, then divided by rate^2.
-__global__ __launch_bounds__(256) void pack_views_kernel(const float* __restrict__ feat, const float* __restrict__ rgb, int V, int Cf,
-                                                         int H, int W, int rate, float4* __restrict__ out, float* __restrict__ ref_out,
-                                                         int* __restrict__ flags, int nflags) {
-    const int HW = H * W, C = Cf + 3;
-    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < nflags; i += gridDim.x * gridDim.y * 256) flags[i] = 0;
-    const int nb = gridDim.x, xcd = blockIdx.x & 7, qq = nb >> 3, rr = nb & 7;   // XCD-aware block order, as pack_c4_kernel
-    const int blk = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (blockIdx.x >> 3);
-    const int pix = blk * 256 + threadIdx.x;
-    if (pix >= HW) return;
-    const int bv = blockIdx.y, b = bv / (V + 1), v = bv % (V + 1);
-    const int y = pix / W, x = pix - y * W;
-    const float* f = feat + (size_t)bv * Cf * HW + pix;
-    const int RW = W * rate;
-    const float* im = rgb + (size_t)bv * 3 * (size_t)(H * rate) * RW;
-    const float inv = 1.0f;   // (the divide below is a true division, like ATen's)
-    (void)inv;
-    auto pooled = [&](int c, int py, int px) -> float {   // avg_pool2d(rgb, rate)[c, py, px]
-        const float* p = im + ((size_t)c * (H * rate) + (size_t)py * rate) * RW + (size_t)px * rate;
-        float sum = 0.0f;
-        for (int j = 0; j < rate; ++j)
-            for (int i = 0; i < rate; ++i) sum += p[(size_t)j * RW + i];
-        return sum / (float)(rate * rate);
-    };
-    if (v == V) {   // the reference view: NCHW copy + pooled image
-        float* o = ref_out + (size_t)b * C * HW + pix;
-        for (int c = 0; c < Cf; ++c) o[(size_t)c * HW] = f[(size_t)c * HW];
-        for (int c = 0; c < 3; ++c) o[(size_t)(Cf + c) * HW] = pooled(c, y, x);
-        return;
-    }
-    const bool hr = x + 1 < W, hd = y + 1 < H;
-    const int ngrp = (C + 3) / 4;
-    float4* o = out + (size_t)(b * V + v) * (ngrp + 2) * HW + pix;
-    float n = 0.f, h = 0.f, vv = 0.f, d1 = 0.f, d2 = 0.f;
-    for (int g = 0; g < ngrp; ++g) {
-        float c4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = g * 4 + j;
-            float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
-            if (c < Cf) {
-                const float* sc = f + (size_t)c * HW;
-                s00 = sc[0];
-                s01 = hr ? sc[1] : 0.f;
-                s10 = hd ? sc[W] : 0.f;
-                s11 = hr && hd ? sc[W + 1] : 0.f;
-            } else if (c < C) {
-                s00 = pooled(c - Cf, y, x);
-                s01 = hr ? pooled(c - Cf, y, x + 1) : 0.f;
-                s10 = hd ? pooled(c - Cf, y + 1, x) : 0.f;
-                s11 = hr && hd ? pooled(c - Cf, y + 1, x + 1) : 0.f;
-            }
-            c4[j] = s00;
-            n = __builtin_fmaf(s00, s00, n);
-            h = __builtin_fmaf(s00, s01, h);
-            vv = __builtin_fmaf(s00, s10, vv);
-            d1 = __builtin_fmaf(s00, s11, d1);
-            d2 = __builtin_fmaf(s01, s10, d2);
-        }
-        o[(size_t)g * HW] = make_float4(c4[0], c4[1], c4[2], c4[3]);
-    }
-    o[(size_t)ngrp * HW] = make_float4(n, h, vv, d1);
-    o[(size_t)(ngrp + 1) * HW] = make_float4(d2, 0.f, 0.f, 0.f);
-}
-
-#endif  // PDEPTH_NSUB == 1 (pre-pass kernel)
-
 static size_t tiled_lds_bytes(int D) {
     return (size_t)(NBUF * NTEX_MAX + NBUF * NSUB * 64) * sizeof(float4) + (size_t)NSUB * (D + NPG) * 64 * sizeof(float) +
            (size_t)(D + 2 * (D / 8 + 1)) * sizeof(float);
@@ -1147,44 +1015,9 @@ static size_t tiled_lds_bytes(int D) {
 int sweep_tiled_max_planes() { return 160; }
 #endif
 
-// workspace head: one flag per (batch item, tile), then the 8 work-queue counters (one per XCD)
-static size_t flag_only_bytes(int B, int H, int W) {
-    const size_t tiles = (size_t)((W + TW - 1) / TW) * ((H + TH - 1) / TH);
-    return ((size_t)B * tiles * sizeof(int) + 255) & ~(size_t)255;
-}
-static size_t flag_bytes(int B, int H, int W) { return flag_only_bytes(B, H, W) + 256; }
+static size_t flag_only_bytes(int B, int H, int W) { return sweep_ws_flag_only_bytes(B, H, W); }
+static size_t flag_bytes(int B, int H, int W) { return sweep_ws_flag_bytes(B, H, W); }
 #if PDEPTH_NSUB == 1
-size_t sweep_ws_flag_only_bytes(int B, int H, int W) { return flag_only_bytes(B, H, W); }
-size_t sweep_ws_flag_bytes(int B, int H, int W) { return flag_bytes(B, H, W); }
-size_t sweep_tiled_workspace_bytes(int B, int V, int C, int H, int W) {
-    // flags + queue counters, packed source, then the list of tiles the fast cell-list kernel leaves to the generic one
-    return flag_bytes(B, H, W) + (size_t)B * V * ((C + 3) / 4 + 2) * H * W * sizeof(float4) + flag_only_bytes(B, H, W);
-}
-
-// pre-pass of a call: packed source + Gram planes, tile flags and queue counters cleared
-hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t stream) {
-    int* flags = reinterpret_cast<int*>(workspace);
-    float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + flag_bytes(a.B, a.H, a.W));
-    const int HW = a.H * a.W;
-    dim3 pgrid((HW + 255) / 256, a.B * a.V);
-    int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + flag_only_bytes(a.B, a.H, a.W));
-    hipLaunchKernelGGL(pack_c4_kernel, pgrid, dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V, a.C, a.H, a.W, packed,
-                       flags, (int)(flag_bytes(a.B, a.H, a.W) / sizeof(int)), a, queue);
-    return hipGetLastError();
-}
-
-// the encoder epilogue (pack_views_kernel): a.C = Cf + 3, a.V source views, views V+1 per item in feat / rgb
-hipError_t launch_pack_views(const SweepArgs& a, const float* feat, const float* rgb, int rate, float* ref_out, void* workspace,
-                             hipStream_t stream) {
-    int* flags = reinterpret_cast<int*>(workspace);
-    float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + flag_bytes(a.B, a.H, a.W));
-    const int HW = a.H * a.W;
-    dim3 pgrid((HW + 255) / 256, a.B * (a.V + 1));
-    hipLaunchKernelGGL(pack_views_kernel, pgrid, dim3(256), 0, stream, feat, rgb, a.V, a.C - 3, a.H, a.W, rate, packed, ref_out, flags,
-                       (int)(flag_bytes(a.B, a.H, a.W) / sizeof(int)));
-    return hipGetLastError();
-}
-
 // Two tiles per block pay off when two such blocks fit a CU (the cost tiles of both sub-tiles live in LDS: D <= 64)
 // and the image is large enough for the wider windows not to dominate; measured on the BASELINE configurations.
 // (PDEPTH_ALGO_TILED_1 / _2 force a variant.)
@@ -1193,40 +1026,6 @@ hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t s
     return two ? launch_sweep_tiled_n2(a, workspace, stream, packed_ready, phases) : launch_sweep_tiled_n1(a, workspace, stream, packed_ready, phases);
 }
 
-// flag clear of a call on an already packed source when the kernel is chosen on the device (else: a memset)
-__global__ __launch_bounds__(256) void clear_and_pick_kernel(SweepArgs pa, int* flags, int nflags, int* queue) {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nflags; i += gridDim.x * 256)
-        if (flags + i != queue + PICK_SLOT) flags[i] = 0;
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0) queue[PICK_SLOT] = 0;
-        __syncthreads();
-        pick_for_launch(pa, queue, threadIdx.x, 256);
-    }
-}
-
-// The pre-pass also clears the tile flags and queue counters; a call on an already packed source clears them itself.
-hipError_t clear_sweep_flags(const SweepArgs& a, void* workspace, hipStream_t stream) {
-    if (a.pick != 0) {
-        int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + flag_only_bytes(a.B, a.H, a.W));
-        const int nflags = (int)(flag_bytes(a.B, a.H, a.W) / sizeof(int));
-        hipLaunchKernelGGL(clear_and_pick_kernel, dim3((nflags + 2047) / 2048), dim3(256), 0, stream, a, reinterpret_cast<int*>(workspace), nflags, queue);
-        return hipGetLastError();
-    }
-    return hipMemsetAsync(workspace, 0, flag_bytes(a.B, a.H, a.W), stream);
-}
-
-// CU count of the current device (cached per device)
-int sweep_device_cus() {
-    static int cus[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (cus[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus[dev] = n;
-    }
-    return cus[dev];
-}
 #endif
 
 // Launches the pre-pass, this variant's tiled kernel, then the gather kernel on the tiles it flagged.
@@ -1243,7 +1042,7 @@ hipError_t PDEPTH_CAT(launch_sweep_tiled_n, PDEPTH_NSUB)(const SweepArgs& a, voi
     int* flags = reinterpret_cast<int*>(workspace);
     float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + flag_bytes(a.B, a.H, a.W));
     hipError_t e = hipSuccess;
-    if (phases & PH_PRE) e = packed_ready ? clear_sweep_flags(a, workspace, stream) : launch_pack_c4(a, workspace, stream);
+    if (phases & PH_PRE) e = packed_ready ? clear_sweep_flags(a, workspace, stream) : launch_pack_c4(a, workspace, stream, /*centre=*/false);
     if (e != hipSuccess) return e;
     const size_t lds = tiled_lds_bytes(a.D);
     int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + flag_only_bytes(a.B, a.H, a.W));

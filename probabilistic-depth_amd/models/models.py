@@ -298,8 +298,8 @@ class BaseModel(nn.Module):
             try:
                 packed, ref = ops.pack_views(feat.float(), flat.float(), V1, self.D)
                 feats = _SweepFeatures(per_view(feat), packed, ref)
-            except RuntimeError:   # a shape the packed sweep does not take: the concatenated tensor below
-                feats = None
+            except ops.UnsupportedShape:   # a shape the packed sweep does not take: the concatenated tensor below
+                feats = None       # (any other failure of the native call -- launch error, out of memory -- propagates)
         if feats is None:
             rate = int(flat.shape[3] / feat.shape[3])
             feats = per_view(torch.cat((feat, F.avg_pool2d(flat, rate)), dim=1))  # [B, V1, C+3, h, w]  (models.py:518-520)

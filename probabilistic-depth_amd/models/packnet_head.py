@@ -45,9 +45,10 @@ class PacknetHead(nn.Module):
             rgb = model_input["rgb"]
             B, V1 = rgb.shape[0], rgb.shape[1]
             flat = rgb.reshape(B * V1, rgb.shape[2], rgb.shape[3], rgb.shape[4])
+            enc = self.encoder(flat).float()   # (outside the try: an encoder failure is not a reason to run it twice)
             try:
-                src, ref = ops.pack_views(self.encoder(flat).float(), flat.float(), V1, len(model_input["d_candi"]))
-            except RuntimeError:
+                src, ref = ops.pack_views(enc, flat.float(), V1, len(model_input["d_candi"]))
+            except ops.UnsupportedShape:   # a shape the packed sweep does not take; other native failures propagate
                 src = ref = None
         if src is None:
             if feat_imgs_all is None:
@@ -56,7 +57,7 @@ class PacknetHead(nn.Module):
             if self.sweep_algo == "auto":   # precomputed features: re-laid once, then the packed entry
                 try:
                     src = ops.pack_source(src, len(model_input["d_candi"]))
-                except RuntimeError:
+                except ops.UnsupportedShape:
                     pass
         poses = model_input["src_cam_poses"].float()
         K = model_input["intrinsics"].float()

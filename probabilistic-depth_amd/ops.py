@@ -13,7 +13,7 @@ from . import _native
 METRICS = {"L2": _native.METRIC_L2, "L1": _native.METRIC_L1}
 # "tiled1" / "tiled2" / "cells" force one of the implementations behind "auto" (parity tests, A/B timing)
 ALGOS = {"auto": _native.ALGO_AUTO, "direct": _native.ALGO_DIRECT, "tiled1": _native.ALGO_TILED_1,
-         "tiled2": _native.ALGO_TILED_2, "cells": _native.ALGO_CELLS, "mfma": _native.ALGO_MFMA}
+         "tiled2": _native.ALGO_TILED_2, "cells": _native.ALGO_CELLS, "mfma": _native.ALGO_MFMA, "corr": _native.ALGO_CORR}
 BLAS_MODES = {"fma": _native.BLAS_FMA, "separate": _native.BLAS_SEPARATE, None: None}
 
 
@@ -69,16 +69,20 @@ def sweep_dpv(ref, src, K, R, t, rays, cxcy, d_candi, sigma, feat_dist="L2", alg
                          want_depth=want_depth, blas_mode=BLAS_MODES[blas])
 
 
-def pack_source(src, n_planes=64):
+UnsupportedShape = _native.UnsupportedShape
+
+
+def pack_source(src, n_planes=64, algo="auto"):
     """Source views [B,V,C,H,W] -> the sweep kernels' staging layout, once (pdepth_pack_source_f32); pass the result as
-    `src` to sweep_cost / sweep_dpv.  The re-layout is 10 % of a fused sweep call."""
-    return _native.pack_source(src, n_planes)
+    `src` to sweep_cost / sweep_dpv with the same algo.  The re-layout is 10 % of a fused sweep call.  Raises
+    UnsupportedShape for shapes the packed sweep does not take."""
+    return _native.pack_source(src, n_planes, ALGOS[algo])
 
 
 def pack_views(feat, rgb, n_views, n_planes=64):
     """Encoder epilogue: cat(feat, avg_pool2d(rgb)) -> (packed source views, NCHW reference view) in one pass
     (pdepth_pack_views_f32; models/models.py:518-534).  Pass the PackedSource as `src` and the tensor as `ref` to
-    sweep_cost / sweep_dpv."""
+    sweep_cost / sweep_dpv.  Raises UnsupportedShape for shapes the packed sweep does not take (callers use cat + avg_pool2d)."""
     return _native.pack_views(feat, rgb, n_views, n_planes)
 
 
