@@ -70,6 +70,14 @@ constexpr int SL_BORDER = SL_XLO | SL_XHI | SL_YLO | SL_YHI;
 __device__ __forceinline__ int opaque_v(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
 
+// Diagnostic build only (-DCORR_STAMPS, tools/dbg/corr_stamps.py): time per phase in 10 ns ticks, summed over waves, in the spare
+// ints behind the queue counters.  No stamp exists in the product build.
+#ifdef CORR_STAMPS
+#define CSTAMP(idx) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); stamp_acc[idx] += now_ - stamp_t; stamp_t = now_; }
+#else
+#define CSTAMP(idx)
+#endif
+
 // every earlier LDS operation of this wave is done (LDS operations of one wave complete in order)
 #define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 // workgroup barrier that waits for this wave's LDS traffic only: global loads and stores stay in flight
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
     bool own_done = false;
     auto steal = [&]() -> int {   // (queue << 28) | index in the queue, or -1: every queue is exhausted
         int* queue = KARG(int*, queue);
-        const int mB = (4 / KARG(int, spi)) * KARG(int, a.B);
+        const int mB = (4 / ca.spi) * KARG(int, a.B);
         for (int j = 1; j < 8; ++j) {
             const int q = (xcd + j) & 7, nq = band_tiles_of(q) * mB;
             if (*(volatile int*)&queue[q] >= nq) continue;
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
         return -1;
     };
     auto resolve = [&](int got) -> int {
-        const int n_own = band_tiles_of(xcd) * (4 / KARG(int, spi)) * KARG(int, a.B);
+        const int n_own = band_tiles_of(xcd) * (4 / ca.spi) * KARG(int, a.B);
         if (!own_done && got < n_own) return (xcd << 28) | got;
         own_done = true;
         return steal();
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
     // floor(nn / dd) for 0 <= nn < 2^22, 0 < dd (an integer divide costs ~40 dependent instructions)
     auto fdiv = [](int nn, int dd) { return (int)(((float)nn + 0.5f) * __builtin_amdgcn_rcpf((float)dd)); };
     auto decode = [&](int item, int& b_, int& tx_, int& ty_, int& sub0_) {
-        const int ntile = KARG(int, ntile), tiles_x = KARG(int, tiles_x), spi = KARG(int, spi);
+        const int ntile = KARG(int, ntile), tiles_x = KARG(int, tiles_x), spi = ca.spi;
         const int m = 4 / spi, msh = spi == 1 ? 2 : 0, qq = ntile >> 3, rr8 = ntile & 7;
         const bool small_idx = (long long)ntile * m * KARG(int, a.B) < (1ll << 22);
         const int tiles_y_ = (H + 3) / 4;
@@ -292,8 +300,12 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
         tx_ = tile - ty_ * tiles_x;
     };
     // (when the grid covers every item -- small problems -- workgroup i takes item i of its XCD's band: no atomics)
-    const bool one_each = (long long)gridDim.x >= 8ll * ((KARG(int, ntile) + 7) / 8) * (4 / KARG(int, spi)) * KARG(int, a.B);
+    const bool one_each = (long long)gridDim.x >= 8ll * ((KARG(int, ntile) + 7) / 8) * (4 / ca.spi) * KARG(int, a.B);
     __syncthreads();
+#ifdef CORR_STAMPS
+    unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t = __builtin_amdgcn_s_memrealtime();
+#endif
     int slot_par = 0;
     int pt = 0;           // running pass counter: selects the set of row-table arrays
     int n_direct = 0;     // (thread 0) pixel blocks evaluated directly
@@ -303,7 +315,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
 
     for (;;) {
         if (tid == 0) {
-            const int n_own = band_tiles_of(xcd) * (4 / KARG(int, spi)) * KARG(int, a.B);
+            const int n_own = band_tiles_of(xcd) * (4 / ca.spi) * KARG(int, a.B);
             L.item[slot_par] = one_each ? (first && got_own < n_own ? (xcd << 28) | got_own : -1) : resolve(got_own);
         }
         first = false;
@@ -312,14 +324,15 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
         slot_par ^= 1;
         if (item < 0) break;
         if (tid == 0 && !one_each && !own_done) got_own = atomicAdd(&KARG(int*, queue)[xcd], 1);
+        CSTAMP(0)   // queue: publish + barrier
         int b, tx, ty, sub0;
         decode(item, b, tx, ty, sub0);
         // per item, for every wave: channel means, the views' homography terms, the camera constants (visible behind the
         // barrier in front of the first block's centring)
-        if (tid < 72) L.mu[tid] = KARG(const float*, mu_tab)[b * STATS_STRIDE + tid];
+        if (tid < 72) L.mu[tid] = ca.mu_tab[b * STATS_STRIDE + tid];
         else if (tid < 80 && tid != 72) L.mu[tid] = 0.0f;
         if (wave == 1) {   // |mu|^2
-            const float* mt = KARG(const float*, mu_tab) + b * STATS_STRIDE;
+            const float* mt = ca.mu_tab + b * STATS_STRIDE;
             float m2 = 0.0f;
             if (lane < 36) { const float u0 = mt[lane], u1 = mt[lane + 36]; m2 = __builtin_fmaf(u0, u0, u1 * u1); }
 #pragma unroll
@@ -330,7 +343,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
             const int v = tid - 128;
             ViewXform xf;
             make_view_xform(KARG(const float*, a.K) + b * 9, KARG(const float*, a.R) + ((size_t)b * V + v) * 9,
-                            KARG(const float*, a.t) + ((size_t)b * V + v) * 3, KARG(int, a.blas_mode), xf);
+                            KARG(const float*, a.t) + ((size_t)b * V + v) * 3, ca.a.blas_mode, xf);
 #pragma unroll
             for (int i = 0; i < 9; ++i) L.xf[v * 12 + i] = xf.kr[i];
 #pragma unroll
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
         }
         const bool wide = b < 64 ? L.wide[b] != 0 : false;
         bool item_ready = false;
-        const int spi = KARG(int, spi);
+        const int spi = ca.spi;
 
         for (int sub = sub0; sub < sub0 + spi; ++sub) {
             if ((wide ? ty * 4 + sub : ty * 4 + 2 * (sub >> 1)) >= H) continue;   // the block lies below the image (uniform)
@@ -363,18 +376,18 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
             float ray[3], rv[MCH];
             {
                 const __amdgpu_buffer_rsrc_t rray =
-                    __builtin_amdgcn_make_buffer_rsrc((void*)(KARG(const float*, a.rays) + (size_t)b * 3 * HW), 0, 3 * HW * 4, 0x00020000);
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(ca.a.rays + (size_t)b * 3 * HW), 0, 3 * HW * 4, 0x00020000);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) ray[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rray, p * 4, i * HW * 4, 0));
                 const __amdgpu_buffer_rsrc_t rref =
-                    __builtin_amdgcn_make_buffer_rsrc((void*)(KARG(const float*, a.ref) + (size_t)b * KARG(long long, a.ref_bstride)), 0,
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(ca.a.ref + (size_t)b * ca.a.ref_bstride), 0,
                                                       C * HW * 4, 0x00020000);
 #pragma unroll
                 for (int mm = 0; mm < MCH; ++mm)
                     rv[mm] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                         rref, tq + 16 * mm < C ? (tq * HW + p) * 4 : OOB, 16 * mm * HW * 4, 0));
             }
-            float Rr[NPL];                 // the pixels' centred reference features, the B operands of every MFMA of the block
+            CSTAMP(1)   // item set-up, pixel loads issued
             float rr = 0.0f, rho = 0.0f;   // |r'|^2 and <r', mu> of the pixel (set with the first pass)
             bool centred = false;
             bool failed = false;           // uniform over the workgroup: some pass of the block did not fit the row tables
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
             for (int j = 0; j < NC; ++j) cost[j] = 0.0f;
 
             for (int v = 0; v < V; ++v) {
-                const float4* srcv = KARG(const float4*, packed) + ((size_t)b * V + v) * (NPL + 2) * HW;
+                const float4* srcv = ca.packed + ((size_t)b * V + v) * (NPL + 2) * HW;
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)srcv, 0, (NPL + 2) * HW * 16, 0x00020000);
 
 #pragma unroll
@@ -403,7 +416,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                                       k2 = *reinterpret_cast<const v4f*>(&L.xf[v * 12 + 8]);
                             xf.kr[0] = k0.x; xf.kr[1] = k0.y; xf.kr[2] = k0.z; xf.kr[3] = k0.w; xf.kr[4] = k1.x; xf.kr[5] = k1.y;
                             xf.kr[6] = k1.z; xf.kr[7] = k1.w; xf.kr[8] = k2.x; xf.kt[0] = k2.y; xf.kt[1] = k2.z; xf.kt[2] = k2.w;
-                            xf.separate = KARG(int, a.blas_mode);
+                            xf.separate = ca.a.blas_mode;
                             ray_term2(xf, ray[0], ray[1], ray[2], t2a, t2b, t2c);
                         }
                         const v4f c0 = *reinterpret_cast<const v4f*>(&L.cst[0]);
@@ -419,6 +432,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                             if (k + 1 >= D || !xlive) cell[j + 1] = NO_CELL;
                         }
                     }
+                    CSTAMP(2)   // (wait for the ray) sample positions
                     // ---- row table: contributions of this thread's planes --------------------------------------------------
                     {
                         int lmin = INT_MAX, lmax = INT_MIN;
@@ -460,7 +474,9 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                         ph = ph + __shfl_xor(ph, 16); ph = ph + __shfl_xor(ph, 32);
                         if (kq == 0) *reinterpret_cast<v2f*>(&L.rp[(wave * 16 + n) * 2]) = v2f{pr, ph};
                     }
+                    CSTAMP(3)   // table atomics, (wait for the reference features) centring
                     LDS_BARRIER();
+                    CSTAMP(4)   // barrier: tables complete
                     const int ybase = __builtin_amdgcn_readfirstlane(L.ired[par][0]), ytop = __builtin_amdgcn_readfirstlane(L.ired[par][1]);
                     int nb = 0;
                     bool fits = true;
@@ -490,36 +506,12 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                             }
                         }
                     }
-                    // the two X / Gram slots of this thread's planes and the border flags of their cells, one register each
-                    int sl[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        sl[j] = 0;
-                        if (fits && cell[j] != NO_CELL) {
-                            const int cyy = cell_y(cell[j]), cxx = cell_x(cell[j]), r = cyy - ybase;
-                            sl[j] = (cxx + L.rowoff[r]) | ((cxx + L.rowoff[r + 1]) << SL_BITS) | SL_VALID | (cxx < 0 ? SL_XLO : 0) |
-                                    (cxx >= W - 1 ? SL_XHI : 0) | (cyy < 0 ? SL_YLO : 0) | (cyy >= H - 1 ? SL_YHI : 0);
-                        }
-                    }
-                    if (!centred) {
-                        // the block's reference features from LDS, as lane (n, kq) feeds them to the matrix pipe
-#pragma unroll
-                        for (int g = 0; g < NCH; ++g) {
-                            const v4f r4 = *reinterpret_cast<const v4f*>(&L.Rs[((g * 4 + kq) * 16 + n) * 4]);
-                            Rr[4 * g + 0] = r4.x; Rr[4 * g + 1] = r4.y; Rr[4 * g + 2] = r4.z; Rr[4 * g + 3] = r4.w;
-                        }
-#pragma unroll
-                        for (int tp = 0; tp < NTL; ++tp) Rr[4 * NCH + tp] = L.Rs[Lds::RS_TAIL + (tp * 4 + kq) * 16 + n];
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) {
-                            const v2f pp = *reinterpret_cast<const v2f*>(&L.rp[(w * 16 + n) * 2]);
-                            rr = rr + pp.x; rho = rho + pp.y;
-                        }
-                        centred = true;
-                    }
-
+                    CSTAMP(5)   // scan
                     // ---- X' = <r', s'> for the blocks of the pass, on the matrix pipe ---------------------------------------
-                    if (fits && nb > 0) {
+                    const bool go = fits && nb > 0;
+                    int sl[4];
+                    {
+                        float Rr[NPL];
                         const int myblk = L.blk[min(lane, MAXB + BLK_PAD - 1)];   // the block list in a register: entry l in lane l
                         // Gram records (N, H, V, D1 + D2) and <s', mu> of the pass's slots (texel = slot of a block), straight
                         // from the packed source into LDS: wave w moves slots 64 c .. 64 c + 63 for c = w, w + 4, ...
@@ -552,7 +544,11 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                             const int be = __builtin_amdgcn_readlane(myblk, bi);
                             const int yy = be >> 16, xx = (int)(short)(be & 0xffff) + n;
                             const bool ok = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
+#ifdef CORR_ABL_ROWWRAP   // timing experiment (results wrong): every texel load from 8 source rows -- an L2-resident source
+                            const int t16 = ((yy & 7) * W + xx) * 16;
+#else
                             const int t16 = (yy * W + xx) * 16;
+#endif
                             vo = opaque_v(ok ? t16 + kq * HW * 16 : OOB);   // (opaque: one load with a selected offset, no branch)
                             if (NTL > 0) vt = opaque_v(ok ? t16 + kq * 4 : OOB);
                         };
@@ -595,11 +591,39 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                                 else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(TB[tp], Rr[4 * NCH + tp], acc0, 0, 0, 0);
                             }
                         };
+                        // the first block's loads and the Gram records are in flight while the slots are looked up
+                        if (go) { prep(wave); load_a(); load_b(); }
+                        // the two X / Gram slots of this thread's planes and the border flags of their cells, one register each
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            sl[j] = 0;
+                            if (fits && cell[j] != NO_CELL) {
+                                const int cyy = cell_y(cell[j]), cxx = cell_x(cell[j]), r = cyy - ybase;
+                                sl[j] = (cxx + L.rowoff[r]) | ((cxx + L.rowoff[r + 1]) << SL_BITS) | SL_VALID | (cxx < 0 ? SL_XLO : 0) |
+                                        (cxx >= W - 1 ? SL_XHI : 0) | (cyy < 0 ? SL_YLO : 0) | (cyy >= H - 1 ? SL_YHI : 0);
+                            }
+                        }
+                        // the block's reference features from LDS, as lane (n, kq) feeds them to the matrix pipe (every pass anew: they
+                        // would otherwise occupy registers through the vector phases of every further view)
+#pragma unroll
+                        for (int g = 0; g < NCH; ++g) {
+                            const v4f r4 = *reinterpret_cast<const v4f*>(&L.Rs[((g * 4 + kq) * 16 + n) * 4]);
+                            Rr[4 * g + 0] = r4.x; Rr[4 * g + 1] = r4.y; Rr[4 * g + 2] = r4.z; Rr[4 * g + 3] = r4.w;
+                        }
+#pragma unroll
+                        for (int tp = 0; tp < NTL; ++tp) Rr[4 * NCH + tp] = L.Rs[Lds::RS_TAIL + (tp * 4 + kq) * 16 + n];
+                        if (!centred) {
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) {
+                                const v2f pp = *reinterpret_cast<const v2f*>(&L.rp[(w * 16 + n) * 2]);
+                                rr = rr + pp.x; rho = rho + pp.y;
+                            }
+                            centred = true;
+                        }
+
+                        if (go) {
                         // wave w: blocks w, w + 4, ... (unrolled with forward exits; loads beyond the list hit the empty entries behind
                         // it and fetch nothing)
-                        prep(wave);
-                        load_a();
-                        load_b();
 #pragma unroll
                         for (int i = 0; i < BPW; ++i) {
                             const int bi = wave + 4 * i;
@@ -612,13 +636,17 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                             if (i + 1 < BPW) load_b();
                             *reinterpret_cast<v4f*>(&L.Xs[n * XSTRIDE + 16 * bi + 4 * kq]) = acc0 + acc1;   // X[texel][pixel] of the block
                         }
+                        CSTAMP(6)   // X: loads + multiplications
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's Gram records have landed in LDS
+                        }
                     }
+                    CSTAMP(7)   // wait for the Gram records
                     LDS_BARRIER();   // X and the Gram records of the pass are complete (or: every wave has seen that it does not fit)
                     if (tid < 64) { L.cmin[par][tid] = INT_MAX; L.cmax[par][tid] = INT_MIN; }   // (this pass's tables are dead)
                     if (tid == 0) { L.ired[par][0] = INT_MAX; L.ired[par][1] = INT_MIN; }
                     ++pt;
                     failed = failed || !fits;
+                    CSTAMP(8)   // barrier: X complete
 
                     // ---- combine: cost of this thread's planes of the pass ------------------------------------------------
                     if (fits) {
@@ -664,6 +692,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                 }
             }
 
+            CSTAMP(9)   // combine
             if (failed) {
                 // ---- the geometry of some pass does not fit the row tables (extreme poses): the whole block directly, in the
                 //      reference's form on the centred features
@@ -671,17 +700,17 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                 const v4f c0 = *reinterpret_cast<const v4f*>(&L.cst[0]), c1 = *reinterpret_cast<const v4f*>(&L.cst[4]);
 #pragma unroll
                 for (int j = 0; j < NC; ++j) cost[j] = 0.0f;
-                const float* refp = KARG(const float*, a.ref) + (size_t)b * KARG(long long, a.ref_bstride) + p;
+                const float* refp = ca.a.ref + (size_t)b * ca.a.ref_bstride + p;
                 for (int v = 0; v < V; ++v) {
                     ViewXform xf;
 #pragma unroll
                     for (int i = 0; i < 9; ++i) xf.kr[i] = L.xf[v * 12 + i];
 #pragma unroll
                     for (int i = 0; i < 3; ++i) xf.kt[i] = L.xf[v * 12 + 9 + i];
-                    xf.separate = KARG(int, a.blas_mode);
+                    xf.separate = ca.a.blas_mode;
                     float t2a, t2b, t2c;
                     ray_term2(xf, ray[0], ray[1], ray[2], t2a, t2b, t2c);
-                    const float* srcf = reinterpret_cast<const float*>(KARG(const float4*, packed) + ((size_t)b * V + v) * (NPL + 2) * HW);
+                    const float* srcf = reinterpret_cast<const float*>(ca.packed + ((size_t)b * V + v) * (NPL + 2) * HW);
 #pragma unroll
                     for (int j = 0; j < NC; ++j) {
                         const int k = 64 * (j >> 2) + 4 * tq + (j & 3);
@@ -719,9 +748,9 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
             // ---- epilogue: cost store, log-softmax over D, expectation ----------------------------------------------------
             // (buffer stores: one 32-bit lane offset, the plane as the scalar offset: plane 64 h + 16 wave + 4 kq + j)
             const int ovoff = xlive ? (4 * kq * HW + p) * 4 : OOB;
-            float* const cost_out = KARG(float*, a.cost_out);
-            float* const logp_out = KARG(float*, a.logp_out);
-            float* const depth_out = KARG(float*, a.depth_out);
+            float* const cost_out = ca.a.cost_out;
+            float* const logp_out = ca.a.logp_out;
+            float* const depth_out = ca.a.depth_out;
             if (cost_out) {
                 const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(cost_out + (size_t)b * D * HW), 0, D * HW * 4, 0x00020000);
 #pragma unroll
@@ -747,6 +776,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                 ssum = ssum + __shfl_xor(ssum, 16); ssum = ssum + __shfl_xor(ssum, 32);
                 esum = esum + __shfl_xor(esum, 16); esum = esum + __shfl_xor(esum, 32);
                 if (kq == 0) *reinterpret_cast<v4f*>(&L.red[(wave * 16 + n) * 4]) = v4f{mx, ssum, esum, 0.0f};
+                CSTAMP(10)   // epilogue: stores, partial softmax
                 LDS_BARRIER();
                 float M = -INFINITY;
 #pragma unroll
@@ -770,8 +800,13 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                 }
                 if (depth_out && xlive && tq == 0) depth_out[(size_t)b * HW + p] = E / S;
             }
+            CSTAMP(11)   // barrier + merge + stores
         }   // pixel blocks of the item
     }   // items
+#ifdef CORR_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(int*, queue) + 16) + i, stamp_acc[i]);
+#endif
 
     // the last workgroup to leave zeroes the queue counters: the next call on this workspace needs no clearing launch
     if (tid == 0) {

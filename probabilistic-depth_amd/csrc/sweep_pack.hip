@@ -164,25 +164,30 @@ __global__ __launch_bounds__(256) void pack_c4_kernel(const float* __restrict__ 
     const int ngrp = (C + 3) / 4;
     float4* o = out + (size_t)bv * (ngrp + 2) * HW + pix;
     float n = 0.f, h = 0.f, vv = 0.f, d1 = 0.f, d2 = 0.f, mm = 0.f;
+    // (branch-free: the neighbours beyond the image are loaded from the texel itself and then dropped)
     const int i01 = hr ? 1 : 0, i10 = hd ? W : 0;
-#pragma unroll 4   // (the loads of four channel groups in flight: -4 % against the rolled loop)
-    for (int g = 0; g < ngrp; ++g) {
+    // a channel group = 16 loads (4 channels x the texel and its three neighbours); the next group's loads are issued before
+    // the current one is used, so that 32 loads per thread are in flight (the kernel is a stream: latency is all that it
+    // can lose -- the compiler's own schedule waits for every channel's loads before it issues the next channel's)
+    auto issue = [&](int g, float(&v)[16]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = g * 4 + j;
+            const float* sc = s + (size_t)min(c, C - 1) * HW;   // (channels beyond C: loaded from the last one, dropped below)
+            v[4 * j + 0] = sc[0]; v[4 * j + 1] = sc[i01]; v[4 * j + 2] = sc[i10]; v[4 * j + 3] = sc[i01 + i10];
+        }
+    };
+    auto finish = [&](int g, const float(&v)[16]) {
         float c4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = g * 4 + j;
-            float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
-            const float u = CENTRE ? mu[c] : 0.0f;   // (channels beyond C: 0, sweep_pack's statistics kernels pad with zeros)
-            if (c < C) {  // uniform
-                // (branch-free: the neighbours beyond the image are loaded from the texel itself and then dropped, so that the
-                //  loads of several channels are in flight together)
-                const float* sc = s + (size_t)c * HW;
-                const float v00 = sc[0], v01 = sc[i01], v10 = sc[i10], v11 = sc[i01 + i10];
-                s00 = v00 - u;
-                s01 = hr ? v01 - u : 0.f;
-                s10 = hd ? v10 - u : 0.f;
-                s11 = hr && hd ? v11 - u : 0.f;
-            }
+            const float u = CENTRE ? mu[c] : 0.0f;   // (channels beyond C: 0, the statistics kernels pad with zeros)
+            const bool in = c < C;   // uniform
+            const float s00 = in ? v[4 * j + 0] - u : 0.f;
+            const float s01 = in && hr ? v[4 * j + 1] - u : 0.f;
+            const float s10 = in && hd ? v[4 * j + 2] - u : 0.f;
+            const float s11 = in && hr && hd ? v[4 * j + 3] - u : 0.f;
             c4[j] = s00;
             n = __builtin_fmaf(s00, s00, n);
             h = __builtin_fmaf(s00, s01, h);
@@ -192,6 +197,18 @@ __global__ __launch_bounds__(256) void pack_c4_kernel(const float* __restrict__ 
             mm = __builtin_fmaf(s00, u, mm);
         }
         o[(size_t)g * HW] = make_float4(c4[0], c4[1], c4[2], c4[3]);
+    };
+    float va[16], vb[16];
+    issue(0, va);
+    for (int g = 0; g < ngrp; g += 2) {
+        if (g + 1 < ngrp) issue(g + 1, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(g, va);
+        if (g + 1 < ngrp) {
+            if (g + 2 < ngrp) issue(g + 2, va);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(g + 1, vb);
+        }
     }
     o[(size_t)ngrp * HW] = make_float4(n, h, vv, d1 + d2);
     o[(size_t)(ngrp + 1) * HW] = make_float4(mm, 0.f, 0.f, 0.f);
