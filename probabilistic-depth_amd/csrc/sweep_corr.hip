@@ -54,6 +54,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef CORR_OCC2
 #define CORR_OCC2 3
 #endif
+#ifndef CORR_PREFETCH_PIXEL   // the next block's pixel loads under the epilogue
+#define CORR_PREFETCH_PIXEL 0
+#endif
 #ifndef CORR_MAXB1   // blocks of 16 texels a pass can take, D <= 64 (LDS: 4 workgroups per CU)
 #define CORR_MAXB1 23
 #endif
@@ -357,6 +360,8 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
         }
         const bool wide = b < 64 ? L.wide[b] != 0 : false;
         bool item_ready = false;
+        float ray[3], rv[MCH];
+        bool loaded = false;   // ray / rv hold the loads of the block about to be processed
         const int spi = ca.spi;
 
         for (int sub = sub0; sub < sub0 + spi; ++sub) {
@@ -365,28 +370,31 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
             // matrix phase lane (n, kq) of a wave feeds texel / pixel n and channel slice kq.  (opaque: the optimiser
             // otherwise hoists every lane-derived invariant of the phases -- masks, LDS addresses, offsets -- to the top of
             // the kernel and spills them)
-            const int n = opaque_v(lane & 15), kq = opaque_v(lane >> 4), tq = wave * 4 + kq;
+            const int tid = opaque_v((int)threadIdx.x), lane = tid & 63;   // (shadow the kernel's: re-derived per pixel block)
+            const int n = lane & 15, kq = lane >> 4, tq = wave * 4 + kq;
             const int HW = opaque_s(H * W);
             const int x = wide ? tx * 16 + n : tx * 16 + 8 * (sub & 1) + (n & 7);
             const int y = wide ? ty * 4 + sub : ty * 4 + 2 * (sub >> 1) + (n >> 3);
             const bool xlive = x < W && y < H;
             const int p = min(y, H - 1) * W + min(x, W - 1);
             // the pixel's ray, and this thread's share of the block's reference features: channels tq, tq + 16, ... of pixel n
-            // (buffer loads: 32-bit offsets, the channel as the scalar offset; channels beyond C = 0)
-            float ray[3], rv[MCH];
-            {
+            // (buffer loads: 32-bit offsets, the channel as the scalar offset; channels beyond C = 0).  Issued here for the first
+            // block of an item, for the others under the previous block's epilogue.
+            auto issue_pixel_loads = [&](int p_) {
                 const __amdgpu_buffer_rsrc_t rray =
                     __builtin_amdgcn_make_buffer_rsrc((void*)(ca.a.rays + (size_t)b * 3 * HW), 0, 3 * HW * 4, 0x00020000);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) ray[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rray, p * 4, i * HW * 4, 0));
+                for (int i = 0; i < 3; ++i) ray[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rray, p_ * 4, i * HW * 4, 0));
                 const __amdgpu_buffer_rsrc_t rref =
                     __builtin_amdgcn_make_buffer_rsrc((void*)(ca.a.ref + (size_t)b * ca.a.ref_bstride), 0,
                                                       C * HW * 4, 0x00020000);
 #pragma unroll
                 for (int mm = 0; mm < MCH; ++mm)
                     rv[mm] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rref, tq + 16 * mm < C ? (tq * HW + p) * 4 : OOB, 16 * mm * HW * 4, 0));
-            }
+                        rref, tq + 16 * mm < C ? (tq * HW + p_) * 4 : OOB, 16 * mm * HW * 4, 0));
+            };
+            if (!loaded) issue_pixel_loads(p);
+            loaded = false;
             CSTAMP(1)   // item set-up, pixel loads issued
             float rr = 0.0f, rho = 0.0f;   // |r'|^2 and <r', mu> of the pixel (set with the first pass)
             bool centred = false;
@@ -431,6 +439,9 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                             if (k >= D || !xlive) cell[j] = NO_CELL;
                             if (k + 1 >= D || !xlive) cell[j + 1] = NO_CELL;
                         }
+                        // (pinned: the optimiser otherwise carries the positions AND their floors to the combine instead of the fractions)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(fw[j])); asm volatile("" : "+v"(fn[j])); }
                     }
                     CSTAMP(2)   // (wait for the ray) sample positions
                     // ---- row table: contributions of this thread's planes --------------------------------------------------
@@ -596,12 +607,12 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                         // the two X / Gram slots of this thread's planes and the border flags of their cells, one register each
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            sl[j] = 0;
-                            if (fits && cell[j] != NO_CELL) {
-                                const int cyy = cell_y(cell[j]), cxx = cell_x(cell[j]), r = cyy - ybase;
-                                sl[j] = (cxx + L.rowoff[r]) | ((cxx + L.rowoff[r + 1]) << SL_BITS) | SL_VALID | (cxx < 0 ? SL_XLO : 0) |
-                                        (cxx >= W - 1 ? SL_XHI : 0) | (cyy < 0 ? SL_YLO : 0) | (cyy >= H - 1 ? SL_YHI : 0);
-                            }
+                            // (branch-free: a plane without a cell looks up row 0 and drops the result)
+                            const bool has = fits && cell[j] != NO_CELL;
+                            const int cyy = cell_y(cell[j]), cxx = cell_x(cell[j]), r = has ? cyy - ybase : 0;
+                            const int v = (cxx + L.rowoff[r]) | ((cxx + L.rowoff[r + 1]) << SL_BITS) | SL_VALID | (cxx < 0 ? SL_XLO : 0) |
+                                          (cxx >= W - 1 ? SL_XHI : 0) | (cyy < 0 ? SL_YLO : 0) | (cyy >= H - 1 ? SL_YHI : 0);
+                            sl[j] = has ? v : 0;
                         }
                         // the block's reference features from LDS, as lane (n, kq) feeds them to the matrix pipe (every pass anew: they
                         // would otherwise occupy registers through the vector phases of every further view)
@@ -745,6 +756,13 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                 }
             }
 
+            // the next block of the item: its pixel loads fly under this block's epilogue
+            if (CORR_PREFETCH_PIXEL && sub + 1 < sub0 + spi && (wide ? ty * 4 + sub + 1 : ty * 4 + 2 * ((sub + 1) >> 1)) < H) {
+                const int xn = wide ? tx * 16 + n : tx * 16 + 8 * ((sub + 1) & 1) + (n & 7);
+                const int yn = wide ? ty * 4 + sub + 1 : ty * 4 + 2 * ((sub + 1) >> 1) + (n >> 3);
+                issue_pixel_loads(min(yn, H - 1) * W + min(xn, W - 1));
+                loaded = true;
+            }
             // ---- epilogue: cost store, log-softmax over D, expectation ----------------------------------------------------
             // (buffer stores: one 32-bit lane offset, the plane as the scalar offset: plane 64 h + 16 wave + 4 kq + j)
             const int ovoff = xlive ? (4 * kq * HW + p) * 4 : OOB;
