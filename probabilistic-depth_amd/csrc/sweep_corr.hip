@@ -58,7 +58,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define CORR_PREFETCH_PIXEL 0
 #endif
 #ifndef CORR_MAXB1   // blocks of 16 texels a pass can take, D <= 64 (LDS: 4 workgroups per CU)
-#define CORR_MAXB1 23
+#define CORR_MAXB1 22
 #endif
 constexpr int MAXROWS = 64;            // source rows per pass (row tables are indexed modulo 64)
 constexpr int BLK_PAD = 12;            // empty entries behind the block list (loads issued beyond it fetch nothing)
@@ -193,8 +193,9 @@ struct __attribute__((aligned(16))) CorrLds {
     static constexpr int XSTRIDE = MAXB * 16 + 4;   // floats per pixel of the X buffer (stride / 4 odd: conflict-free b128 stores)
     static constexpr int RS_TAIL = (NPL / 4) * 256;  // reference features: [chunk g][kq][pixel][4] floats, then [tail][kq][pixel]
     float Xs[16 * XSTRIDE];      // X[pixel][slot]
-    float G4s[MAXB * 16 * 4];    // Gram record (N, H, V, D1 + D2) per slot
-    float Ms[MAXB * 16];         // <s', mu> per slot
+    static constexpr int NSLOT = (MAXB * 16 + 63) / 64 * 64;   // (the Gram records arrive 64 slots per transfer)
+    float G4s[NSLOT * 4];        // Gram record (N, H, V, D1 + D2) per slot
+    float Ms[NSLOT];             // <s', mu> per slot
     float Rs[RS_TAIL + (NPL % 4) * 64 + 4];   // centred reference features of the block's 16 pixels, in B-operand order
     float rp[4 * 16 * 2];        // per wave and pixel: partial |r'|^2, <r', mu>
     float mu[80];                // channel means of the batch item in work; [72] = |mu|^2
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
             CSTAMP(1)   // item set-up, pixel loads issued
             float rr = 0.0f, rho = 0.0f;   // |r'|^2 and <r', mu> of the pixel (set with the first pass)
             bool centred = false;
-            bool failed = false;           // uniform over the workgroup: some pass of the block did not fit the row tables
+            unsigned failmask = 0;         // uniform over the workgroup: passes (view v, plane group h) that did not fit the row tables
 
             float cost[NC];
 #pragma unroll
@@ -517,6 +518,9 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                             }
                         }
                     }
+#ifdef CORR_FORCE_DIRECT   // test build: every pass takes the direct evaluation
+                    fits = false;
+#endif
                     CSTAMP(5)   // scan
                     // ---- X' = <r', s'> for the blocks of the pass, on the matrix pipe ---------------------------------------
                     const bool go = fits && nb > 0;
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
 #pragma unroll
                             for (int c = 0; c < (MAXB * 16 + 255) / 256; ++c) {
                                 const int c64 = (wave + 4 * c) * 64;
-                                if (c64 < 16 * nb) {   // (uniform per wave)
+                                if (go && c64 < 16 * nb) {   // (uniform per wave)
                                     const int slot = c64 + lane;
                                     const int be = L.blk[min(slot >> 4, MAXB + BLK_PAD - 1)];
                                     const int yy = be >> 16, xx = (int)(short)(be & 0xffff) + (slot & 15);
@@ -656,11 +660,12 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                     if (tid < 64) { L.cmin[par][tid] = INT_MAX; L.cmax[par][tid] = INT_MIN; }   // (this pass's tables are dead)
                     if (tid == 0) { L.ired[par][0] = INT_MAX; L.ired[par][1] = INT_MIN; }
                     ++pt;
-                    failed = failed || !fits;
                     CSTAMP(8)   // barrier: X complete
 
                     // ---- combine: cost of this thread's planes of the pass ------------------------------------------------
-                    if (fits) {
+                    if (!fits) {
+                        failmask |= 1u << (v * NH + h);   // (evaluated directly behind the view loop: direct_pass below)
+                    } else {
                         const v2f sg = *reinterpret_cast<const v2f*>(&L.cst[6]);   // sigma, 1 / sigma
                         const float M2 = L.mu[72];
 #pragma unroll
@@ -704,15 +709,19 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
             }
 
             CSTAMP(9)   // combine
-            if (failed) {
-                // ---- the geometry of some pass does not fit the row tables (extreme poses): the whole block directly, in the
-                //      reference's form on the centred features
-                if (tid == 0) ++n_direct;
+            if (failmask != 0) {
+                // Passes whose geometry does not fit the row tables (more than MAXB blocks or rows: long epipolar segments): their
+                // planes directly, in the reference's form on the centred features -- per plane the four taps of every channel
+                // group by 16-byte loads from the packed source, the pixel's centred reference features and the means from LDS.
+                // Taps outside the image: weight 0 on a clamped address (s' absent), and the (1 - Win) mu term of the header.
+                // About twice the work of a pass that fits.
                 const v4f c0 = *reinterpret_cast<const v4f*>(&L.cst[0]), c1 = *reinterpret_cast<const v4f*>(&L.cst[4]);
-#pragma unroll
-                for (int j = 0; j < NC; ++j) cost[j] = 0.0f;
-                const float* refp = ca.a.ref + (size_t)b * ca.a.ref_bstride + p;
-                for (int v = 0; v < V; ++v) {
+                const float M2 = L.mu[72];
+#pragma unroll 1
+                for (int vh = 0; vh < V * NH; ++vh) {
+                    if (!(failmask >> vh & 1u)) continue;
+                    if (tid == 0) ++n_direct;
+                    const int v = vh / NH, h = vh - v * NH;
                     ViewXform xf;
 #pragma unroll
                     for (int i = 0; i < 9; ++i) xf.kr[i] = L.xf[v * 12 + i];
@@ -722,40 +731,55 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                     float t2a, t2b, t2c;
                     ray_term2(xf, ray[0], ray[1], ray[2], t2a, t2b, t2c);
                     const float* srcf = reinterpret_cast<const float*>(ca.packed + ((size_t)b * V + v) * (NPL + 2) * HW);
-#pragma unroll
-                    for (int j = 0; j < NC; ++j) {
-                        const int k = 64 * (j >> 2) + 4 * tq + (j & 3);
-                        float part = 0.0f;
-                        if (k < D && xlive) {
-                            float ix, iy;
-                            plane_sample_pos_fast(xf, t2a, t2b, t2c, L.dcl[k], c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ix, iy);
-                            const Footprint f = make_footprint(ix, iy, W, H);
-                            const float win = ((f.mask & 1u) ? f.nw : 0.0f) + ((f.mask & 2u) ? f.ne : 0.0f) +
-                                              ((f.mask & 4u) ? f.sw : 0.0f) + ((f.mask & 8u) ? f.se : 0.0f);
-                            const float om = f.mask == 15u ? 0.0f : 1.0f - win;
-                            const float* s00 = srcf + (size_t)(f.y0 * W + f.x0) * 4;
-                            part = (f.nw + f.ne + f.sw + f.se) * 0.0f;   // (NaN weights: NaN cost, as the reference)
 #pragma unroll 1
-                            for (int c = 0; c < C; ++c) {
-                                const float* s = s00 + (size_t)(c >> 2) * HW * 4 + (c & 3);
-                                const float vnw = (f.mask & 1u) ? s[0] : 0.0f;
-                                const float vne = (f.mask & 2u) ? s[4] : 0.0f;
-                                const float vsw = (f.mask & 4u) ? s[W * 4] : 0.0f;
-                                const float vse = (f.mask & 8u) ? s[(W + 1) * 4] : 0.0f;
-                                float val = vnw * f.nw;
-                                val = __builtin_fmaf(vne, f.ne, val);
-                                val = __builtin_fmaf(vsw, f.sw, val);
-                                val = __builtin_fmaf(vse, f.se, val);
-                                const float u = L.mu[c];
-                                const float diff = (val - (refp[(size_t)c * HW] - u)) - om * u;
-                                part = __builtin_fmaf(diff, diff, part);
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = 64 * h + 4 * tq + j;
+                        float ix, iy, fwj, fnj;
+                        plane_sample_pos_fast(xf, t2a, t2b, t2c, L.dcl[k], c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ix, iy);
+                        int cellj = cell_of(ix, iy, W, H, fwj, fnj);
+                        if (k >= D || !xlive) cellj = NO_CELL;
+                        float q = (__builtin_fmaf(2.0f, rho, rr) + M2) + (fwj + fnj) * 0.0f;   // (no tap inside the image)
+                        if (cellj != NO_CELL) {
+                            const int cxx = cell_x(cellj), cyy = cell_y(cellj);
+                            const bool x0in = cxx >= 0, x1in = cxx + 1 < W, y0in = cyy >= 0, y1in = cyy + 1 < H;
+                            const float fe = 1.0f - fwj, fs = 1.0f - fnj;
+                            const float wnw = x0in && y0in ? fs * fe : 0.0f, wne = x1in && y0in ? fs * fwj : 0.0f;
+                            const float wsw = x0in && y1in ? fnj * fe : 0.0f, wse = x1in && y1in ? fnj * fwj : 0.0f;
+                            const float om = (x0in && x1in && y0in && y1in) ? 0.0f : 1.0f - (((wnw + wne) + wsw) + wse);
+                            const int xa = max(cxx, 0), xb = min(cxx + 1, W - 1), ya = max(cyy, 0), yb = min(cyy + 1, H - 1);
+                            const int i00 = (ya * W + xa) * 4, i01 = (ya * W + xb) * 4, i10 = (yb * W + xa) * 4, i11 = (yb * W + xb) * 4;
+                            float part = 0.0f;
+#pragma unroll 1
+                            for (int g = 0; g < NPL; ++g) {
+                                const float* sg4 = srcf + (size_t)g * HW * 4;
+                                const v4f t00 = *reinterpret_cast<const v4f*>(sg4 + i00), t01 = *reinterpret_cast<const v4f*>(sg4 + i01);
+                                const v4f t10 = *reinterpret_cast<const v4f*>(sg4 + i10), t11 = *reinterpret_cast<const v4f*>(sg4 + i11);
+                                const v4f u4 = *reinterpret_cast<const v4f*>(&L.mu[min(4 * g, 68)]);
+                                v4f r4;   // channels 4 g .. 4 g + 3 of pixel n in the B-operand image (chunk g >> 2, lane slice g & 3)
+                                if (g < 4 * NCH) r4 = *reinterpret_cast<const v4f*>(&L.Rs[(((g >> 2) * 4 + (g & 3)) * 16 + n) * 4]);
+                                else {
+                                    const float* rt = &L.Rs[Lds::RS_TAIL + ((g - 4 * NCH) * 4) * 16 + n];
+                                    r4 = v4f{rt[0], rt[16], rt[32], rt[48]};
+                                }
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    float val = t00[i] * wnw;
+                                    val = __builtin_fmaf(t01[i], wne, val);
+                                    val = __builtin_fmaf(t10[i], wsw, val);
+                                    val = __builtin_fmaf(t11[i], wse, val);
+                                    const float diff = (val - r4[i]) - om * u4[i];
+                                    part = __builtin_fmaf(diff, diff, part);
+                                }
                             }
+                            q = part + (fwj + fnj) * 0.0f;
                         }
-                        cost[j] = cost[j] + (fabsf(part) < 1.0e30f ? div_core(part, c1.z, c1.w) : part * c1.w);
+                        const float cj = fabsf(q) < 1.0e30f ? div_core(q, c1.z, c1.w) : q * c1.w;
+#pragma unroll
+                        for (int jj = 0; jj < NC; ++jj) cost[jj] = cost[jj] + (jj == 4 * h + j ? cj : 0.0f);
                     }
                 }
+                LDS_BARRIER();   // (every wave is done with the block's reference features: the next block may overwrite them)
             }
-
             // the next block of the item: its pixel loads fly under this block's epilogue
             if (CORR_PREFETCH_PIXEL && sub + 1 < sub0 + spi && (wide ? ty * 4 + sub + 1 : ty * 4 + 2 * ((sub + 1) >> 1)) < H) {
                 const int xn = wide ? tx * 16 + n : tx * 16 + 8 * ((sub + 1) & 1) + (n & 7);
