@@ -215,7 +215,7 @@ class PackedSource:
         self.centred = bool(centred)             # the channel means were subtracted (pdepth_sweep_centres_source)
 
 
-def pack_source(src, n_planes=64, algo=ALGO_AUTO):
+def pack_source(src, n_planes=64, algo=ALGO_AUTO, metric=METRIC_L2):
     """src [B,V,C,H,W] fp32 device tensor -> PackedSource (n_planes and algo only select the kernel that will sweep it, like
     desc.D and desc.algo: the layout the correlation-form kernel takes is mean-centred, the LDS-tiled kernel's is not)."""
     lib = load()
@@ -226,7 +226,7 @@ def pack_source(src, n_planes=64, algo=ALGO_AUTO):
     B, V, C, H, W = src.shape
     if not _inner_contiguous(src, 3) or (V > 1 and src.stride(1) < C * H * W):
         src = src.contiguous()
-    desc = SweepDesc(B, V, C, int(n_planes), H, W, METRIC_L2, int(algo), BLAS_FMA, 1.0, C * H * W,
+    desc = SweepDesc(B, V, C, int(n_planes), H, W, int(metric), int(algo), BLAS_FMA, 1.0, C * H * W,
                      src.stride(0) if B > 1 else V * C * H * W, src.stride(1) if V > 1 else C * H * W)
     ws_bytes = lib.pdepth_sweep_workspace_bytes(ctypes.byref(desc))
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=src.device)

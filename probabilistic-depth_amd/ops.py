@@ -72,11 +72,12 @@ def sweep_dpv(ref, src, K, R, t, rays, cxcy, d_candi, sigma, feat_dist="L2", alg
 UnsupportedShape = _native.UnsupportedShape
 
 
-def pack_source(src, n_planes=64, algo="auto"):
+def pack_source(src, n_planes=64, algo="auto", feat_dist="L2"):
     """Source views [B,V,C,H,W] -> the sweep kernels' staging layout, once (pdepth_pack_source_f32); pass the result as
-    `src` to sweep_cost / sweep_dpv with the same algo.  The re-layout is 10 % of a fused sweep call.  Raises
-    UnsupportedShape for shapes the packed sweep does not take."""
-    return _native.pack_source(src, n_planes, ALGOS[algo])
+    `src` to sweep_cost / sweep_dpv with the same algo and feat_dist (the kernel they select decides whether the layout is
+    mean-centred).  The re-layout is 10 % of a fused sweep call.  Raises UnsupportedShape for shapes the packed sweep does
+    not take."""
+    return _native.pack_source(src, n_planes, ALGOS[algo], _metric(feat_dist))
 
 
 def pack_views(feat, rgb, n_views, n_planes=64):

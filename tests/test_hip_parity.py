@@ -388,17 +388,15 @@ def test_fuzz_large_tiled_against_gather(dev):
     print(f"large fuzz: worst relative difference {worst:.2e}, {fallback} tiles through the gather kernel")
 
 
-@pytest.mark.parametrize("variant", ["tiled1", "tiled2", "cells", "mfma"])
+@pytest.mark.parametrize("variant", ["tiled1", "tiled2", "corr"])
 def test_every_sweep_implementation_on_small_ragged_shapes(dev, variant):
-    """The library holds two builds of the tiled kernel (one / two 16x4 tiles per block; ALGO_AUTO picks one per call
-    by shape) and the cell-list kernels; the implementation selectors force one, so that each meets the ragged sizes,
-    odd tile counts, multi-view and D > 64 cases whatever the heuristic would choose."""
+    """The library holds the correlation-form kernel (what ALGO_AUTO runs for the L2 metric) and two builds of the LDS-tiled
+    kernel (one / two 16x4 tiles per block); the implementation selectors force one, so that each meets the ragged sizes,
+    odd tile counts, multi-view and D > 64 cases whatever ALGO_AUTO would choose."""
     rng = np.random.default_rng(7)
     for case in range(30):
         H, W = int(rng.integers(3, 90)), int(rng.integers(3, 150))
         C, D, V = int(rng.integers(1, 20)), int(rng.integers(1, 100 if variant != "tiled2" else 65)), int(rng.integers(1, 3))
-        if variant == "cells" and case % 3 == 0:
-            D = 64 if case % 2 else 128   # the straight-line kernel only runs full 64-plane windows
         b = synth.make_batch(700 + case, 2 if case % 4 == 0 else 1, C=C, D=D, H=H, W=W, V=V,
                              pose=("mono", "stereo", "wide")[case % 3], cx_off=float(rng.uniform(-2, 2)))
         d = to_dev(b, dev)
@@ -433,13 +431,13 @@ def test_soak_regressions(dev):
         assert err < 2e-6, f"{algo}: {err:.3e}"
     b = synth.make_batch(5480, 1, C=22, D=83, H=195, W=286, V=3, pose="mono", cx_off=1.999560470167534, cy_off=-0.5343920453361704)
     b["t"][0, 0] = torch.tensor([18.91592254, 18.98302991, -11.80695313])
-    for algo in ("auto", "tiled1", "cells", "mfma"):
+    for algo in ("auto", "tiled1", "corr"):
         agree(b, algo)
     rng = np.random.default_rng(1301)
     for D in (64, 128):
         b = synth.make_batch(6301, 1, C=33, D=D, H=150, W=302, V=1, pose="stereo")
         b["d_candi"] = rng.uniform(0.5, 60.0, size=D)
-        for algo in ("cells", "mfma", "auto", "tiled2" if D == 64 else "tiled1"):
+        for algo in ("corr", "auto", "tiled2" if D == 64 else "tiled1"):
             agree(b, algo)
 
 
@@ -458,7 +456,7 @@ def test_packed_entry_with_gather_fallback(dev):
         args = (d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 9.0)
         for metric in ("L2", "L1"):
             try:
-                ps = ops.pack_source(d["src"], D)
+                ps = ops.pack_source(d["src"], D, feat_dist=metric)
                 cp, lp, dp = ops.sweep_dpv(d["ref"], ps, *args, feat_dist=metric, want_cost=True)
             except RuntimeError as e:   # shapes the packed entry declines (e.g. L1 with C > 68)
                 assert "packed" in str(e), str(e)

@@ -1,0 +1,155 @@
+"""GPU suite: features that are NOT zero-mean.
+
+The L2 cost sum_c (sum_t w_t s_t - r)^2 (warping/homography.py:80-82,129) does not change when the same constant is added
+to every reference and source value of a channel -- wherever the four taps lie inside the image.  The correlation form
+w^T G w - 2 w.X + |r|^2 that the fast kernels evaluate does: its three terms grow with (mean/std)^2 and cancel.  Round 3's
+kernels lost the 1e-4 depth bound at mean/std = 3.  ALGO_AUTO now centres the features (csrc/sweep_corr.hip,
+csrc/sweep_pack.hip); the LDS-tiled kernel, which is left for the L1 metric and wide features, switches its correlation-form
+plane group off when the pre-pass finds offsets larger than the spread.  Everything here is against the CPU oracle, at the
+north-star tolerance: depth 1e-4 m, cost 2e-4 abs + 2e-5 rel."""
+import numpy as np
+import pytest
+import torch
+
+import pdepth_amd  # noqa: F401
+from pdepth_amd import _native, ops, synth
+from util import DEPTH_ATOL, oracle_batch, to_dev
+
+pytestmark = pytest.mark.gpu
+COST_ATOL, COST_RTOL = 2e-4, 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU suite needs a GPU"
+    return torch.device("cuda:0")
+
+
+def _offset_batch(kind, pose, B=2, C=67, D=64, H=64, W=128, V=1, seed=9):
+    """N(0,1) features of synth.make_batch plus a per-channel offset: 'uniform8' mu_c ~ U(-8, 8); 'relu' = max(x + 1.5, 0)
+    (all positive, like the output of a ReLU); 'ramp' adds a vertical ramp on top of the offset (the sampled rows of the
+    statistics kernel see the mean, not the trend)."""
+    b = synth.make_batch(seed, B, C=C, D=D, H=H, W=W, V=V, pose=pose)
+    g = torch.Generator().manual_seed(1234 + seed)
+    if kind == "uniform8":
+        mu = (torch.rand(C, generator=g) * 2 - 1) * 8.0
+        b["ref"] = b["ref"] + mu[None, :, None, None]
+        b["src"] = b["src"] + mu[None, None, :, None, None]
+    elif kind == "relu":
+        b["ref"] = torch.clamp(b["ref"] + 1.5, min=0.0)
+        b["src"] = torch.clamp(b["src"] + 1.5, min=0.0)
+    elif kind == "ramp":
+        mu = (torch.rand(C, generator=g) * 2 - 1) * 4.0
+        ramp = torch.linspace(-2.0, 2.0, H)[None, None, :, None]
+        b["ref"] = b["ref"] + mu[None, :, None, None] + ramp
+        b["src"] = b["src"] + mu[None, None, :, None, None] + ramp[:, None]
+    else:
+        raise ValueError(kind)
+    return b
+
+
+def _check(b, dev, algo, **kw):
+    ocost, ologp, odepth = oracle_batch(b)
+    d = to_dev(b, dev)
+    cost, logp, depth = ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0,
+                                      algo=algo, want_cost=True, **kw)
+    np.testing.assert_allclose(cost.cpu().numpy(), ocost.numpy(), rtol=COST_RTOL, atol=COST_ATOL, err_msg=algo)
+    err = (depth.cpu() - odepth).abs().max().item()
+    assert err <= DEPTH_ATOL, f"{algo}: depth differs from the oracle by {err:.3e}"
+    return err
+
+
+@pytest.mark.parametrize("pose", ["mono", "stereo"])
+@pytest.mark.parametrize("kind", ["uniform8", "relu", "ramp"])
+def test_offset_features_against_the_oracle(dev, kind, pose):
+    """64x128, C=67, D=64: every implementation ALGO_AUTO can run, on features with per-channel means of up to 8 standard
+    deviations."""
+    b = _offset_batch(kind, pose)
+    for algo in ("auto", "corr", "tiled1", "tiled2", "direct"):
+        _check(b, dev, algo)
+        # the tiled kernel only gets there because the pre-pass switches its correlation-form plane group off
+        if kind == "uniform8" and algo.startswith("tiled"):
+            assert _native.noncentred_guard(2, 64, 128) is True
+
+
+def test_offset_features_border_cells_and_views(dev):
+    """Cells on the image border are where centring is NOT free (a tap outside the image reads zero, not the mean): a pose
+    that pushes many samples across the border, two source views, an off-centre principal point, ragged sizes."""
+    for H, W, V, pose, D in ((37, 83, 2, "wide", 48), (64, 96, 2, "mono", 100), (50, 70, 1, "stereo", 64)):
+        b = synth.make_batch(77, 1, C=19, D=D, H=H, W=W, V=V, pose=pose, cx_off=1.7, cy_off=-0.9)
+        g = torch.Generator().manual_seed(5)
+        mu = (torch.rand(19, generator=g) * 2 - 1) * 6.0
+        b["ref"] = b["ref"] + mu[None, :, None, None]
+        b["src"] = b["src"] + mu[None, None, :, None, None]
+        ocost, ologp, odepth = oracle_batch(b)
+        d = to_dev(b, dev)
+        for algo in ("auto", "corr"):
+            cost, logp, depth = ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0,
+                                              algo=algo, want_cost=True)
+            fin = torch.isfinite(ocost)
+            assert torch.equal(torch.isfinite(cost.cpu()), fin), (algo, pose)
+            np.testing.assert_allclose(cost.cpu()[fin].numpy(), ocost[fin].numpy(), rtol=COST_RTOL, atol=COST_ATOL, err_msg=f"{algo} {pose}")
+            dfin = torch.isfinite(odepth)
+            assert (depth.cpu()[dfin] - odepth[dfin]).abs().max().item() <= DEPTH_ATOL * max(1.0, float(np.max(b["d_candi"])) / 40.0)
+
+
+def test_centred_features_do_not_raise_the_guard(dev):
+    """N(0,1) features: the tiled kernel keeps its correlation-form plane group (the guard costs the headline nothing)."""
+    b = synth.make_batch(3, 2, C=67, D=64, H=64, W=128, V=1, pose="mono")
+    _check(b, dev, "tiled1")
+    assert _native.noncentred_guard(2, 64, 128) is False
+
+
+def test_packed_source_is_tied_to_the_kernel_family(dev):
+    """The centred layout (ALGO_AUTO / 'corr', L2) and the plain one (the tiled kernel: L1, forced selectors) differ, and
+    the library cannot tell them apart from the host: the binding refuses to sweep a packed source with a descriptor that
+    selects the other family (pdepth_sweep_centres_source), and both families give the NCHW entry's answer bit for bit."""
+    b = _offset_batch("uniform8", "mono", B=1)
+    d = to_dev(b, dev)
+    args = (d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0)
+    centred = ops.pack_source(d["src"], 64)                      # auto, L2
+    plain = ops.pack_source(d["src"], 64, algo="tiled1")
+    assert centred.centred and not plain.centred
+    with pytest.raises(RuntimeError, match="another kernel family"):
+        ops.sweep_dpv(d["ref"], centred, *args, algo="tiled1")
+    with pytest.raises(RuntimeError, match="another kernel family"):
+        ops.sweep_dpv(d["ref"], plain, *args, algo="auto")
+    with pytest.raises(RuntimeError, match="another kernel family"):
+        ops.sweep_dpv(d["ref"], centred, *args, feat_dist="L1")
+    first = {}
+    for ps, algo in ((centred, "auto"), (plain, "tiled1")):
+        cp, lp, dp = ops.sweep_dpv(d["ref"], ps, *args, algo=algo, want_cost=True)
+        ca, la, da = ops.sweep_dpv(d["ref"], d["src"], *args, algo=algo, want_cost=True)
+        assert torch.equal(cp, ca) and torch.equal(lp, la) and torch.equal(dp, da), algo
+        first[algo] = cp
+    # a second and a third sweep of the same packed source (the kernel leaves the workspace ready for the next call)
+    for _ in range(2):
+        c2 = ops.sweep_dpv(d["ref"], centred, *args, algo="auto", want_cost=True)[0]
+        assert torch.equal(c2, first["auto"])
+
+
+def test_passes_that_do_not_fit_are_evaluated_directly(dev):
+    """A wide-baseline pose: epipolar segments of hundreds of texels, more blocks of X than the kernel's LDS holds -- those
+    passes take the direct evaluation inside the same launch (no tile flags, no second kernel) and meet the same bounds;
+    the diagnostics counter says that it happened."""
+    total = 0
+    for seed, (H, W, D, V) in enumerate(((96, 200, 64, 1), (120, 260, 128, 2))):
+        b = synth.make_batch(900 + seed, 1, C=35, D=D, H=H, W=W, V=V, pose="wide")
+        g = torch.Generator().manual_seed(seed)
+        mu = (torch.rand(35, generator=g) * 2 - 1) * 3.0
+        b["ref"] = b["ref"] + mu[None, :, None, None]
+        b["src"] = b["src"] + mu[None, None, :, None, None]
+        ocost, ologp, odepth = oracle_batch(b)
+        d = to_dev(b, dev)
+        cost, logp, depth = ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0,
+                                          algo="corr", want_cost=True)
+        total += _native.fallback_tiles(1, H, W)
+        fin = torch.isfinite(ocost)
+        assert torch.equal(torch.isfinite(cost.cpu()), fin)
+        np.testing.assert_allclose(cost.cpu()[fin].numpy(), ocost[fin].numpy(), rtol=COST_RTOL, atol=COST_ATOL)
+        dfin = torch.isfinite(odepth)
+        assert (depth.cpu()[dfin] - odepth[dfin]).abs().max().item() <= DEPTH_ATOL
+        # cost only (no softmax epilogue between consecutive pixel blocks)
+        c2 = ops.sweep_cost(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0, algo="corr")
+        assert torch.equal(c2.nan_to_num(nan=-7.0), cost.nan_to_num(nan=-7.0))
+    assert total > 0, "these poses are meant to exceed the row tables"
