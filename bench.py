@@ -23,7 +23,10 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2   # wave-instructions / s: 256 CUs x 4 SIMDs, one wave64 VALU op per 2 clocks at 2.4 GHz
+# wave-instructions / s: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 clocks at 2.4 GHz (16 lanes x 4 passes; the 157 TFLOP/s
+# fp32 peak = this rate x 64 lanes x 2 flop x 2 packed components).  Rounds 1-3 divided by 2 clocks and under-reported valu_frac by 2x:
+# SQ_ACTIVE_INST_VALU of the same runs (one quad-cycle per VALU instruction) says 4.
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4
 
 
 def algorithmic_bytes_per_volume(C, V, D, H, W):
@@ -87,9 +90,11 @@ def main():
     ap.add_argument("--planes", type=int, default=64)
     ap.add_argument("--views", type=int, default=1)
     ap.add_argument("--pose", default="mono", choices=["mono", "stereo"])
-    ap.add_argument("--algo", default="auto", choices=["auto", "direct", "tiled1", "tiled2", "cells", "mfma"])
+    ap.add_argument("--algo", default="auto", choices=["auto", "direct", "corr", "tiled1", "tiled2", "cells", "mfma"],
+                    help="cells / mfma: lab builds of the library only (make LAB=1)")
     ap.add_argument("--peaked", action="store_true", help="SURVEY 8(d)'s correlated feature variant (src = 0.7 shift(ref) + 0.3 noise: a peaked DPV)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-start measurement in front of the headline")
     ap.add_argument("--config", default=None, help="an experiment file in the reference's JSON schema (configs/*.json): "
                     "planes, depth range, sigma, channels and the pose family come from it; the sweep resolution stays "
                     "--height x --width (BASELINE quotes the metric at 256x512)")
@@ -148,12 +153,19 @@ def main():
             print("per-step ms: " + " ".join("%.4f" % ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps)), file=sys.stderr)
         return out, wall, kern_ms
 
-    # Before anything is timed: (1) the gather kernel -- the reference's op order, pinned to the oracle by the tests -- on
-    # the very batch that is about to be timed, as a cross-check of the headline output (reported as `preflight`);
-    # (2) the secondary measurement, the same step on features already in the kernels' staging layout.  Both also mean that
-    # the W warm-up steps of the headline start on a GPU at its sustained clocks: from idle the clocks take ~20 ms of work
-    # to come up (per-step times of a cold run: 0.59 ms falling to 0.47; PDEPTH_BENCH_TRACE=1 prints them), more than the
-    # 5 x 0.5 ms of warm-up the driver asks for.
+    # Order of the GPU work of this process, all of it reported in the line:
+    #   1. `cold_start`: the headline protocol -- W warm-up steps, K timed steps -- as the FIRST GPU work of the process.  From idle
+    #      the GPU's clocks take ~20 ms of work to come up, more than the driver's 5 warm-up steps: these K steps run on rising clocks
+    #      (PDEPTH_BENCH_TRACE=1 prints them: 0.59 ms falling to 0.47 in round 3).
+    #   2. `preflight`: the gather kernel -- the reference's op order, pinned to the oracle by the tests -- on the very batch that is
+    #      timed, as a cross-check of the headline output.
+    #   3. `packed_entry`: the same step on features already in the kernels' staging layout (W + K steps).
+    #   4. the headline: W warm-up steps, K timed steps, now at sustained clocks.  `preheat_ms` = the GPU time of 1-3 in front of it.
+    t_pre0 = time.perf_counter()
+    cold = None
+    if not a.no_cold:
+        _, _, cold_ms = timed(d["src"])
+        cold = {"ms_per_step": cold_ms, "what": "the same W warm-up + K timed steps as the first GPU work of the process (clocks still rising)"}
     depth_gather = None
     try:
         depth_gather = ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], dc, sigma,
@@ -161,13 +173,15 @@ def main():
     except RuntimeError:
         pass
     packed_entry, out_p, kern_p = None, None, None
-    if a.algo == "auto":   # secondary: the same step on features already in the kernels' staging layout
+    if a.algo in ("auto", "corr"):   # secondary: the same step on features already in the kernels' staging layout
         try:
-            ps = ops.pack_source(d["src"], cfg["D"])
+            ps = ops.pack_source(d["src"], cfg["D"], a.algo)
             out_p, _, kern_p = timed(ps)
             del ps
         except RuntimeError as e:
             packed_entry = {"error": str(e)}
+    torch.cuda.synchronize(dev)
+    preheat_ms = (time.perf_counter() - t_pre0) * 1e3
 
     out, wall, kern_ms = timed(d["src"])
     depth = out[2]
@@ -202,14 +216,19 @@ def main():
                         prof = rec
             except Exception:
                 prof = {}
-        kname = {"mfma": "sweep_mfma_kernel (matrix-pipe kernel)", "tiled": "sweep_tiled_kernel (LDS-tiled band kernel)",
+        kname = {"corr": "sweep_corr_kernel (correlation form on mean-centred features, matrix pipe)",
+                 "mfma": "sweep_mfma_kernel (matrix-pipe kernel)", "tiled": "sweep_tiled_kernel (LDS-tiled band kernel)",
                  "tiled1": "sweep_tiled_kernel, one tile per block", "tiled2": "sweep_tiled_kernel, two tiles per block",
                  "cells": "sweep_cells_fast_kernel + sweep_cells_kernel", "direct": "sweep_direct_kernel (gather)"}.get(impl, str(impl))
         roof = {"traffic": prof.get("hbm_bytes_per_launch"),
+                # (PMC counters cannot be collected inside this run: the record is the committed one of this workload and kernel,
+                #  with the commit and box it was collected on)
                 "traffic_source": prof.get("source"),
-                "kernel": "fused sweep+DPV call = pack_c4_kernel (source re-layout pre-pass) + " + kname +
-                          " (+ the gather kernel on flagged tiles" + ("; ALGO_AUTO launches both sweep kernels on this shape class and "
-                          "the pre-pass picks one on the device, the other leaves at once)" if (a.algo == "auto" and tiled_class) else ")"),
+                "traffic_collected": prof.get("collected"),
+                "kernel": ("fused sweep+DPV call = feature_stats_kernel + pack_c4_kernel (pre-pass: channel means, centred re-layout) + " + kname
+                           if impl == "corr" else
+                           "fused sweep+DPV call = feature_stats_kernel + pack_c4_kernel (source re-layout pre-pass) + " + kname +
+                           " + the gather kernel on flagged tiles"),
                 "sweep_kernel": impl,
                 # secondary figure of SURVEY 8(d): flops of the direct formulation, 11*D*h*w*V*C per volume, against
                 # the dense fp32 vector peak (157.3 TFLOP/s); the band mode executes fewer
@@ -220,7 +239,11 @@ def main():
             # VALU wave-instructions per launch (PMC SQ_INSTS_VALU, committed profile) / issue peak / kernel time
             roof["valu_frac"] = prof["valu_wave_instr_per_launch"] / (kern_ms * 1e-3) / VALU_ISSUE_PEAK
             roof["valu_wave_instr_per_launch"] = prof["valu_wave_instr_per_launch"]
-        extras = {"roofline": roof, "gather_fallback_tiles": fallback}
+        extras = {"roofline": roof, "gather_fallback_tiles": fallback,
+                  "preheat_ms": preheat_ms, "preheat": "cold_start + preflight + packed_entry (see those objects) ran before the headline's warm-up"}
+        if cold is not None:
+            cold["value"] = (hi - lo) * world / (cold["ms_per_step"] * 1e-3)
+            extras["cold_start"] = cold
         if preflight is not None:
             extras["preflight"] = preflight
         if packed_entry is not None:

@@ -57,6 +57,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef CORR_PREFETCH_PIXEL   // the next block's pixel loads under the epilogue
 #define CORR_PREFETCH_PIXEL 0
 #endif
+#ifndef CORR_STORE_AUX   // cache policy of the output stores: 2 = nt (written once, read by nobody in this launch: -2 % on the
+#define CORR_STORE_AUX 2 // forward-motion pose, whose 8x2 pixel blocks store 32-byte runs)
+#endif
+#ifndef CORR_ABL   // timing experiments (results wrong): 1 no texel loads, 2 no multiplications, 3 no X phase at all, 4 no combine, 5 no
+#define CORR_ABL 0  // softmax epilogue, 6 no Gram transfers
+#endif
 #ifndef CORR_MAXB1   // blocks of 16 texels a pass can take, D <= 64 (LDS: 4 workgroups per CU)
 #define CORR_MAXB1 22
 #endif
@@ -207,6 +213,7 @@ struct __attribute__((aligned(16))) CorrLds {
     int rowoff[MAXROWS + 2];     // per texel row of the pass: slot = x + rowoff
     int blk[MAXB + BLK_PAD];     // per block: (y << 16) | (x & 0xffff) of its first texel
     int ired[2][2];              // min / max cell row of the pass; two sets
+    int tab[4];                  // wave 0's row table of the pass: blocks, fits, first row
     int item[2];                 // work item: current / next
     unsigned char wide[64];      // per batch item: pixel blocks are 16x1 (else 8x2)
 };
@@ -489,44 +496,70 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                     CSTAMP(3)   // table atomics, (wait for the reference features) centring
                     LDS_BARRIER();
                     CSTAMP(4)   // barrier: tables complete
-                    const int ybase = __builtin_amdgcn_readfirstlane(L.ired[par][0]), ytop = __builtin_amdgcn_readfirstlane(L.ired[par][1]);
-                    int nb = 0;
-                    bool fits = true;
-                    if (ybase <= ytop) {
-                        const int ncell = ytop - ybase + 1;
-                        if (ncell + 1 > MAXB) {   // (every texel row takes a block; also keeps the modulo-64 rows apart)
-                            fits = false;
-                        } else {
-                            // lane = texel row ybase + lane: the cells of rows lane - 1 and lane touch it (every wave computes the
-                            // same table and writes the same values)
-                            int lo = INT_MAX, hi = INT_MIN;
-                            if (lane < ncell) { lo = L.cmin[par][(ybase + lane) & 63]; hi = L.cmax[par][(ybase + lane) & 63]; }
-                            if (lane >= 1 && lane <= ncell) {
-                                lo = min(lo, L.cmin[par][(ybase + lane - 1) & 63]);
-                                hi = max(hi, L.cmax[par][(ybase + lane - 1) & 63]);
-                            }
-                            const int nblk = lo <= hi ? (hi - lo + 2 + 15) >> 4 : 0;   // texels lo .. hi + 1
-                            const int incl = wave_scan_incl(nblk);
-                            nb = __builtin_amdgcn_readlane(incl, 63);
-                            fits = nb <= MAXB;
-                            if (fits) {
-                                const int fb = incl - nblk;
-                                if (lane <= ncell) L.rowoff[lane] = 16 * fb - lo;
-                                for (int i = 0; i < nblk; ++i) L.blk[fb + i] = ((ybase + lane) << 16) | ((lo + 16 * i) & 0xffff);
-                                if (lane < BLK_PAD) L.blk[nb + lane] = EMPTY_BLOCK;
-                                WAVE_LDS_SYNC();
+                    // ---- the row table is cut into blocks by wave 0 alone (the same ~250 instructions in every wave were 15 % of the
+                    //      kernel's vector work); the other waves fetch the block's reference features meanwhile
+                    if (wave == 0) {
+                        const int yb = __builtin_amdgcn_readfirstlane(L.ired[par][0]), yt = __builtin_amdgcn_readfirstlane(L.ired[par][1]);
+                        int nb_ = 0;
+                        bool fits_ = true;
+                        if (yb <= yt) {
+                            const int ncell = yt - yb + 1;
+                            if (ncell + 1 > MAXB) {   // (every texel row takes a block; also keeps the modulo-64 rows apart)
+                                fits_ = false;
+                            } else {
+                                // lane = texel row yb + lane: the cells of rows lane - 1 and lane touch it
+                                int lo = INT_MAX, hi = INT_MIN;
+                                if (lane < ncell) { lo = L.cmin[par][(yb + lane) & 63]; hi = L.cmax[par][(yb + lane) & 63]; }
+                                if (lane >= 1 && lane <= ncell) {
+                                    lo = min(lo, L.cmin[par][(yb + lane - 1) & 63]);
+                                    hi = max(hi, L.cmax[par][(yb + lane - 1) & 63]);
+                                }
+                                const int nblk = lo <= hi ? (hi - lo + 2 + 15) >> 4 : 0;   // texels lo .. hi + 1
+                                const int incl = wave_scan_incl(nblk);
+                                nb_ = __builtin_amdgcn_readlane(incl, 63);
+                                fits_ = nb_ <= MAXB;
+                                if (fits_) {
+                                    const int fb = incl - nblk;
+                                    if (lane <= ncell) L.rowoff[lane] = 16 * fb - lo;
+                                    for (int i = 0; i < nblk; ++i) L.blk[fb + i] = ((yb + lane) << 16) | ((lo + 16 * i) & 0xffff);
+                                    if (lane < BLK_PAD) L.blk[nb_ + lane] = EMPTY_BLOCK;
+                                }
                             }
                         }
+                        if (lane == 0) { L.tab[0] = nb_; L.tab[1] = fits_ ? 1 : 0; L.tab[2] = yb; }
+                        // (only this wave reads the min / max tables: they are dead now)
+                        L.cmin[par][lane] = INT_MAX; L.cmax[par][lane] = INT_MIN;
+                        if (lane == 0) { L.ired[par][0] = INT_MAX; L.ired[par][1] = INT_MIN; }
                     }
+                    // the block's reference features from LDS, as lane (n, kq) feeds them to the matrix pipe (every pass anew: they
+                    // would otherwise occupy registers through the vector phases of every further view)
+                    float Rr[NPL];
+#pragma unroll
+                    for (int g = 0; g < NCH; ++g) {
+                        const v4f r4 = *reinterpret_cast<const v4f*>(&L.Rs[((g * 4 + kq) * 16 + n) * 4]);
+                        Rr[4 * g + 0] = r4.x; Rr[4 * g + 1] = r4.y; Rr[4 * g + 2] = r4.z; Rr[4 * g + 3] = r4.w;
+                    }
+#pragma unroll
+                    for (int tp = 0; tp < NTL; ++tp) Rr[4 * NCH + tp] = L.Rs[Lds::RS_TAIL + (tp * 4 + kq) * 16 + n];
+                    if (!centred) {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const v2f pp = *reinterpret_cast<const v2f*>(&L.rp[(w * 16 + n) * 2]);
+                            rr = rr + pp.x; rho = rho + pp.y;
+                        }
+                        centred = true;
+                    }
+                    LDS_BARRIER();   // the block list is complete
+                    const int nb = __builtin_amdgcn_readfirstlane(L.tab[0]), ybase = __builtin_amdgcn_readfirstlane(L.tab[2]);
+                    bool fits = __builtin_amdgcn_readfirstlane(L.tab[1]) != 0;
 #ifdef CORR_FORCE_DIRECT   // test build: every pass takes the direct evaluation
                     fits = false;
 #endif
                     CSTAMP(5)   // scan
                     // ---- X' = <r', s'> for the blocks of the pass, on the matrix pipe ---------------------------------------
-                    const bool go = fits && nb > 0;
+                    const bool go = fits && nb > 0 && CORR_ABL != 3;
                     int sl[4];
                     {
-                        float Rr[NPL];
                         const int myblk = L.blk[min(lane, MAXB + BLK_PAD - 1)];   // the block list in a register: entry l in lane l
                         // Gram records (N, H, V, D1 + D2) and <s', mu> of the pass's slots (texel = slot of a block), straight
                         // from the packed source into LDS: wave w moves slots 64 c .. 64 c + 63 for c = w, w + 4, ...
@@ -539,7 +572,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
 #pragma unroll
                             for (int c = 0; c < (MAXB * 16 + 255) / 256; ++c) {
                                 const int c64 = (wave + 4 * c) * 64;
-                                if (go && c64 < 16 * nb) {   // (uniform per wave)
+                                if (go && CORR_ABL != 6 && c64 < 16 * nb) {   // (uniform per wave)
                                     const int slot = c64 + lane;
                                     const int be = L.blk[min(slot >> 4, MAXB + BLK_PAD - 1)];
                                     const int yy = be >> 16, xx = (int)(short)(be & 0xffff) + (slot & 15);
@@ -570,20 +603,23 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                         auto load_a = [&]() {
 #pragma unroll
                             for (int gi = 0; gi < LA; ++gi)
-                                SA[gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, gi * 4 * HW * 16, 0));
+                                SA[gi] = CORR_ABL == 1 ? v4f{(float)vo, 1.f, 2.f, 3.f}
+                                                       : __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, gi * 4 * HW * 16, 0));
                         };
                         auto load_b = [&]() {
 #pragma unroll
                             for (int gi = 0; gi < LB; ++gi)
-                                SB[gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, (LA + gi) * 4 * HW * 16, 0));
+                                SB[gi] = CORR_ABL == 1 ? v4f{(float)vo, 1.f, 2.f, 3.f}
+                                                       : __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, (LA + gi) * 4 * HW * 16, 0));
 #pragma unroll
                             for (int tp = 0; tp < NTL; ++tp)
-                                TB[tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vt, (4 * NCH + tp) * HW * 16, 0));
+                                TB[tp] = CORR_ABL == 1 ? (float)vt : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vt, (4 * NCH + tp) * HW * 16, 0));
                         };
                         // ceil(C/4) MFMAs per block in two alternating accumulator chains (a dependent f32 MFMA waits 40 cycles, an
                         // independent one issues after 32)
                         v4f acc0, acc1;
                         auto mul_a = [&]() {
+                            if (CORR_ABL == 2) { for (int gi = 0; gi < LA; ++gi) acc0 += SA[gi] * Rr[4 * gi]; return; }
 #pragma unroll
                             for (int gi = 0; gi < LA; ++gi) {
                                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(SA[gi][0], Rr[4 * gi + 0], acc0, 0, 0, 0);
@@ -593,6 +629,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                             }
                         };
                         auto mul_b = [&]() {
+                            if (CORR_ABL == 2) { for (int gi = 0; gi < LB; ++gi) acc1 += SB[gi] * Rr[4 * (LA + gi)]; for (int tp = 0; tp < NTL; ++tp) acc1[0] += TB[tp]; return; }
 #pragma unroll
                             for (int gi = 0; gi < LB; ++gi) {
                                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(SB[gi][0], Rr[4 * (LA + gi) + 0], acc0, 0, 0, 0);
@@ -618,24 +655,6 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                                           (cxx >= W - 1 ? SL_XHI : 0) | (cyy < 0 ? SL_YLO : 0) | (cyy >= H - 1 ? SL_YHI : 0);
                             sl[j] = has ? v : 0;
                         }
-                        // the block's reference features from LDS, as lane (n, kq) feeds them to the matrix pipe (every pass anew: they
-                        // would otherwise occupy registers through the vector phases of every further view)
-#pragma unroll
-                        for (int g = 0; g < NCH; ++g) {
-                            const v4f r4 = *reinterpret_cast<const v4f*>(&L.Rs[((g * 4 + kq) * 16 + n) * 4]);
-                            Rr[4 * g + 0] = r4.x; Rr[4 * g + 1] = r4.y; Rr[4 * g + 2] = r4.z; Rr[4 * g + 3] = r4.w;
-                        }
-#pragma unroll
-                        for (int tp = 0; tp < NTL; ++tp) Rr[4 * NCH + tp] = L.Rs[Lds::RS_TAIL + (tp * 4 + kq) * 16 + n];
-                        if (!centred) {
-#pragma unroll
-                            for (int w = 0; w < 4; ++w) {
-                                const v2f pp = *reinterpret_cast<const v2f*>(&L.rp[(w * 16 + n) * 2]);
-                                rr = rr + pp.x; rho = rho + pp.y;
-                            }
-                            centred = true;
-                        }
-
                         if (go) {
                         // wave w: blocks w, w + 4, ... (unrolled with forward exits; loads beyond the list hit the empty entries behind
                         // it and fetch nothing)
@@ -657,8 +676,6 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                     }
                     CSTAMP(7)   // wait for the Gram records
                     LDS_BARRIER();   // X and the Gram records of the pass are complete (or: every wave has seen that it does not fit)
-                    if (tid < 64) { L.cmin[par][tid] = INT_MAX; L.cmax[par][tid] = INT_MIN; }   // (this pass's tables are dead)
-                    if (tid == 0) { L.ired[par][0] = INT_MAX; L.ired[par][1] = INT_MIN; }
                     ++pt;
                     CSTAMP(8)   // barrier: X complete
 
@@ -673,7 +690,8 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                             // (no tap inside the image: the taps read zero, cost = |r|^2 = |r' + mu|^2 -- and NaN where the
                             //  position itself is not finite, as the reference's weights inf - floor(inf) make it)
                             float q = (__builtin_fmaf(2.0f, rho, rr) + M2) + (fw[j] + fn[j]) * 0.0f;
-                            if (sl[j] & SL_VALID) {
+                            if (CORR_ABL == 4) q = q + (float)sl[j] + fw[j];
+                            if (CORR_ABL != 4 && (sl[j] & SL_VALID)) {
                                 const int st = sl[j] & SL_MASK, sb = (sl[j] >> SL_BITS) & SL_MASK;
                                 const float* xr = &L.Xs[n * XSTRIDE];
                                 const float X00 = xr[st], X01 = xr[st + 1], X10 = xr[sb], X11 = xr[sb + 1];
@@ -797,9 +815,10 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                 const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(cost_out + (size_t)b * D * HW), 0, D * HW * 4, 0x00020000);
 #pragma unroll
                 for (int j = 0; j < NC; ++j)   // (planes beyond D lie beyond the descriptor: dropped)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cost[j]), rc, ovoff, (64 * (j >> 2) + 16 * wave + (j & 3)) * HW * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cost[j]), rc, ovoff, (64 * (j >> 2) + 16 * wave + (j & 3)) * HW * 4, CORR_STORE_AUX);
             }
-            if (logp_out || depth_out) {
+            if (CORR_ABL == 5) { if (depth_out && xlive) depth_out[(size_t)b * HW + p] = cost[0] + cost[1] + cost[2] + cost[3]; }
+            else if (logp_out || depth_out) {
                 // per wave: max, sum exp, sum d exp over its planes of pixel n; merged over the four waves through LDS
                 float mx = -INFINITY;
 #pragma unroll
@@ -811,7 +830,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     const int k = 64 * (j >> 2) + 4 * tq + (j & 3);
-                    const float ek = k < D ? exp_nonpos(cost[j] - mx) : 0.0f;
+                    const float ek = k < D ? (CORR_ABL == 8 ? (cost[j] - mx) * 0.01f + 1.0f : exp_nonpos(cost[j] - mx)) : 0.0f;
                     ssum = ssum + ek;
                     esum = __builtin_fmaf(L.dcl[k], ek, esum);
                 }
@@ -819,6 +838,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                 esum = esum + __shfl_xor(esum, 16); esum = esum + __shfl_xor(esum, 32);
                 if (kq == 0) *reinterpret_cast<v4f*>(&L.red[(wave * 16 + n) * 4]) = v4f{mx, ssum, esum, 0.0f};
                 CSTAMP(10)   // epilogue: stores, partial softmax
+                if (CORR_ABL == 9) WAVE_LDS_SYNC(); else
                 LDS_BARRIER();
                 float M = -INFINITY;
 #pragma unroll
@@ -833,12 +853,12 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                     E = __builtin_fmaf(part.z, sc, E);
                 }
                 const float ls = logf(S);
-                if (logp_out) {
+                if (logp_out && !(CORR_ABL == 7 && S != 12345.0f)) {
                     const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(logp_out + (size_t)b * D * HW), 0, D * HW * 4, 0x00020000);
 #pragma unroll
                     for (int j = 0; j < NC; ++j)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (cost[j] - M) - ls), rl, ovoff,
-                                                              (64 * (j >> 2) + 16 * wave + (j & 3)) * HW * 4, 0);
+                                                              (64 * (j >> 2) + 16 * wave + (j & 3)) * HW * 4, CORR_STORE_AUX);
                 }
                 if (depth_out && xlive && tq == 0) depth_out[(size_t)b * HW + p] = E / S;
             }

@@ -41,17 +41,18 @@ __device__ __forceinline__ int stats_row(int i, int nrows, int H) { return min(H
 
 // Block (c, b): mean and variance of channel c of item b over the sampled rows.  POOLED: the channel is avg_pool2d(rgb, rate)
 // of the encoder epilogue (pack_views_kernel), computed on the fly like there.  The samples of a thread are independent
-// loads issued together (8 at a time), then summed: the kernel is a few microseconds of latency, not a dependent chain.
+// loads issued together (32 at a time), then summed: the kernel is a few microseconds of latency, not a dependent chain.
 template <bool POOLED>
 __device__ __forceinline__ void channel_stats(const float* __restrict__ plane, int H, int W, int rate, int IW, float* __restrict__ mu_out,
                                               float* __restrict__ var_out, int centre) {
     __shared__ float scratch[4];
     const int nrows = min(H, STATS_ROWS), total = nrows * W;
     float s = 0.0f, s2 = 0.0f;
-    for (int i0 = threadIdx.x; i0 < total; i0 += 256 * 8) {
-        float v[8];
+    constexpr int NU = POOLED ? 8 : 32;   // samples of a thread in flight together
+    for (int i0 = threadIdx.x; i0 < total; i0 += 256 * NU) {
+        float v[NU];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int i = i0 + 256 * u;
             v[u] = 0.0f;
             if (i < total) {
@@ -68,7 +69,7 @@ __device__ __forceinline__ void channel_stats(const float* __restrict__ plane, i
             }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { s += v[u]; s2 = __builtin_fmaf(v[u], v[u], s2); }
+        for (int u = 0; u < NU; ++u) { s += v[u]; s2 = __builtin_fmaf(v[u], v[u], s2); }
     }
     const float cnt = (float)total;
     const float mean = block_sum_256(s, scratch) / cnt;
