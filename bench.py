@@ -264,7 +264,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, gpu_depth0=None if a.config else depth[0].cpu())
         print(json.dumps(line), flush=True)
     pdist.barrier()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -10,7 +10,7 @@
 //     [statistics: B x STATS_STRIDE floats]                  mu[c] (the constant subtracted per channel; zeros = not centred)
 //                                                            at +0, var[c] at +STATS_VAR
 //
-// Mean-centring (sweep_corr.hip says why): mu[b][c] = mean of channel c over a sample of 16 rows of source view 0 of
+// Mean-centring (sweep_corr.hip says why): mu[b][c] = mean of channel c over a sample of 8 rows of source view 0 of
 // item b -- an estimate is all it takes, the correlation form is exact for ANY constant; what matters is that the
 // residual offset is small against the spread.  Consumers that do not centre (the LDS-tiled kernel: direct form on the
 // near planes) get mu = 0 and the layout is bit for bit the uncentred one; for those the pre-pass also raises
@@ -25,7 +25,7 @@ namespace pdepth {
 namespace {
 
 constexpr int TW = 16, TH = 4;
-constexpr int STATS_ROWS = 16;
+constexpr int STATS_ROWS = 8;
 
 __device__ __forceinline__ float block_sum_256(float v, float* scratch) {
 #pragma unroll

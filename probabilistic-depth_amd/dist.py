@@ -14,12 +14,15 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """(rank, world, local_rank).  Initialises torch.distributed when WORLD_SIZE > 1."""
+def init_from_env(backend=None, force=None):
+    """(rank, world, local_rank).  Initialises torch.distributed when WORLD_SIZE > 1 -- or, with force (argument or
+    PDEPTH_DIST_FORCE=1), also for a single rank: the way the test suite runs the RCCL calls of an N > 1 job on a one-GPU box."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if force is None:
+        force = os.environ.get("PDEPTH_DIST_FORCE") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:

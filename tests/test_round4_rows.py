@@ -1,0 +1,119 @@
+"""Round 4: (1) the HIP ops of EVERY feedback step of a five-frame window on the reference's own tensors (fixture g22,
+tests/golden/make_golden_r4.py) -- teacher forcing: what is asserted per frame is the op, not the 3-D network in front of
+it; (2) the RCCL code path of dist.py / bench.py, once, on the hardware.
+
+  warp_feature                      models/models.py:616-625     1e-5 abs (bit-faithful positions, bilinear taps)
+  log_softmax(BV_cur + BV_resi)     models/models.py:694         2e-5 abs on the log-DPV, 1e-4 m on E[d]
+  the decoder's log_softmax + E[d]  models/models.py:351, trainer/default_trainer.py:230-233   the same bounds
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import pdepth_amd  # noqa: F401
+from pdepth_amd import ops, synth
+from oracle import ref_cpu as O
+from util import golden, golden_blas
+
+DEV = "cuda:0"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LOGP_ATOL, DEPTH_ATOL = 2e-5, 1e-4
+
+
+def _frames(g):
+    hw = [int(v) for v in g["image_hw"]]
+    for frame in range(1, int(g["nframes"])):
+        yield frame, "f%d_" % frame, synth.make_model_input(int(g["input_seed0"]) + frame, B=1, V=1, H=hw[0], W=hw[1], D=64, pose="mono")
+
+
+def test_oracle_reproduces_every_feedback_step_of_the_window():
+    g = golden("g22_feedback_window.npz")
+    for frame, f, inp in _frames(g):
+        upd = torch.log_softmax(torch.from_numpy(g[f + "BV_cur"]) + torch.from_numpy(g[f + "BV_resi"]), dim=1)
+        np.testing.assert_allclose(upd.numpy()[:, ::2], g[f + "BV_upd_even"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(O.dpv_to_depthmap(upd, inp["d_candi"], BV_log=True).numpy(), g[f + "depth_low"], rtol=0, atol=2e-5)
+        dec = torch.log_softmax(torch.from_numpy(g[f + "dec_pre_crop"]), dim=1)
+        np.testing.assert_allclose(dec.numpy()[:, ::2], g[f + "dec_logp_even"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(O.dpv_to_depthmap(dec, inp["d_candi"], BV_log=True).numpy(), g[f + "depth_ref_crop"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_hip_feedback_ops_on_the_reference_tensors_of_every_frame():
+    """Frames 1-4 of the window: the feedback update (reduce_ex with addend), the decoder's DPV pass and warp_feature, each on
+    the tensors the reference had at that point of that frame; depth within 1e-4 m per frame."""
+    g = golden("g22_feedback_window.npz")
+    r0, r1 = [int(v) for v in g["rows"]]
+    worst = {"upd_logp": 0.0, "upd_depth": 0.0, "dec_logp": 0.0, "dec_depth": 0.0, "warp": 0.0}
+    for frame, f, inp in _frames(g):
+        cur, resi = torch.from_numpy(g[f + "BV_cur"]).to(DEV), torch.from_numpy(g[f + "BV_resi"]).to(DEV)
+        r = ops.dpv_reduce_ex(cur, inp["d_candi"], addend=resi, want_logp=True, want_prob=True, want_depth=True)
+        el = np.abs(r["logp"].cpu().numpy()[:, ::2] - g[f + "BV_upd_even"]).max()
+        ed = np.abs(r["depth"].cpu().numpy() - g[f + "depth_low"]).max()
+        assert el <= LOGP_ATOL and ed <= DEPTH_ATOL, f"frame {frame}: feedback update differs by {el:.2e} (log-DPV), {ed:.2e} m"
+        np.testing.assert_allclose(r["prob"].cpu().numpy()[:, ::2], np.exp(g[f + "BV_upd_even"]), rtol=2e-5, atol=1e-7)
+        pre = torch.from_numpy(g[f + "dec_pre_crop"]).to(DEV).contiguous()
+        logp, depth = ops.dpv_reduce(pre, inp["d_candi"])
+        dl = np.abs(logp.cpu().numpy()[:, ::2] - g[f + "dec_logp_even"]).max()
+        dd = np.abs(depth.cpu().numpy() - g[f + "depth_ref_crop"]).max()
+        assert dl <= LOGP_ATOL and dd <= DEPTH_ATOL, f"frame {frame}: decoder DPV pass differs by {dl:.2e} (log-DPV), {dd:.2e} m"
+        # warp_feature on every 4th channel with every 4th plane: channel i only ever meets plane i
+        feat = torch.from_numpy(g[f + "feat_raw_c4"]).to(DEV)            # [1, V+1, 16, h, w]
+        poses, K = inp["src_cam_poses"].to(DEV), inp["intrinsics"].to(DEV)
+        out = ops.warp_feature(feat, K, poses[:, :, :3, :3].contiguous(), poses[:, :, :3, 3].contiguous(), inp["unit_ray"].to(DEV),
+                               K[:, :2, 2].contiguous(), inp["d_candi"][::4], blas=golden_blas(g))
+        ew = np.abs(out.cpu().numpy()[:, :, :, r0:r1] - g[f + "warped_c4"]).max()
+        scale = float(np.abs(g[f + "warped_c4"]).max())
+        assert ew <= 1e-5 * max(1.0, scale), f"frame {frame}: warp_feature differs by {ew:.2e} (values up to {scale:.2f})"
+        for k, v in (("upd_logp", el), ("upd_depth", ed), ("dec_logp", dl), ("dec_depth", dd), ("warp", ew)):
+            worst[k] = max(worst[k], float(v))
+    print("feedback window on reference tensors, worst over frames 1-4:", json.dumps(worst))
+
+
+_RCCL_CHILD = r"""
+import json, os, sys, time
+sys.path.insert(0, {repo!r})
+import torch
+import pdepth_amd
+from pdepth_amd import dist as pdist
+rank, world, local_rank = pdist.init_from_env()
+assert (rank, world, local_rank) == (0, 1, 0), (rank, world, local_rank)
+assert torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl", torch.distributed.get_backend()
+dev = torch.device("cuda", local_rank)
+torch.cuda.set_device(dev)
+m = torch.tensor([4.0, 0.5, 17.25, 1.0], dtype=torch.float32, device=dev)
+allm = pdist.gather_metrics(m).cpu()
+assert tuple(allm.shape) == (1, 4) and torch.equal(allm[0], m.cpu())
+pdist.barrier()
+assert pdist.max_over_ranks(1.25, dev) == 1.25
+lo, hi = pdist.shard_range(4, rank, world)
+assert (lo, hi) == (0, 4)
+torch.distributed.destroy_process_group()
+print(json.dumps({{"backend": "nccl", "world": world, "ok": True}}))
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_path_initialises_on_the_hardware():
+    """dist.py with backend nccl (= RCCL) in a fresh child process, WORLD_SIZE = 1: init_from_env, the all_gather of the metric
+    vector, the MAX all-reduce and the barrier -- the calls bench.py makes at N > 1 -- and then bench.py itself under
+    torch.distributed.run.  The children are started from a parent that may have touched the GPU: they are new processes
+    (subprocess, no exec of this one)."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29731",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PDEPTH_DIST_FORCE="1")
+    p = subprocess.run([sys.executable, "-c", _RCCL_CHILD.format(repo=REPO)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert json.loads(p.stdout.strip().splitlines()[-1])["ok"] is True
+    env2 = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env2["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env2["PDEPTH_DIST_FORCE"] = "1"   # (a single rank would not open a process group otherwise)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29733", os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-cold"], env=env2, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = json.loads([l for l in p.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["value"] > 0 and line["scaling"] == "weak"
