@@ -427,7 +427,7 @@ def dpv_reduce_ex(logits, d_candi, addend=None, want_logp=True, want_prob=False,
     return out
 
 
-def ufield(dpv, d_candi, intr, mask, bv_log, unc_ang, z_start, z_end, min_depth, quash):
+def ufield(dpv, d_candi, intr, mask, bv_log, unc_ang, z_start, z_end, min_depth, quash, d_sum=None):
     """dpv [B,D,H,W], intr [B,3,3], mask [B,H,W] | None -> (plane [B,D,W], depth_zero [B,H,W])  (pdepth_ufield_f32)."""
     lib = load()
     _no_autograd("ufield", dpv)
@@ -445,8 +445,9 @@ def ufield(dpv, d_candi, intr, mask, bv_log, unc_ang, z_start, z_end, min_depth,
             raise RuntimeError(f"ufield: mask must be [{B},{H},{W}], got {tuple(mask.shape)}")
         mask = mask.contiguous().float()
     d_candi = d_candi.contiguous()
-    # depth of rows shifted in from outside the image: dpv_to_depthmap of the zero padding (exp(0) = 1 per plane)
-    oob = float(d_candi.sum().item()) if bv_log else 0.0
+    # depth of rows shifted in from outside the image: dpv_to_depthmap of the zero padding (exp(0) = 1 per plane).  d_sum = that
+    # sum formed by the caller on the host (ops.ufield); a caller that only has the candidates on the device pays one read-back.
+    oob = (float(d_sum) if d_sum is not None else float(d_candi.sum().item())) if bv_log else 0.0
     dev = dpv.device
     ws_bytes = lib.pdepth_ufield_workspace_bytes(B, H, W)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)

@@ -350,8 +350,11 @@ int check_corr(const char* who, int32_t B, int32_t C, int32_t H, int32_t W, int3
                     "reference kernel (needs (kernel_size-1)/2 <= max_displacement mod stride2)", who, k, md, s2);
     if (!pdepth::correlation_output_size(H, W, pad, k, md, s1, oH, oW))
         return fail(PDEPTH_E_ARG, "%s: empty output (pad %d too small for max_displacement %d, kernel %d)", who, pad, md, k);
-    if ((long long)(2 * (md / s2) + 1) * (2 * (md / s2) + 1) * *oH * *oW * B >= (1ll << 40))
-        return fail(PDEPTH_E_ARG, "%s: output too large", who);
+    // (one thread per output / input element in a 1-D grid of 256-thread blocks: below the 2^31 - 1 block limit with room to spare)
+    if ((long long)(2 * (md / s2) + 1) * (2 * (md / s2) + 1) * *oH * *oW * B >= (1ll << 38))
+        return fail(PDEPTH_E_ARG, "%s: output too large for one launch (2^38 elements)", who);
+    if ((long long)B * C * H * W >= (1ll << 38))
+        return fail(PDEPTH_E_ARG, "%s: input too large for one launch (2^38 elements)", who);
     return PDEPTH_OK;
 }
 bool corr_fast_path(int32_t pad, int32_t k, int32_t md, int32_t s1, int32_t s2) {   // the configuration of pwclite.py:123-125 and kin

@@ -667,7 +667,7 @@ hipError_t launch_sweep_cells(const SweepArgs& a, void* workspace, hipStream_t s
     int* flags = reinterpret_cast<int*>(workspace);
     int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + flag_only);
     float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + flag_only + 256);
-    hipError_t e = packed_ready ? clear_sweep_flags(a, workspace, stream) : launch_pack_c4(a, workspace, stream);
+    hipError_t e = packed_ready ? clear_sweep_flags(a, workspace, stream) : launch_pack_c4(a, workspace, stream, /*centre=*/false);
     if (e != hipSuccess) return e;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;

@@ -784,7 +784,7 @@ hipError_t launch_sweep_mfma(const SweepArgs& a, void* workspace, hipStream_t st
     float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + sweep_ws_flag_bytes(a.B, a.H, a.W));
     int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + sweep_ws_flag_only_bytes(a.B, a.H, a.W));
     hipError_t e = hipSuccess;
-    if (phases & PH_PRE) e = packed_ready ? clear_sweep_flags(a, workspace, stream) : launch_pack_c4(a, workspace, stream);
+    if (phases & PH_PRE) e = packed_ready ? clear_sweep_flags(a, workspace, stream) : launch_pack_c4(a, workspace, stream, /*centre=*/false);
     if (e != hipSuccess) return e;
     if (phases & PH_KERNEL) e = launch_by_npl<MFMA_MAX_NPL>((a.C + 3) / 4, a, packed, flags, queue, tiles_x, tiles, stream);
     if (e != hipSuccess || !(phases & PH_GATHER)) return e;

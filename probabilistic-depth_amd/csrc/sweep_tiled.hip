@@ -73,12 +73,8 @@ constexpr int NT = 64 * NW;       // threads per block
 constexpr int KP = 4;             // planes per group
 constexpr int SG = NPG * KP;      // planes per super group
 constexpr int NBUF = 2;           // LDS window buffers: chunk ch+1 is in flight (LDS-DMA) while chunk ch is computed
-#ifndef PDEPTH_NTEX   // experiment knobs (tools/variants.sh): window texels per buffer, blocks per CU
-#define PDEPTH_NTEX (PDEPTH_NSUB == 1 ? 1024 : 1216)
-#endif
-#ifndef PDEPTH_OCC   // waves per SIMD the register allocation must allow (second argument of __launch_bounds__)
+#define PDEPTH_NTEX (PDEPTH_NSUB == 1 ? 1024 : 1216)   // (build constants of the two variants; their tuning history: DESIGN.md of rounds 1-3)
 #define PDEPTH_OCC (PDEPTH_NSUB == 1 ? 3 : 4)
-#endif
 constexpr int NTEX_MAX = PDEPTH_NTEX;    // window texels per buffer (LDS: NTEX_MAX*NBUF*16 B = 32 KB)
 constexpr int BUF_BYTES = NTEX_MAX * 16;   // one window buffer of the direct groups
 // Band mode (see "band group" in the kernel).  Its windows are small, so the 32 KB of the two direct-mode window
@@ -87,55 +83,13 @@ constexpr int BUF_BYTES = NTEX_MAX * 16;   // one window buffer of the direct gr
 //     [2 * BR chunks][4 channels][64 pixels] floats   reference ring (6 KB)
 // and, once the channel loop is done, the last stage -- the two Gram planes -- sits in ring slot 0 and everything
 // behind it (the other slots and the reference ring) holds the X exchange buffer (NX_MAX slots of 256 B).
-#ifndef PDEPTH_BR
 #define PDEPTH_BR (PDEPTH_NSUB == 1 ? 3 : 2)
-#endif
-#ifndef PDEPTH_BAND_TEX
 #define PDEPTH_BAND_TEX (PDEPTH_NSUB == 1 ? 256 : 448)
-#endif
-// Counter experiments only (tools/variants_tiled.sh; the results are WRONG with them): -DPDEPTH_CONF_TAPS / _BANDX /
-// _GRAM replace the per-pixel gather address of one class of LDS reads by the conflict-free lane * 16 (+ a KiB per read), so that the
-// difference in SQ_LDS_BANK_CONFLICT attributes the conflicts to that class.
-#ifndef PDEPTH_ABL_STOP
-#define PDEPTH_ABL_STOP 0
-#endif
-#ifndef PDEPTH_ABL_NOWAIT
-#define PDEPTH_ABL_NOWAIT 0
-#endif
-#ifndef PDEPTH_STEAL   // blocks whose XCD band is exhausted take items of the other bands ...
-#define PDEPTH_STEAL 1
-#endif
-#ifndef PDEPTH_STEAL_ROUNDS   // ... that have more than this many rounds of their own XCD's blocks left
-#define PDEPTH_STEAL_ROUNDS 2
-#endif
-#ifndef PDEPTH_TRY8    // band decision: also try the band group [8, D)
-#define PDEPTH_TRY8 0
-#endif
 // Band boxes follow the epipolar line row by row (1) or are bounding rectangles (0).  Only where the X slots are scarce:
 // the two-tile build has 48 per pixel, and the rectangle of planes [16, D) exceeds them in 17 % of the tiles of the
 // benchmark pose (=> twice the direct work); with 64 slots (one-tile build) the rectangle fits and the shear only costs.
-#ifndef PDEPTH_SHEAR
 #define PDEPTH_SHEAR (PDEPTH_NSUB == 2)
-#endif
-#define PDEPTH_CONF_SEL_TAPS 0
-#define PDEPTH_CONF_SEL_BANDX 0
-#define PDEPTH_CONF_SEL_GRAM 0
-#ifdef PDEPTH_CONF_TAPS
-#undef PDEPTH_CONF_SEL_TAPS
-#define PDEPTH_CONF_SEL_TAPS 1
-#endif
-#ifdef PDEPTH_CONF_BANDX
-#undef PDEPTH_CONF_SEL_BANDX
-#define PDEPTH_CONF_SEL_BANDX 1
-#endif
-#ifdef PDEPTH_CONF_GRAM
-#undef PDEPTH_CONF_SEL_GRAM
-#define PDEPTH_CONF_SEL_GRAM 1
-#endif
-#define PDEPTH_CONF_ADDR(WHICH, addr, salt) (PDEPTH_CONF_SEL_##WHICH ? ((int)(threadIdx.x & 63) * 16 + (salt) * 1024) : (addr))
-#ifndef PDEPTH_NX
 #define PDEPTH_NX (PDEPTH_NSUB == 1 ? 64 : 48)
-#endif
 constexpr int BR = PDEPTH_BR;               // ring depth in stages (BR-1 stages in flight)
 constexpr int BAND_TEX = PDEPTH_BAND_TEX;    // window texels of a band group
 constexpr int BAND_CHUNK_BYTES = BAND_TEX * 16;
@@ -190,10 +144,6 @@ __device__ __forceinline__ void wait_dma_but(int n) {
 }
 // raw barrier: every LDS access of this wave has completed, but VMEM (the DMA of later chunks) stays in flight
 __device__ __forceinline__ void lds_barrier() {
-#ifdef PDEPTH_ABL_NOBAR   // timing experiment (results wrong): what do the per-chunk barriers of the staging loops cost?
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    return;
-#endif
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 __device__ __forceinline__ v4i make_rsrc(const void* base, int bytes) {
@@ -311,7 +261,6 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
         b_ = it / band_tiles;
         const int ti = it - b_ * band_tiles;
         tile_ = band_first_of(qx) + ti;
-#ifndef PDEPTH_NO_BALANCE
         const int tiles_y_ = ntile / tiles_x;
         if (rr == 0 && tiles_y_ % 16 == 0 && tiles_y_ * tiles_x == ntile) {
             // XCD q owns half-bands q and 8 + q of the image's 16 (as the matrix-pipe kernel, sweep_mfma.hip): on a forward
@@ -324,7 +273,6 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
             const int col = (cc & 1) ? tiles_x - 1 - (cc >> 1) : (cc >> 1);
             tile_ = (hbi * hb_rows + r_) * tiles_x + col;
         } else
-#endif
         if (colmajor) {
             // walk the band column by column, so that the blocks in flight on one XCD share a narrow strip of
             // source columns (working set ~1 MB instead of the full image width)
@@ -345,15 +293,13 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     // runs blocks: the last round of a band is quicker on its own XCD (warm L2) than spread over the others.
     const int n_own = band_tiles_of(xcd) * a.B;
     auto steal = [&]() -> int {   // (one thread) index | queue << 24, or -1 when every band is exhausted
-#if PDEPTH_STEAL
 #pragma unroll 1
         for (int j = 1; j < 8; ++j) {
             const int x = (xcd + j) & 7, n = band_tiles_of(x) * a.B;
-            if (n - *(volatile int*)&queue[x] <= PDEPTH_STEAL_ROUNDS * (int)(gridDim.x >> 3)) continue;
+            if (n - *(volatile int*)&queue[x] <= 2 * (int)(gridDim.x >> 3)) continue;
             const int it = atomicAdd(&queue[x], 1);
             if (it < n) return it | (x << 24);
         }
-#endif
         return -1;
     };
     int nxt_own = n_own;   // (thread 0) result of the atomic issued at the top of the tile
@@ -368,13 +314,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     }
     int item = __builtin_amdgcn_readfirstlane(queued ? s_item[0] : ((int)(blockIdx.x >> 3) < n_own ? (int)(blockIdx.x >> 3) | (xcd << 24) : -1));
     int item_par = 0;
-#ifdef PDEPTH_EXIT_STAMPS
-    if (tid == 0) atomicMax(reinterpret_cast<unsigned long long*>(queue + 16) + 4, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
-#endif
     while (item >= 0) {
-#ifdef PDEPTH_EXIT_STAMPS
-    const unsigned long long t_item0 = __builtin_amdgcn_s_memrealtime();
-#endif
     if (tid == 0 && queued && !own_done) nxt_own = atomicAdd(&queue[xcd], 1);
     int b, tile, p; bool live;
     map_item(item, b, tile, live, p);
@@ -519,27 +459,15 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
             const int k1 = aD > 16 ? 16 : 0;
             if (trial(k1)) {
                 commit(k1);
-#if PDEPTH_TRY8
-                // [8, D): half a direct group less, when the box of [16, D) leaves a third of the slots free
-                if (k1 != 0 && NC * NR * 3 <= NX_MAX * 2 && trial(8)) {
-                    commit(8);
-                    if (NC * NR * 3 <= NX_MAX * 2 && trial(0)) commit(0);
-                }
-#else
                 // (with sheared boxes [0, D) only ever fits next to a box of [16, D) of at most a third of the slots:
                 //  `tools/analysis`: 51 % of those tiles, 2 % of the tiles between a third and a half)
                 if (k1 != 0 && NC * NR * (PDEPTH_SHEAR ? 3 : 2) <= NX_MAX && trial(0)) commit(0);
-#endif
             } else {
                 for (int kc = k1 + 16; kc < aD; kc += 16)
                     if (trial(kc)) { commit(kc); break; }
             }
         }
         const int kend = ks;  // planes [0, kend) are evaluated directly
-#if PDEPTH_ABL_STOP == 1   // counter experiments (results wrong): leave the tile after the band decision, ...
-        if (ks + NC + NR + bbx0 + bby0 + gwx0 + gwy0 + gWC + gWR == 0x7ffffff0 && lane == 0) flag_subtile();  // (keeps the decision alive)
-        goto tile_done;
-#endif
 
         for (int k0 = 0; k0 < kend; k0 += SG) {
             // ---- geometry of this thread's KP planes (registers) ----------------------------
@@ -684,9 +612,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
             lds_barrier();  // every reader of the previous part / super group is done with the buffers
             stage(0, 0);
             for (int ch = 0; ch < nchunk; ++ch) {
-#if !(PDEPTH_ABL_NOWAIT & 1)   // timing experiment (results wrong): direct groups do not wait for their DMA
                 wait_dma();
-#endif
                 lds_barrier();
                 if (ch + 1 < nchunk) stage((ch + 1) & 1, ch + 1);
                 {
@@ -700,8 +626,8 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     }
 #define PDEPTH_LOAD(T, i_)                                                          \
     {                                                                               \
-        const lds_v4f q0 = (lds_v4f)(size_t)(unsigned)(PDEPTH_CONF_ADDR(TAPS, off[i_], (i_) & 3) + CUR * NTEX_MAX * 16);        \
-        const lds_v4f q1 = (lds_v4f)(size_t)(unsigned)(PDEPTH_CONF_ADDR(TAPS, off[i_], (i_) & 3) + WCB + CUR * NTEX_MAX * 16);  \
+        const lds_v4f q0 = (lds_v4f)(size_t)(unsigned)(off[i_] + CUR * NTEX_MAX * 16);        \
+        const lds_v4f q1 = (lds_v4f)(size_t)(unsigned)(off[i_] + WCB + CUR * NTEX_MAX * 16);  \
         T[0] = q0[0]; T[1] = q0[1]; T[2] = q1[0]; T[3] = q1[1];                     \
     }
                     // Software pipeline over the part's planes: the four taps of plane i+1 are in flight while
@@ -760,9 +686,6 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
             }
         }
 
-#if PDEPTH_ABL_STOP == 2   // ... after the direct groups, ...
-        goto tile_done;
-#endif
         // ---- band group: planes [ks, D) in correlation form --------------------------------------------
         if (ks < aD) {  // block-uniform
             typedef const __attribute__((address_space(3))) v4f* lds_v4f;
@@ -805,7 +728,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
 #pragma unroll
                 for (int m = 0; m < XPW; ++m) {
                     while (jc >= NC) { jc -= NC; ++jr; }
-                    xaddr[m] = PDEPTH_CONF_ADDR(BANDX, jr < NR ? base + (jr * gWC + jc + row_shift(jr)) * 16 : base, m);
+                    xaddr[m] = (jr < NR ? base + (jr * gWC + jc + row_shift(jr)) * 16 : base);
                     xacc[m] = 0.0f;
                     jc += NPG;
                 }
@@ -814,9 +737,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
             lds_barrier();  // every reader of the previous group is done with the buffers
             for (int st = 0; st < BR - 1 && st < nstage; ++st) stage(st);
             for (int st = 0; st < nstage; ++st) {
-#if !(PDEPTH_ABL_NOWAIT & 2)   // ... the band group does not
                 wait_dma_but(ndma * min(BR - 2, nstage - 1 - st));  // stage st has landed, younger ones stay in flight
-#endif
                 lds_barrier();
                 if (st + BR - 1 < nstage) stage(st + BR - 1);  // into the slot of stage st-1
                 if (st < gstage) {
@@ -894,7 +815,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
                     dt = dx; db = dx;
                 }
                 const int slot = dy * NC + dt, slot_b = (dy + 1) * NC + db;
-                const int tex = PDEPTH_CONF_ADDR(GRAM, ((bby0 + dy - gwy0) * gWC + (bbx0 + dx - gwx0)) * 16, 0);
+                const int tex = (((bby0 + dy - gwy0) * gWC + (bbx0 + dx - gwx0)) * 16);
                 auto xat = [&](int j) { return *(lds_f)(size_t)(unsigned)(xb + j * 256); };
                 const float X00 = xat(slot), X01 = xat(slot + 1), X10 = xat(slot_b), X11 = xat(slot_b + 1);
                 const v4f G00 = *(lds_v4f)(size_t)(unsigned)(g4b + tex);
@@ -916,9 +837,6 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
             if (wave_max_s(viol) != 0 && lane == 0) flag_subtile();  // the gather kernel redoes the sub-tile
         }
     }
-#if PDEPTH_ABL_STOP == 3   // ... or before the epilogue
-    goto tile_done;
-#endif
     __syncthreads();
     {
     // ---- epilogue from LDS: cost store, log-softmax over D, expectation ----------------------
@@ -936,12 +854,8 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
         float mw = -INFINITY;
         for (int k = pgl; k < aD; k += NPG) mw = fmaxf(mw, costs[k * 64 + lane]);
         // (exp_nonpos: 2^(x log2 e) on v_exp_f32 with an exact split of the product, ~1.5 ulp in 9 instructions against
-        //  libm's 20; every argument here is <= 0.  PDEPTH_LIBM_EPILOGUE=1 at build time restores expf.)
-#ifdef PDEPTH_LIBM_EPILOGUE
-#define PDEPTH_EXPNP(x) expf(x)
-#else
+        //  libm's 20; every argument here is <= 0.)
 #define PDEPTH_EXPNP(x) exp_nonpos(x)
-#endif
         float sw = 0.0f;
         for (int k = pgl; k < aD; k += NPG) sw = sw + PDEPTH_EXPNP(costs[k * 64 + lane] - mw);
         float* redm = reft + sub * 512;        // [NPG][64] of this sub-tile
@@ -972,13 +886,6 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     }
     }
 tile_done:
-#ifdef PDEPTH_EXIT_STAMPS   // (diagnostic: the item's duration in 10 ns ticks over the depth of its first pixel, its start over the second)
-    if (tid == 0 && PDEPTH_COLD_ARG(float*, depth_out)) {
-        float* dd = PDEPTH_COLD_ARG(float*, depth_out) + (size_t)b * HW + (tile / tiles_x * TH) * a.W + (tile % tiles_x) * TW * NSUB;
-        dd[0] = (float)(__builtin_amdgcn_s_memrealtime() - t_item0);
-        dd[1] = (float)(t_item0 & 0xffffff);
-    }
-#endif
     if (tid == 0) {   // publish the next item (the barrier below makes it visible)
         int nx = -1;
         if (queued) {
@@ -991,14 +898,6 @@ tile_done:
     item_par ^= 1;
     item = __builtin_amdgcn_readfirstlane(s_item[item_par]);   // (block-uniform)
     }  // work items
-#ifdef PDEPTH_EXIT_STAMPS   // diagnostic build (tools/dbg/tiled_tail.py): when do the persistent blocks run out of work?
-    if (tid == 0) {
-        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-        unsigned long long* st = reinterpret_cast<unsigned long long*>(queue + 16);
-        atomicMax(st + 0, ~t); atomicMax(st + 1, t); atomicAdd(st + 2, t); atomicAdd(st + 3, 1ull);
-        atomicMax(st + 5 + xcd, t);   // (last exit per XCD)
-    }
-#endif
 }
 
 }  // namespace PDEPTH_VARIANT

@@ -122,7 +122,14 @@ def ufield(dpv, d_candi, intr, mask=None, BV_log=True, unc_ang=5, z_start=0.6, z
     (utils/img_utils.py:268-358).  mask [B,H,W] | [B,1,H,W] | None."""
     if mask is not None and mask.dim() == 4:
         mask = mask[:, 0]
-    return _native.ufield(dpv, d_candi_tensor(d_candi, dpv.device), intr, mask, BV_log, unc_ang, z_start, z_end, min_depth, quash)
+    # depth of rows shifted in from outside the image = dpv_to_depthmap of the zero padding = the fp32 sum of the candidates:
+    # formed on the host when the candidates come from the host (no device synchronisation inside the call)
+    d_sum = None
+    if not isinstance(d_candi, torch.Tensor):
+        import numpy as np
+        d_sum = float(torch.from_numpy(np.ascontiguousarray(np.asarray(d_candi), dtype=np.float32)).sum())
+    return _native.ufield(dpv, d_candi_tensor(d_candi, dpv.device), intr, mask, BV_log, unc_ang, z_start, z_end, min_depth, quash,
+                          d_sum=d_sum)
 
 
 def dpv_expect(dpv, d_candi, BV_log=False):
