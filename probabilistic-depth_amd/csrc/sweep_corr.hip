@@ -40,6 +40,7 @@
 #include "geometry.hpp"
 #include "kernels.hpp"
 #include "pick.hpp"
+#include "sweep_corr_knobs.hpp"
 
 namespace pdepth {
 
@@ -48,24 +49,6 @@ namespace {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-#ifndef CORR_OCC1   // waves per SIMD the register allocation must allow: D <= 64 / D <= 128
-#define CORR_OCC1 4
-#endif
-#ifndef CORR_OCC2
-#define CORR_OCC2 3
-#endif
-#ifndef CORR_PREFETCH_PIXEL   // the next block's pixel loads under the epilogue
-#define CORR_PREFETCH_PIXEL 0
-#endif
-#ifndef CORR_STORE_AUX   // cache policy of the output stores: 2 = nt (written once, read by nobody in this launch: -2 % on the
-#define CORR_STORE_AUX 2 // forward-motion pose, whose 8x2 pixel blocks store 32-byte runs)
-#endif
-#ifndef CORR_ABL   // timing experiments (results wrong): 1 no texel loads, 2 no multiplications, 3 no X phase at all, 4 no combine, 5 no
-#define CORR_ABL 0  // softmax epilogue, 6 no Gram transfers
-#endif
-#ifndef CORR_MAXB1   // blocks of 16 texels a pass can take, D <= 64 (LDS: 4 workgroups per CU)
-#define CORR_MAXB1 22
-#endif
 constexpr int MAXROWS = 64;            // source rows per pass (row tables are indexed modulo 64)
 constexpr int BLK_PAD = 12;            // empty entries behind the block list (loads issued beyond it fetch nothing)
 constexpr int OOB = 0x7fffffff;        // buffer offset beyond every descriptor: the load returns 0
@@ -78,14 +61,6 @@ constexpr int SL_BORDER = SL_XLO | SL_XHI | SL_YLO | SL_YHI;
 
 __device__ __forceinline__ int opaque_v(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
-
-// Diagnostic build only (-DCORR_STAMPS, tools/dbg/corr_stamps.py): time per phase in 10 ns ticks, summed over waves, in the spare
-// ints behind the queue counters.  No stamp exists in the product build.
-#ifdef CORR_STAMPS
-#define CSTAMP(idx) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); stamp_acc[idx] += now_ - stamp_t; stamp_t = now_; }
-#else
-#define CSTAMP(idx)
-#endif
 
 // every earlier LDS operation of this wave is done (LDS operations of one wave complete in order)
 #define WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -320,6 +295,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
     int slot_par = 0;
     int pt = 0;           // running pass counter: selects the set of row-table arrays
     int n_direct = 0;     // (thread 0) pixel blocks evaluated directly
+    int b_tables = -1;    // batch item whose tables (means, homography terms, camera constants) are in LDS
     // (thread 0) the atomic on the own queue is issued at the top of an item and its result looked at when the item is done
     int got_own = (tid == 0 && !one_each) ? atomicAdd(&KARG(int*, queue)[xcd], 1) : (int)(blockIdx.x >> 3);
     bool first = true;
@@ -338,38 +314,42 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
         CSTAMP(0)   // queue: publish + barrier
         int b, tx, ty, sub0;
         decode(item, b, tx, ty, sub0);
-        // per item, for every wave: channel means, the views' homography terms, the camera constants (visible behind the
-        // barrier in front of the first block's centring)
-        if (tid < 72) L.mu[tid] = ca.mu_tab[b * STATS_STRIDE + tid];
-        else if (tid < 80 && tid != 72) L.mu[tid] = 0.0f;
-        if (wave == 1) {   // |mu|^2
-            const float* mt = ca.mu_tab + b * STATS_STRIDE;
-            float m2 = 0.0f;
-            if (lane < 36) { const float u0 = mt[lane], u1 = mt[lane + 36]; m2 = __builtin_fmaf(u0, u0, u1 * u1); }
+        // per BATCH item, for every wave: channel means, the views' homography terms, the camera constants (visible behind the
+        // barrier in front of the first block's centring).  Items come out of the queues batch item by batch item: the tables
+        // are rebuilt four times per launch, not once per tile.
+        const bool new_b = b != b_tables;
+        if (new_b) {
+            b_tables = b;
+            if (tid < 72) L.mu[tid] = ca.mu_tab[b * STATS_STRIDE + tid];
+            else if (tid < 80 && tid != 72) L.mu[tid] = 0.0f;
+            if (wave == 1) {   // |mu|^2
+                const float* mt = ca.mu_tab + b * STATS_STRIDE;
+                float m2 = 0.0f;
+                if (lane < 36) { const float u0 = mt[lane], u1 = mt[lane + 36]; m2 = __builtin_fmaf(u0, u0, u1 * u1); }
 #pragma unroll
-            for (int sh = 32; sh >= 1; sh >>= 1) m2 = m2 + __shfl_xor(m2, sh);
-            if (lane == 0) L.mu[72] = m2;
-        }
-        if (tid >= 128 && tid < 128 + V) {
-            const int v = tid - 128;
-            ViewXform xf;
-            make_view_xform(KARG(const float*, a.K) + b * 9, KARG(const float*, a.R) + ((size_t)b * V + v) * 9,
-                            KARG(const float*, a.t) + ((size_t)b * V + v) * 3, ca.a.blas_mode, xf);
+                for (int sh = 32; sh >= 1; sh >>= 1) m2 = m2 + __shfl_xor(m2, sh);
+                if (lane == 0) L.mu[72] = m2;
+            }
+            if (tid >= 128 && tid < 128 + V) {
+                const int v = tid - 128;
+                ViewXform xf;
+                make_view_xform(KARG(const float*, a.K) + b * 9, KARG(const float*, a.R) + ((size_t)b * V + v) * 9,
+                                KARG(const float*, a.t) + ((size_t)b * V + v) * 3, ca.a.blas_mode, xf);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) L.xf[v * 12 + i] = xf.kr[i];
+                for (int i = 0; i < 9; ++i) L.xf[v * 12 + i] = xf.kr[i];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) L.xf[v * 12 + 9 + i] = xf.kt[i];
-        }
-        if (tid == 255) {
-            const float* const cxcy_ = KARG(const float*, a.cxcy);
-            const float cx = cxcy_[b * 2 + 0], cy = cxcy_[b * 2 + 1], sg = KARG(float, a.sigma);
-            L.cst[0] = cx; L.cst[1] = cy; L.cst[2] = refined_rcp(cx); L.cst[3] = refined_rcp(cy);
-            L.cst[4] = (float)W / 2.0f; L.cst[5] = (float)H / 2.0f; L.cst[6] = sg; L.cst[7] = refined_rcp(sg);
+                for (int i = 0; i < 3; ++i) L.xf[v * 12 + 9 + i] = xf.kt[i];
+            }
+            if (tid == 255) {
+                const float* const cxcy_ = KARG(const float*, a.cxcy);
+                const float cx = cxcy_[b * 2 + 0], cy = cxcy_[b * 2 + 1], sg = KARG(float, a.sigma);
+                L.cst[0] = cx; L.cst[1] = cy; L.cst[2] = refined_rcp(cx); L.cst[3] = refined_rcp(cy);
+                L.cst[4] = (float)W / 2.0f; L.cst[5] = (float)H / 2.0f; L.cst[6] = sg; L.cst[7] = refined_rcp(sg);
+            }
         }
         const bool wide = b < 64 ? L.wide[b] != 0 : false;
-        bool item_ready = false;
+        bool item_ready = !new_b;
         float ray[3], rv[MCH];
-        bool loaded = false;   // ray / rv hold the loads of the block about to be processed
         const int spi = ca.spi;
 
         for (int sub = sub0; sub < sub0 + spi; ++sub) {
@@ -386,8 +366,8 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
             const bool xlive = x < W && y < H;
             const int p = min(y, H - 1) * W + min(x, W - 1);
             // the pixel's ray, and this thread's share of the block's reference features: channels tq, tq + 16, ... of pixel n
-            // (buffer loads: 32-bit offsets, the channel as the scalar offset; channels beyond C = 0).  Issued here for the first
-            // block of an item, for the others under the previous block's epilogue.
+            // (buffer loads: 32-bit offsets, the channel as the scalar offset; channels beyond C = 0).  (Issuing them for the next
+            // block under this block's epilogue was measured: slower, the eight registers they hold spill.)
             auto issue_pixel_loads = [&](int p_) {
                 const __amdgpu_buffer_rsrc_t rray =
                     __builtin_amdgcn_make_buffer_rsrc((void*)(ca.a.rays + (size_t)b * 3 * HW), 0, 3 * HW * 4, 0x00020000);
@@ -401,8 +381,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                     rv[mm] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                         rref, tq + 16 * mm < C ? (tq * HW + p_) * 4 : OOB, 16 * mm * HW * 4, 0));
             };
-            if (!loaded) issue_pixel_loads(p);
-            loaded = false;
+            issue_pixel_loads(p);
             CSTAMP(1)   // item set-up, pixel loads issued
             float rr = 0.0f, rho = 0.0f;   // |r'|^2 and <r', mu> of the pixel (set with the first pass)
             bool centred = false;
@@ -521,7 +500,10 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                                 if (fits_) {
                                     const int fb = incl - nblk;
                                     if (lane <= ncell) L.rowoff[lane] = 16 * fb - lo;
-                                    for (int i = 0; i < nblk; ++i) L.blk[fb + i] = ((yb + lane) << 16) | ((lo + 16 * i) & 0xffff);
+#pragma unroll
+                                    for (int i = 0; i < 3; ++i)   // (a row rarely needs more than three blocks: no loop for those)
+                                        if (i < nblk) L.blk[fb + i] = ((yb + lane) << 16) | ((lo + 16 * i) & 0xffff);
+                                    for (int i = 3; i < nblk; ++i) L.blk[fb + i] = ((yb + lane) << 16) | ((lo + 16 * i) & 0xffff);
                                     if (lane < BLK_PAD) L.blk[nb_ + lane] = EMPTY_BLOCK;
                                 }
                             }
@@ -557,7 +539,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
 #endif
                     CSTAMP(5)   // scan
                     // ---- X' = <r', s'> for the blocks of the pass, on the matrix pipe ---------------------------------------
-                    const bool go = fits && nb > 0 && CORR_ABL != 3;
+                    const bool go = fits && nb > 0;
                     int sl[4];
                     {
                         const int myblk = L.blk[min(lane, MAXB + BLK_PAD - 1)];   // the block list in a register: entry l in lane l
@@ -572,7 +554,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
 #pragma unroll
                             for (int c = 0; c < (MAXB * 16 + 255) / 256; ++c) {
                                 const int c64 = (wave + 4 * c) * 64;
-                                if (go && CORR_ABL != 6 && c64 < 16 * nb) {   // (uniform per wave)
+                                if (go && c64 < 16 * nb) {   // (uniform per wave)
                                     const int slot = c64 + lane;
                                     const int be = L.blk[min(slot >> 4, MAXB + BLK_PAD - 1)];
                                     const int yy = be >> 16, xx = (int)(short)(be & 0xffff) + (slot & 15);
@@ -592,34 +574,27 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                             const int be = __builtin_amdgcn_readlane(myblk, bi);
                             const int yy = be >> 16, xx = (int)(short)(be & 0xffff) + n;
                             const bool ok = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
-#ifdef CORR_ABL_ROWWRAP   // timing experiment (results wrong): every texel load from 8 source rows -- an L2-resident source
-                            const int t16 = ((yy & 7) * W + xx) * 16;
-#else
                             const int t16 = (yy * W + xx) * 16;
-#endif
                             vo = opaque_v(ok ? t16 + kq * HW * 16 : OOB);   // (opaque: one load with a selected offset, no branch)
                             if (NTL > 0) vt = opaque_v(ok ? t16 + kq * 4 : OOB);
                         };
                         auto load_a = [&]() {
 #pragma unroll
                             for (int gi = 0; gi < LA; ++gi)
-                                SA[gi] = CORR_ABL == 1 ? v4f{(float)vo, 1.f, 2.f, 3.f}
-                                                       : __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, gi * 4 * HW * 16, 0));
+                                SA[gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, gi * 4 * HW * 16, 0));
                         };
                         auto load_b = [&]() {
 #pragma unroll
                             for (int gi = 0; gi < LB; ++gi)
-                                SB[gi] = CORR_ABL == 1 ? v4f{(float)vo, 1.f, 2.f, 3.f}
-                                                       : __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, (LA + gi) * 4 * HW * 16, 0));
+                                SB[gi] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, (LA + gi) * 4 * HW * 16, 0));
 #pragma unroll
                             for (int tp = 0; tp < NTL; ++tp)
-                                TB[tp] = CORR_ABL == 1 ? (float)vt : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vt, (4 * NCH + tp) * HW * 16, 0));
+                                TB[tp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vt, (4 * NCH + tp) * HW * 16, 0));
                         };
                         // ceil(C/4) MFMAs per block in two alternating accumulator chains (a dependent f32 MFMA waits 40 cycles, an
                         // independent one issues after 32)
                         v4f acc0, acc1;
                         auto mul_a = [&]() {
-                            if (CORR_ABL == 2) { for (int gi = 0; gi < LA; ++gi) acc0 += SA[gi] * Rr[4 * gi]; return; }
 #pragma unroll
                             for (int gi = 0; gi < LA; ++gi) {
                                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(SA[gi][0], Rr[4 * gi + 0], acc0, 0, 0, 0);
@@ -629,7 +604,6 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                             }
                         };
                         auto mul_b = [&]() {
-                            if (CORR_ABL == 2) { for (int gi = 0; gi < LB; ++gi) acc1 += SB[gi] * Rr[4 * (LA + gi)]; for (int tp = 0; tp < NTL; ++tp) acc1[0] += TB[tp]; return; }
 #pragma unroll
                             for (int gi = 0; gi < LB; ++gi) {
                                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(SB[gi][0], Rr[4 * (LA + gi) + 0], acc0, 0, 0, 0);
@@ -690,8 +664,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                             // (no tap inside the image: the taps read zero, cost = |r|^2 = |r' + mu|^2 -- and NaN where the
                             //  position itself is not finite, as the reference's weights inf - floor(inf) make it)
                             float q = (__builtin_fmaf(2.0f, rho, rr) + M2) + (fw[j] + fn[j]) * 0.0f;
-                            if (CORR_ABL == 4) q = q + (float)sl[j] + fw[j];
-                            if (CORR_ABL != 4 && (sl[j] & SL_VALID)) {
+                            if (sl[j] & SL_VALID) {
                                 const int st = sl[j] & SL_MASK, sb = (sl[j] >> SL_BITS) & SL_MASK;
                                 const float* xr = &L.Xs[n * XSTRIDE];
                                 const float X00 = xr[st], X01 = xr[st + 1], X10 = xr[sb], X11 = xr[sb + 1];
@@ -798,13 +771,6 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                 }
                 LDS_BARRIER();   // (every wave is done with the block's reference features: the next block may overwrite them)
             }
-            // the next block of the item: its pixel loads fly under this block's epilogue
-            if (CORR_PREFETCH_PIXEL && sub + 1 < sub0 + spi && (wide ? ty * 4 + sub + 1 : ty * 4 + 2 * ((sub + 1) >> 1)) < H) {
-                const int xn = wide ? tx * 16 + n : tx * 16 + 8 * ((sub + 1) & 1) + (n & 7);
-                const int yn = wide ? ty * 4 + sub + 1 : ty * 4 + 2 * ((sub + 1) >> 1) + (n >> 3);
-                issue_pixel_loads(min(yn, H - 1) * W + min(xn, W - 1));
-                loaded = true;
-            }
             // ---- epilogue: cost store, log-softmax over D, expectation ----------------------------------------------------
             // (buffer stores: one 32-bit lane offset, the plane as the scalar offset: plane 64 h + 16 wave + 4 kq + j)
             const int ovoff = xlive ? (4 * kq * HW + p) * 4 : OOB;
@@ -817,8 +783,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                 for (int j = 0; j < NC; ++j)   // (planes beyond D lie beyond the descriptor: dropped)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cost[j]), rc, ovoff, (64 * (j >> 2) + 16 * wave + (j & 3)) * HW * 4, CORR_STORE_AUX);
             }
-            if (CORR_ABL == 5) { if (depth_out && xlive) depth_out[(size_t)b * HW + p] = cost[0] + cost[1] + cost[2] + cost[3]; }
-            else if (logp_out || depth_out) {
+            if (logp_out || depth_out) {
                 // per wave: max, sum exp, sum d exp over its planes of pixel n; merged over the four waves through LDS
                 float mx = -INFINITY;
 #pragma unroll
@@ -830,7 +795,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     const int k = 64 * (j >> 2) + 4 * tq + (j & 3);
-                    const float ek = k < D ? (CORR_ABL == 8 ? (cost[j] - mx) * 0.01f + 1.0f : exp_nonpos(cost[j] - mx)) : 0.0f;
+                    const float ek = k < D ? exp_nonpos(cost[j] - mx) : 0.0f;
                     ssum = ssum + ek;
                     esum = __builtin_fmaf(L.dcl[k], ek, esum);
                 }
@@ -838,7 +803,6 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                 esum = esum + __shfl_xor(esum, 16); esum = esum + __shfl_xor(esum, 32);
                 if (kq == 0) *reinterpret_cast<v4f*>(&L.red[(wave * 16 + n) * 4]) = v4f{mx, ssum, esum, 0.0f};
                 CSTAMP(10)   // epilogue: stores, partial softmax
-                if (CORR_ABL == 9) WAVE_LDS_SYNC(); else
                 LDS_BARRIER();
                 float M = -INFINITY;
 #pragma unroll
@@ -853,7 +817,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                     E = __builtin_fmaf(part.z, sc, E);
                 }
                 const float ls = logf(S);
-                if (logp_out && !(CORR_ABL == 7 && S != 12345.0f)) {
+                if (logp_out) {
                     const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(logp_out + (size_t)b * D * HW), 0, D * HW * 4, 0x00020000);
 #pragma unroll
                     for (int j = 0; j < NC; ++j)

@@ -1,0 +1,25 @@
+// Build-time constants and diagnostics of sweep_corr.hip (one place for them: the kernel source itself carries no experiment
+// switches).  A product build defines none of these names.
+#pragma once
+
+#ifndef CORR_OCC1   // waves per SIMD the register allocation must allow: D <= 64 / D <= 128
+#define CORR_OCC1 4
+#endif
+#ifndef CORR_OCC2
+#define CORR_OCC2 3
+#endif
+#ifndef CORR_STORE_AUX   // cache policy of the output stores: 2 = nt (written once, read by nobody in this launch: -2 % on the
+#define CORR_STORE_AUX 2 // forward-motion pose, whose 8x2 pixel blocks store 32-byte runs)
+#endif
+#ifndef CORR_MAXB1   // blocks of 16 texels a pass can take, D <= 64 (LDS: 4 workgroups per CU)
+#define CORR_MAXB1 22
+#endif
+
+// Diagnostic build only (-DCORR_STAMPS, tools/dbg/corr_stamps.py): time per phase in 10 ns ticks, summed over waves, in the spare
+// ints behind the queue counters.  No stamp exists in the product build.
+#ifdef CORR_STAMPS
+#define CSTAMP(idx) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); stamp_acc[idx] += now_ - stamp_t; stamp_t = now_; }
+#else
+#define CSTAMP(idx)
+#endif
+
