@@ -866,7 +866,7 @@ hipError_t launch_inst(const SweepArgs& a, const float4* packed, const float* mu
     CorrArgs ca;
     ca.a = a; ca.packed = packed; ca.mu_tab = mu_tab; ca.queue = queue; ca.tiles_x = tiles_x; ca.ntile = tiles;
     // small problems: one pixel block per item, so that every CU gets work
-    ca.spi = (long long)tiles * a.B < 2 * nblk ? 1 : 4;
+    ca.spi = (long long)tiles * a.B < CORR_SPI1_BELOW * nblk ? 1 : 4;
     const long long need = 8ll * ((tiles + 7) / 8) * (4 / ca.spi) * a.B;   // a workgroup per item of the largest XCD band, times 8
     if (need <= nblk) nblk = need;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, stream, ca);

@@ -11,6 +11,9 @@
 #ifndef CORR_STORE_AUX   // cache policy of the output stores: 2 = nt (written once, read by nobody in this launch: -2 % on the
 #define CORR_STORE_AUX 2 // forward-motion pose, whose 8x2 pixel blocks store 32-byte runs)
 #endif
+#ifndef CORR_SPI1_BELOW   // queue items are single pixel blocks (not 16x4 tiles of four) while there are fewer tiles than this many per workgroup
+#define CORR_SPI1_BELOW 2
+#endif
 #ifndef CORR_MAXB1   // blocks of 16 texels a pass can take, D <= 64 (LDS: 4 workgroups per CU)
 #define CORR_MAXB1 22
 #endif

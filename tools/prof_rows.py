@@ -22,8 +22,14 @@ if case == "cfg5":
     f = sweep(2, 128, 512, 1024, 4, "mono")
 elif case == "cfg3":
     f = sweep(4, 64, 256, 512, 1, "stereo")
-elif case == "cfg2_mfma":
-    f = sweep(4, 64, 256, 512, 1, "mono", "mfma")
+elif case == "cfg2_tiled":
+    f = sweep(4, 64, 256, 512, 1, "mono", "tiled2")
+elif case == "model_real_packed":   # BASELINE config 1 as the host model runs it: the sources already in the staging layout
+    b_ = synth.make_batch(2, 1, C=67, D=64, H=64, W=128, V=1, pose="mono")
+    d_ = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in b_.items()}
+    ps_ = ops.pack_source(d_["src"], 64)
+    dc_ = ops.d_candi_tensor(d_["d_candi"], "cuda")
+    f = lambda: ops.sweep_dpv(d_["ref"], ps_, d_["K"], d_["R"], d_["t"], d_["rays"], d_["cxcy"], dc_, 10.0)
 elif case == "model_real":
     f = sweep(4, 64, 64, 128, 1, "mono")
 elif case == "reduce_ex":

@@ -7,7 +7,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/small_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-for case in "1 64 128 auto" "1 64 96 auto" "1 64 128 tiled1" "1 64 128 cells" "4 64 128 auto"; do
+for case in "1 64 128 auto" "1 64 96 auto" "1 64 128 packed" "1 64 128 tiled1" "4 64 128 auto" "4 64 128 packed"; do
   set -- $case
   name=B$1_$2x$3_$4
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name -- python3 tools/dbg/one_sweep.py $1 $2 $3 $4 200 > $out/$name.log 2>&1 || true

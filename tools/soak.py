@@ -1,10 +1,13 @@
 """Soak test on the GPU box: random shapes / poses / depth candidates / metrics, every implementation forced in turn
-(both builds of the tiled kernel, the cell-list kernels where they apply: L2, D <= 128; every fourth case the `auto`
-selection), against the gather kernel, which evaluates in the reference's op order.
+(the correlation-form kernel where it applies -- L2, D <= 128, C <= 72, V <= 8 --, both builds of the tiled kernel; every
+fourth case the `auto` selection), against the gather kernel, which evaluates in the reference's op order.
 
     python tools/soak.py <seed> <cases> [case,case,...] [algo]
 
     SOAK_DPV=1   also the fused outputs (log-DPV, expected depth) and, every fifth case, the packed-source entry
+    SOAK_OFFSET=1  every other case with per-channel offsets of up to 8 standard deviations on reference and source features
+    SOAK_ORACLE=1  a leg against the CPU ORACLE (oracle.sweep_cost_at, its per-pixel form) at 160 sampled pixels per case:
+                   cost, and the depth of the fused output, against the north-star bound (1e-4 m, scaled with the candidates)
     SOAK_SPEC=1  C = 67, D = 64, V = 1 (the compile-time specialised instantiation) at random sizes up to 300 x 560
     third / fourth argument: replay only these case numbers of the seed (the generator is advanced through the others
     without building them), optionally with one implementation forced; a failing case then prints where it differs
@@ -47,6 +50,8 @@ from pdepth_amd import _native, ops, synth  # noqa: E402
 DEV = torch.device("cuda")
 SPEC = bool(os.environ.get("SOAK_SPEC"))
 DPV = bool(os.environ.get("SOAK_DPV"))
+OFFSET = bool(os.environ.get("SOAK_OFFSET"))
+ORACLE = bool(os.environ.get("SOAK_ORACLE"))
 POSES = ("mono", "stereo", "wide", "identity")
 
 
@@ -82,6 +87,11 @@ def draw_case(rng, case, build):
         b["d_candi"] = cand
     elif k == 4:
         b["d_candi"] = np.sort(cand)[::-1].copy()
+    if OFFSET and case % 2 == 0:   # (an own generator: the draws of a seed's cases stay what they were)
+        g = torch.Generator().manual_seed(9000 + case)
+        mu = (torch.rand(C, generator=g) * 2 - 1) * 8.0
+        b["ref"] = b["ref"] + mu[None, :, None, None]
+        b["src"] = b["src"] + mu[None, None, :, None, None]
     return shape, b
 
 
@@ -101,12 +111,41 @@ def where(ca, cd, fin):
         print("   tile", ty, tx, "bad per plane", sub.reshape(sub.shape[0], -1).sum(1).tolist())
 
 
+def oracle_leg(b, d, args, algo, tag, rng):
+    """Item 0 of the case at 160 sampled pixels through the oracle's per-pixel form: cost and fused depth of `algo`."""
+    from oracle import ref_cpu as O
+    H, W, D = b["ref"].shape[2], b["ref"].shape[3], len(b["d_candi"])
+    idx = torch.from_numpy(np.unique(rng.integers(0, H * W, 160))).long()
+    K = b["K"][0]
+    ocost = O.sweep_cost_at(b["ref"][0:1], b["src"][0:1], b["d_candi"], b["R"][0], b["t"][0], K, b["rays"][0], K.numpy()[0, 2], K.numpy()[1, 2],
+                            8.0, idx)                                                     # [1, D, n]
+    odepth = O.dpv_to_depthmap(O.log_dpv(ocost.reshape(1, D, 1, -1)), b["d_candi"], BV_log=True).reshape(-1)
+    cost, _, depth = ops.sweep_dpv(*args, feat_dist="L2", algo=algo, want_cost=True)
+    c_at = cost[0].reshape(D, H * W)[:, idx.to(DEV)].cpu()
+    d_at = depth[0].reshape(H * W)[idx.to(DEV)].cpu()
+    fin = torch.isfinite(ocost[0])
+    if not torch.equal(torch.isfinite(c_at), fin):
+        print(tag, "ORACLE: finiteness of the cost differs")
+        return 0.0
+    cerr = float(((c_at - ocost[0]).abs() - 2e-5 * ocost[0].abs())[fin].max()) if bool(fin.any()) else 0.0
+    if cerr > 2e-4:
+        print(tag, "ORACLE: cost differs by", cerr, "beyond 2e-5 relative")
+    dfin = torch.isfinite(odepth)
+    if not bool(dfin.any()):
+        return 0.0
+    scale = max(1.0, float(np.max(np.abs(b["d_candi"]))) / 40.0)
+    derr = float((d_at - odepth)[dfin].abs().max()) / scale
+    if derr > 1e-4:
+        print(tag, "ORACLE: depth differs by", derr * scale, "(candidates up to", scale * 40.0, "m)")
+    return derr
+
+
 def main():
     rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     only = set(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 and sys.argv[3] else None
     force = sys.argv[4] if len(sys.argv) > 4 else None
-    worst = worst_d = 0.0
+    worst = worst_d = worst_o = 0.0
     n = fb = 0
     for case in range(cases):
         s, b = draw_case(rng, case, build=only is None or case in only)
@@ -114,10 +153,8 @@ def main():
             continue
         d = {kk: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for kk, v in b.items()}
         metric = "L1" if case % 7 == 3 else "L2"
-        algo = ("tiled1", "tiled2", "cells", "mfma")[case % 4]
-        if algo == "mfma" and (metric == "L1" or s["D"] > 128 or s["C"] > 72):
-            algo = "tiled1"
-        if algo == "cells" and (metric == "L1" or s["D"] > 128):
+        algo = ("tiled1", "tiled2", "corr", "corr")[case % 4]
+        if algo == "corr" and (metric == "L1" or s["D"] > 128 or s["C"] > 72):
             algo = "tiled1"
         if algo == "tiled2" and s["D"] > 64:
             algo = "tiled1"
@@ -125,8 +162,8 @@ def main():
             algo = "auto"
         if force:
             algo = force
-            if force == "mfma" and (metric == "L1" or s["D"] > 128 or s["C"] > 72):
-                algo = "tiled1"   # (shapes the matrix-pipe kernel is not built for)
+            if force == "corr" and (metric == "L1" or s["D"] > 128 or s["C"] > 72):
+                algo = "tiled1"   # (shapes the correlation-form kernel is not built for)
         args = (d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 8.0)
         tag = describe(case, algo, s, metric)
         if DPV:
@@ -144,7 +181,7 @@ def main():
                         print(tag, "depth differs by", de, "(candidates up to", scale * 40.0, "m)")
             if case % 5 == 0 and algo in ("auto", "tiled1", "tiled2") and metric == "L2" and s["C"] <= 68:
                 try:
-                    ps = ops.pack_source(d["src"], s["D"])
+                    ps = ops.pack_source(d["src"], s["D"], "auto", metric)
                     cp, _, dp = ops.sweep_dpv(d["ref"], ps, *args[2:], feat_dist=metric, algo="auto", want_cost=True)
                     ca2, _, da2 = ops.sweep_dpv(*args, feat_dist=metric, algo="auto", want_cost=True)
                     if not (torch.equal(cp.nan_to_num(), ca2.nan_to_num()) and torch.equal(dp.nan_to_num(), da2.nan_to_num())):
@@ -152,6 +189,8 @@ def main():
                 except RuntimeError as e:   # shapes the packed entry declines
                     if "packed" not in str(e):
                         raise
+        if ORACLE and metric == "L2" and case % 3 == 0:
+            worst_o = max(worst_o, oracle_leg(b, d, args, algo, tag, np.random.default_rng(77 + case)))
         ca = ops.sweep_cost(*args, feat_dist=metric, algo=algo).cpu().numpy()
         fb += _native.fallback_tiles(s["B"], s["H"], s["W"])
         cd = ops.sweep_cost(*args, feat_dist=metric, algo="direct").cpu().numpy()
@@ -167,7 +206,8 @@ def main():
                 print(tag, "err", err)
                 if only is not None:
                     where(ca, cd, fin)
-    print("cases", n, "worst", worst, "fallback tiles", fb, ("worst depth difference (scaled) %.3e" % worst_d) if DPV else "")
+    print("cases", n, "worst", worst, "fallback tiles", fb, ("worst depth difference (scaled) %.3e" % worst_d) if DPV else "",
+          ("worst depth difference from the ORACLE at the sampled pixels (scaled) %.3e" % worst_o) if ORACLE else "")
 
 
 if __name__ == "__main__":
