@@ -48,7 +48,7 @@ __device__ __forceinline__ void channel_stats(const float* __restrict__ plane, i
     __shared__ float scratch[4];
     const int nrows = min(H, STATS_ROWS), total = nrows * W;
     float s = 0.0f, s2 = 0.0f;
-    constexpr int NU = POOLED ? 8 : 32;   // samples of a thread in flight together
+    constexpr int NU = 32;   // samples of a thread in flight together
     for (int i0 = threadIdx.x; i0 < total; i0 += 256 * NU) {
         float v[NU];
 #pragma unroll
@@ -58,11 +58,9 @@ __device__ __forceinline__ void channel_stats(const float* __restrict__ plane, i
             if (i < total) {
                 const int r = i / W, x = i - r * W, y = stats_row(r, nrows, H);
                 if (POOLED) {
-                    const float* p = plane + ((size_t)y * rate) * IW + (size_t)x * rate;
-                    float sum = 0.0f;
-                    for (int j = 0; j < rate; ++j)
-                        for (int ii = 0; ii < rate; ++ii) sum += p[(size_t)j * IW + ii];
-                    v[u] = sum / (float)(rate * rate);
+                    // (the mean of the pooled channel = the mean of the image itself: one image row per sampled map row, every
+                    //  rate-th column -- the variance, which only feeds the tiled kernel's guard, is the image's, an upper bound)
+                    v[u] = plane[((size_t)y * rate) * IW + (size_t)x * rate];
                 } else {
                     v[u] = plane[(size_t)y * W + x];
                 }
@@ -248,6 +246,14 @@ __global__ __launch_bounds__(256) void pack_views_kernel(const float* __restrict
     auto pooled = [&](int c, int py, int px) -> float {   // avg_pool2d(rgb, rate)[c, py, px]
         const float* p = im + ((size_t)c * IH + (size_t)py * rate) * IW + (size_t)px * rate;
         float sum = 0.0f;
+        if (rate == 4 && (IW & 3) == 0) {   // (the reference's quarter-resolution sweep: a window row is one 16-byte load; same order of the sum)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 q = *reinterpret_cast<const float4*>(p + (size_t)j * IW);
+                sum += q.x; sum += q.y; sum += q.z; sum += q.w;
+            }
+            return sum / 16.0f;
+        }
         for (int j = 0; j < rate; ++j)
             for (int i = 0; i < rate; ++i) sum += p[(size_t)j * IW + i];
         return sum / (float)(rate * rate);
@@ -262,13 +268,55 @@ __global__ __launch_bounds__(256) void pack_views_kernel(const float* __restrict
     const int ngrp = (C + 3) / 4;
     float4* o = out + (size_t)(b * V + v) * (ngrp + 2) * HW + pix;
     float n = 0.f, h = 0.f, vv = 0.f, d1 = 0.f, d2 = 0.f, mm = 0.f;
-    for (int g = 0; g < ngrp; ++g) {
+    const int i01 = hr ? 1 : 0, i10 = hd ? W : 0;
+    auto accumulate = [&](float s00, float s01, float s10, float s11, float u) {
+        n = __builtin_fmaf(s00, s00, n);
+        h = __builtin_fmaf(s00, s01, h);
+        vv = __builtin_fmaf(s00, s10, vv);
+        d1 = __builtin_fmaf(s00, s11, d1);
+        d2 = __builtin_fmaf(s01, s10, d2);
+        mm = __builtin_fmaf(s00, u, mm);
+    };
+    // the groups of encoder channels: software-pipelined like pack_c4_kernel (16 loads of the next group in flight)
+    const int gfeat = Cf / 4;   // groups that hold encoder channels only
+    auto issue = [&](int g, float(&v_)[16]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* sc = f + (size_t)(g * 4 + j) * HW;
+            v_[4 * j + 0] = sc[0]; v_[4 * j + 1] = sc[i01]; v_[4 * j + 2] = sc[i10]; v_[4 * j + 3] = sc[i01 + i10];
+        }
+    };
+    auto finish = [&](int g, const float(&v_)[16]) {
+        float c4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float u = mu[min(g * 4 + j, STATS_VAR - 1)];   // (zero everywhere when the consumer does not centre)
+            const float s00 = v_[4 * j + 0] - u;
+            c4[j] = s00;
+            accumulate(s00, hr ? v_[4 * j + 1] - u : 0.f, hd ? v_[4 * j + 2] - u : 0.f, hr && hd ? v_[4 * j + 3] - u : 0.f, u);
+        }
+        o[(size_t)g * HW] = make_float4(c4[0], c4[1], c4[2], c4[3]);
+    };
+    float va[16], vb[16];
+    if (gfeat > 0) issue(0, va);
+    for (int g = 0; g < gfeat; g += 2) {
+        if (g + 1 < gfeat) issue(g + 1, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(g, va);
+        if (g + 1 < gfeat) {
+            if (g + 2 < gfeat) issue(g + 2, va);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(g + 1, vb);
+        }
+    }
+    // the groups that hold left-over encoder channels and the pooled image
+    for (int g = gfeat; g < ngrp; ++g) {
         float c4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = g * 4 + j;
             float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
-            const float u = mu[min(c, STATS_VAR - 1)];   // (zero beyond C, zero everywhere when the consumer does not centre)
+            const float u = mu[min(c, STATS_VAR - 1)];   // (zero beyond C)
             if (c < Cf) {
                 const float* sc = f + (size_t)c * HW;
                 s00 = sc[0] - u;
@@ -282,12 +330,7 @@ __global__ __launch_bounds__(256) void pack_views_kernel(const float* __restrict
                 s11 = hr && hd ? pooled(c - Cf, y + 1, x + 1) - u : 0.f;
             }
             c4[j] = s00;
-            n = __builtin_fmaf(s00, s00, n);
-            h = __builtin_fmaf(s00, s01, h);
-            vv = __builtin_fmaf(s00, s10, vv);
-            d1 = __builtin_fmaf(s00, s11, d1);
-            d2 = __builtin_fmaf(s01, s10, d2);
-            mm = __builtin_fmaf(s00, u, mm);
+            accumulate(s00, s01, s10, s11, u);
         }
         o[(size_t)g * HW] = make_float4(c4[0], c4[1], c4[2], c4[3]);
     }
