@@ -40,6 +40,7 @@ constexpr int NONCENTRED_SLOT = 51;        // set by the pre-pass of a NOT centr
 constexpr int CORR_DONE_SLOT = 52;         // sweep_corr.hip: workgroups that have left (the last one zeroes the queue counters)
 constexpr int CORR_DIRECT_SLOT = 53;       // ... pixel blocks evaluated directly, this call so far / of the last finished call
 constexpr int CORR_DIRECT_LAST_SLOT = 54;
+constexpr int CORR_PACK_TIMEOUT_SLOT = 55;   // ... workgroups that gave up waiting for the in-kernel pack (never, unless the counters were corrupted)
 // channel statistics of the source (workspace tail, sweep_pack.hip): per batch item mu[c] at +0, var[c] at +STATS_VAR, the
 // squared offset that was NOT subtracted at +STATS_OFF
 constexpr int STATS_VAR = 80, STATS_OFF = 160, STATS_STRIDE = 240;
@@ -66,6 +67,10 @@ hipError_t launch_sweep_tiled_n2(const SweepArgs& a, void* workspace, hipStream_
 // sweep_pack.hip: pre-pass of the packed-source kernels (channel statistics + packed source + Gram planes; clears flags and
 // queue counters).  centre: subtract the channel means (sweep_corr.hip); else the plain layout (mu = 0)
 hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t stream, bool centre);
+// ... of a call whose sweep kernel packs the source itself: statistics + workspace bookkeeping only
+hipError_t launch_stats_only(const SweepArgs& a, void* workspace, hipStream_t stream);
+bool sweep_ws_holds_pack_counters(int B, int H, int W);
+int* sweep_ws_pack_counters(const SweepArgs& a, void* workspace);
 hipError_t clear_sweep_flags(const SweepArgs& a, void* workspace, hipStream_t stream);
 // encoder epilogue: cat(feat, avg_pool2d(rgb)) -> packed source views + NCHW reference view, in one pass (a.C = Cf + 3)
 hipError_t launch_pack_views(const SweepArgs& a, const float* feat, const float* rgb, int rate, int img_h, int img_w, float* ref_out,

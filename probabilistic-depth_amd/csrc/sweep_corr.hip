@@ -35,10 +35,13 @@
 //       call on an already packed source is this one launch.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <climits>
 
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "pack_body.hpp"
 #include "pick.hpp"
 #include "sweep_corr_knobs.hpp"
 
@@ -157,6 +160,10 @@ struct CorrArgs {
     const float* mu_tab;
     int* queue;
     int tiles_x, ntile, spi;
+    // the kernel packs the source itself (NCHW entry): pack items per batch item (0: the packed source is ready) and the
+    // counters [2 b] = items of batch item b handed out, [2 b + 1] = items finished (zero at launch, zeroed on the way out)
+    int npack;
+    int* pack_ctr;
 };
 template <typename T>
 __device__ __forceinline__ T cold_arg(size_t offset) {
@@ -190,6 +197,8 @@ struct __attribute__((aligned(16))) CorrLds {
     int ired[2][2];              // min / max cell row of the pass; two sets
     int tab[4];                  // wave 0's row table of the pass: blocks, fits, first row
     int item[2];                 // work item: current / next
+    int pk;                      // pack item
+    float mun[80];               // channel means of the batch item that is being packed
     unsigned char wide[64];      // per batch item: pixel blocks are 16x1 (else 8x2)
 };
 
@@ -288,6 +297,45 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
     // (when the grid covers every item -- small problems -- workgroup i takes item i of its XCD's band: no atomics)
     const bool one_each = (long long)gridDim.x >= 8ll * ((KARG(int, ntile) + 7) / 8) * (4 / ca.spi) * KARG(int, a.B);
     __syncthreads();
+    // ---- the pre-pass inside the sweep (NCHW entry) -------------------------------------------------------------------
+    // The source of batch item b + 1 is packed while item b is swept: a workgroup that finishes a pixel block of item b
+    // takes a pack item of b + 1 (256 texels of one view: sweep_pack.hip's layout, pack_body.hpp's arithmetic) as long as
+    // there are any, and a workgroup that reaches item b for the first time takes what is left of b's own and then waits
+    // for the count of finished items.  No item waits on anything once it is taken, so the wait ends.  Visibility across the XCDs' L2s:
+    // the packed planes are stored write-through (sc1) and released at agent scope before the count goes up; no line of
+    // them is in any cache before that -- they are first read after the wait (caches are clean at launch).
+    const int npack = KARG(int, npack);
+    int mun_b = -1;       // batch item whose means are in L.mun
+    int pack_dry = -1;    // the pack queues of batch items <= this are exhausted
+    auto pack_take = [&](int pb) -> bool {
+        if (tid == 0) L.pk = atomicAdd(&KARG(int*, pack_ctr)[2 * pb], 1);
+        LDS_BARRIER();
+        const int ip = __builtin_amdgcn_readfirstlane(*(volatile int*)&L.pk);
+        if (ip >= npack) { pack_dry = pb; return false; }
+        if (mun_b != pb) {
+            mun_b = pb;
+            if (tid < 80) L.mun[tid] = ca.mu_tab[pb * STATS_STRIDE + tid];
+            LDS_BARRIER();
+        }
+        const int HW = H * W, nblk = (HW + 255) >> 8;
+        const int vsel = ip / nblk, pix = (ip - vsel * nblk) * 256 + tid;
+        if (pix < HW) {
+            const int y = pix / W, x = pix - y * W;
+            const float* s = KARG(const float*, a.src) + (size_t)pb * KARG(long long, a.src_bstride) + (size_t)vsel * KARG(long long, a.src_vstride) + pix;
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(ca.packed + ((size_t)pb * V + vsel) * (NPL + 2) * HW), 0, (NPL + 2) * HW * 16, 0x00020000);
+            pack_texel<true>(s, C, HW, W, x + 1 < W, y + 1 < H, L.mun, [&](int g, float4 q) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, q), ro, pix * 16, g * HW * 16, CORR_PACK_AUX);
+            });
+        }
+        // (a release fence at agent scope here writes the whole L2 back -- the sweep's own output included -- per item:
+        //  measured 0.96 ms per call instead of 0.67)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have reached memory
+        LDS_BARRIER();
+        if (tid == 0) atomicAdd(&KARG(int*, pack_ctr)[2 * pb + 1], 1);
+        return true;
+    };
+
 #ifdef CORR_STAMPS
     unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_t = __builtin_amdgcn_s_memrealtime();
@@ -318,6 +366,23 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
         // barrier in front of the first block's centring).  Items come out of the queues batch item by batch item: the tables
         // are rebuilt four times per launch, not once per tile.
         const bool new_b = b != b_tables;
+        if (npack > 0) {
+            // the first item of batch item b: what is left of b's pack items, then the wait for all of them; every other
+            // item: one pack item of b + 1, if there is any left
+            const int pb = new_b ? b : b + 1;
+            if (pb < KARG(int, a.B))
+                while (pack_dry < pb && pack_take(pb) && new_b) {}
+            if (new_b) {
+                if (tid == 0) {
+                    int* done = &KARG(int*, pack_ctr)[2 * b + 1];
+                    // (bounded: a call that got here with broken counters ends with wrong numbers and a raised slot, not with a hung GPU)
+                    int spins = 0;
+                    while (atomicAdd(done, 0) < npack && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(8);
+                    if (spins >= (1 << 20)) atomicAdd(&KARG(int*, queue)[CORR_PACK_TIMEOUT_SLOT], 1);
+                }
+                LDS_BARRIER();
+            }
+        }
         if (new_b) {
             b_tables = b;
             if (tid < 72) L.mu[tid] = ca.mu_tab[b * STATS_STRIDE + tid];
@@ -844,13 +909,18 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
             for (int q = 0; q < 8; ++q) queue[q] = 0;
             queue[CORR_DONE_SLOT] = 0;
             queue[CORR_DIRECT_SLOT] = 0;
+            if (npack > 0) {
+                int* pc = KARG(int*, pack_ctr);
+                for (int i = 0; i < 2 * KARG(int, a.B); ++i) pc[i] = 0;
+            }
             queue[CORR_DIRECT_LAST_SLOT] = nd;   // diagnostics: pixel blocks of this call evaluated directly
         }
     }
 }
 
 template <int NPL, int NH>
-hipError_t launch_inst(const SweepArgs& a, const float4* packed, const float* mu_tab, int* queue, int tiles_x, int tiles, hipStream_t stream) {
+hipError_t launch_inst(const SweepArgs& a, const float4* packed, const float* mu_tab, int* queue, int tiles_x, int tiles, int npack, int* pack_ctr,
+                       hipStream_t stream) {
     auto kern = sweep_corr_kernel<NPL, NH>;
     // persistent grid: as many workgroups as the chip holds at once (registers and LDS decide: asked once per
     // instantiation and device), a multiple of 8; fewer when there is less work
@@ -865,6 +935,7 @@ hipError_t launch_inst(const SweepArgs& a, const float4* packed, const float* mu
     long long nblk = ((long long)sweep_device_cus() * per_cu[dev] + 7) & ~7ll;
     CorrArgs ca;
     ca.a = a; ca.packed = packed; ca.mu_tab = mu_tab; ca.queue = queue; ca.tiles_x = tiles_x; ca.ntile = tiles;
+    ca.npack = npack; ca.pack_ctr = pack_ctr;
     // small problems: one pixel block per item, so that every CU gets work
     ca.spi = (long long)tiles * a.B < CORR_SPI1_BELOW * nblk ? 1 : 4;
     const long long need = 8ll * ((tiles + 7) / 8) * (4 / ca.spi) * a.B;   // a workgroup per item of the largest XCD band, times 8
@@ -875,11 +946,11 @@ hipError_t launch_inst(const SweepArgs& a, const float4* packed, const float* mu
 
 template <int NPL>
 hipError_t launch_by_npl(int npl, const SweepArgs& a, const float4* packed, const float* mu_tab, int* queue, int tiles_x, int tiles,
-                         hipStream_t stream) {
+                         int npack, int* pack_ctr, hipStream_t stream) {
     if (npl == NPL)
-        return a.D <= 64 ? launch_inst<NPL, 1>(a, packed, mu_tab, queue, tiles_x, tiles, stream)
-                         : launch_inst<NPL, 2>(a, packed, mu_tab, queue, tiles_x, tiles, stream);
-    if constexpr (NPL > 1) return launch_by_npl<NPL - 1>(npl, a, packed, mu_tab, queue, tiles_x, tiles, stream);
+        return a.D <= 64 ? launch_inst<NPL, 1>(a, packed, mu_tab, queue, tiles_x, tiles, npack, pack_ctr, stream)
+                         : launch_inst<NPL, 2>(a, packed, mu_tab, queue, tiles_x, tiles, npack, pack_ctr, stream);
+    if constexpr (NPL > 1) return launch_by_npl<NPL - 1>(npl, a, packed, mu_tab, queue, tiles_x, tiles, npack, pack_ctr, stream);
     return hipErrorInvalidValue;
 }
 
@@ -895,18 +966,32 @@ bool sweep_corr_supports(const SweepArgs& a) {
            hw * a.D * 4 < (1ll << 31) && hw * a.C * 4 < (1ll << 31) && hw * (npl + 2) * 16 < (1ll << 31) && hw * 12 < (1ll << 31);
 }
 
-// Launches the pre-pass (channel means, then the packed centred source; unless the workspace is already packed) and the
-// sweep kernel.
+// Launches the pre-pass and the sweep kernel.  NCHW entry: channel means and pack kernel (launch_pack_c4), then the sweep
+// kernel -- or, on request, the channel means and a sweep kernel that packs the centred source itself, batch item b + 1
+// under the sweep of item b.  Packed entry: the sweep kernel alone.
 hipError_t launch_sweep_corr(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready) {
     const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 3) / 4, tiles = tiles_x * tiles_y;
     float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + sweep_ws_flag_bytes(a.B, a.H, a.W));
     int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + sweep_ws_flag_only_bytes(a.B, a.H, a.W));
     const float* mu_tab = reinterpret_cast<const float*>(static_cast<char*>(workspace) + sweep_ws_stats_offset(a.B, a.V, a.C, a.H, a.W));
+    int npack = 0;
+    int* pack_ctr = nullptr;
     if (!packed_ready) {
-        hipError_t e = launch_pack_c4(a, workspace, stream, /*centre=*/true);
-        if (e != hipSuccess) return e;
+        const long long items = (long long)a.V * ((a.H * a.W + 255) / 256);
+        // (measured slower than the pack kernel in front -- profiles/r04_ab/fuse_pack_*.txt, DESIGN.md section 3 -- and so
+        //  only on request: PDEPTH_CORR_FUSE_PACK=1)
+        const char* fuse = getenv("PDEPTH_CORR_FUSE_PACK");
+        if (fuse && fuse[0] == '1' && sweep_ws_holds_pack_counters(a.B, a.H, a.W) && items < (1ll << 30)) {
+            hipError_t e = launch_stats_only(a, workspace, stream);
+            if (e != hipSuccess) return e;
+            npack = (int)items;
+            pack_ctr = sweep_ws_pack_counters(a, workspace);
+        } else {
+            hipError_t e = launch_pack_c4(a, workspace, stream, /*centre=*/true);
+            if (e != hipSuccess) return e;
+        }
     }
-    return launch_by_npl<CORR_MAX_NPL>((a.C + 3) / 4, a, packed, mu_tab, queue, tiles_x, tiles, stream);
+    return launch_by_npl<CORR_MAX_NPL>((a.C + 3) / 4, a, packed, mu_tab, queue, tiles_x, tiles, npack, pack_ctr, stream);
 }
 
 }  // namespace pdepth

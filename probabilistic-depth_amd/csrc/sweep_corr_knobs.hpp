@@ -14,6 +14,9 @@
 #ifndef CORR_SPI1_BELOW   // queue items are single pixel blocks (not 16x4 tiles of four) while there are fewer tiles than this many per workgroup
 #define CORR_SPI1_BELOW 2
 #endif
+#ifndef CORR_PACK_AUX   // cache policy of the in-kernel pack's stores: 16 = sc1 (write-through to memory: the other XCDs read them)
+#define CORR_PACK_AUX 16
+#endif
 #ifndef CORR_MAXB1   // blocks of 16 texels a pass can take, D <= 64 (LDS: 4 workgroups per CU)
 #define CORR_MAXB1 22
 #endif

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels.hpp"
+#include "pack_body.hpp"
 #include "pick.hpp"
 
 namespace pdepth {
@@ -82,9 +83,18 @@ __device__ __forceinline__ void channel_stats(const float* __restrict__ plane, i
     }
 }
 
+// flags != nullptr: the call's workspace bookkeeping is done here (the sweep kernel that packs the source itself has no
+// pack kernel in front of it): tile flags and queue slots cleared, the pack counters of the sweep kernel zeroed.
 __global__ __launch_bounds__(256) void feature_stats_kernel(const float* __restrict__ src, long long bstride, int C, int H, int W,
-                                                            float* __restrict__ stats, int centre) {
+                                                            float* __restrict__ stats, int centre, int* __restrict__ flags, int nflags,
+                                                            int* __restrict__ pack_ctr, int nctr) {
     const int c = blockIdx.x, b = blockIdx.y;
+    if (flags) {
+        // (nflags covers the tile flags and the 64 queue ints behind them)
+        for (int i = (b * gridDim.x + c) * 256 + threadIdx.x; i < nflags; i += gridDim.x * gridDim.y * 256) flags[i] = 0;
+        if (c == 0 && b == 0)
+            for (int i = threadIdx.x; i < nctr; i += 256) pack_ctr[i] = 0;
+    }
     float* st = stats + (size_t)b * STATS_STRIDE;
     if (c == 0 && threadIdx.x < STATS_VAR - C && C + (int)threadIdx.x < STATS_VAR) {   // channels beyond C
         st[C + threadIdx.x] = 0.0f; st[STATS_VAR + C + threadIdx.x] = 0.0f; st[STATS_OFF + C + threadIdx.x] = 0.0f;
@@ -162,55 +172,7 @@ __global__ __launch_bounds__(256) void pack_c4_kernel(const float* __restrict__ 
     const float* s = src + (size_t)(bv / V) * bstride + (size_t)(bv % V) * vstride + pix;
     const int ngrp = (C + 3) / 4;
     float4* o = out + (size_t)bv * (ngrp + 2) * HW + pix;
-    float n = 0.f, h = 0.f, vv = 0.f, d1 = 0.f, d2 = 0.f, mm = 0.f;
-    // (branch-free: the neighbours beyond the image are loaded from the texel itself and then dropped)
-    const int i01 = hr ? 1 : 0, i10 = hd ? W : 0;
-    // a channel group = 16 loads (4 channels x the texel and its three neighbours); the next group's loads are issued before
-    // the current one is used, so that 32 loads per thread are in flight (the kernel is a stream: latency is all that it
-    // can lose -- the compiler's own schedule waits for every channel's loads before it issues the next channel's)
-    auto issue = [&](int g, float(&v)[16]) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = g * 4 + j;
-            const float* sc = s + (size_t)min(c, C - 1) * HW;   // (channels beyond C: loaded from the last one, dropped below)
-            v[4 * j + 0] = sc[0]; v[4 * j + 1] = sc[i01]; v[4 * j + 2] = sc[i10]; v[4 * j + 3] = sc[i01 + i10];
-        }
-    };
-    auto finish = [&](int g, const float(&v)[16]) {
-        float c4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = g * 4 + j;
-            const float u = CENTRE ? mu[c] : 0.0f;   // (channels beyond C: 0, the statistics kernels pad with zeros)
-            const bool in = c < C;   // uniform
-            const float s00 = in ? v[4 * j + 0] - u : 0.f;
-            const float s01 = in && hr ? v[4 * j + 1] - u : 0.f;
-            const float s10 = in && hd ? v[4 * j + 2] - u : 0.f;
-            const float s11 = in && hr && hd ? v[4 * j + 3] - u : 0.f;
-            c4[j] = s00;
-            n = __builtin_fmaf(s00, s00, n);
-            h = __builtin_fmaf(s00, s01, h);
-            vv = __builtin_fmaf(s00, s10, vv);
-            d1 = __builtin_fmaf(s00, s11, d1);
-            d2 = __builtin_fmaf(s01, s10, d2);
-            mm = __builtin_fmaf(s00, u, mm);
-        }
-        o[(size_t)g * HW] = make_float4(c4[0], c4[1], c4[2], c4[3]);
-    };
-    float va[16], vb[16];
-    issue(0, va);
-    for (int g = 0; g < ngrp; g += 2) {
-        if (g + 1 < ngrp) issue(g + 1, vb);
-        __builtin_amdgcn_sched_barrier(0);
-        finish(g, va);
-        if (g + 1 < ngrp) {
-            if (g + 2 < ngrp) issue(g + 2, va);
-            __builtin_amdgcn_sched_barrier(0);
-            finish(g + 1, vb);
-        }
-    }
-    o[(size_t)ngrp * HW] = make_float4(n, h, vv, d1 + d2);
-    o[(size_t)(ngrp + 1) * HW] = make_float4(mm, 0.f, 0.f, 0.f);
+    pack_texel<CENTRE>(s, C, HW, W, hr, hd, mu, [&](int g, float4 q) { o[(size_t)g * HW] = q; });
 }
 
 // Encoder epilogue: what the host model does between its feature encoder and the sweep --
@@ -381,7 +343,7 @@ hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t strea
     float* stats = reinterpret_cast<float*>(static_cast<char*>(workspace) + sweep_ws_stats_offset(a.B, a.V, a.C, a.H, a.W));
     const int HW = a.H * a.W;
     hipLaunchKernelGGL(feature_stats_kernel, dim3(a.C < STATS_VAR ? a.C : STATS_VAR, a.B), dim3(256), 0, stream, a.src, a.src_bstride, a.C,
-                       a.H, a.W, stats, (centre && a.C <= 72) ? 1 : 0);
+                       a.H, a.W, stats, (centre && a.C <= 72) ? 1 : 0, (int*)nullptr, 0, (int*)nullptr, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     dim3 pgrid((HW + 255) / 256, a.B * a.V);
@@ -392,6 +354,20 @@ hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t strea
     else
         hipLaunchKernelGGL(pack_c4_kernel<false>, pgrid, dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V, a.C, a.H, a.W, packed,
                            flags, (int)(flag_only_bytes(a.B, a.H, a.W) / sizeof(int)), a, queue, stats);
+    return hipGetLastError();
+}
+
+// Pre-pass of a call whose sweep kernel packs the source itself (sweep_corr.hip): the channel statistics, and the workspace
+// bookkeeping the pack kernel otherwise does.  The pack counters (two ints per batch item) live in the tile-list region.
+bool sweep_ws_holds_pack_counters(int B, int H, int W) { return (size_t)2 * B * sizeof(int) <= flag_only_bytes(B, H, W); }
+int* sweep_ws_pack_counters(const SweepArgs& a, void* workspace) {
+    return reinterpret_cast<int*>(static_cast<char*>(workspace) + flag_bytes(a.B, a.H, a.W) + packed_bytes(a.B, a.V, a.C, a.H, a.W));
+}
+hipError_t launch_stats_only(const SweepArgs& a, void* workspace, hipStream_t stream) {
+    float* stats = reinterpret_cast<float*>(static_cast<char*>(workspace) + sweep_ws_stats_offset(a.B, a.V, a.C, a.H, a.W));
+    hipLaunchKernelGGL(feature_stats_kernel, dim3(a.C < STATS_VAR ? a.C : STATS_VAR, a.B), dim3(256), 0, stream, a.src, a.src_bstride, a.C,
+                       a.H, a.W, stats, 1, reinterpret_cast<int*>(workspace), (int)(flag_bytes(a.B, a.H, a.W) / sizeof(int)),
+                       sweep_ws_pack_counters(a, workspace), 2 * a.B);
     return hipGetLastError();
 }
 

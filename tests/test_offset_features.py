@@ -155,3 +155,22 @@ def test_passes_that_do_not_fit_are_evaluated_directly(dev):
         c2 = ops.sweep_cost(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0, algo="corr")
         assert torch.equal(c2.nan_to_num(nan=-7.0), cost.nan_to_num(nan=-7.0))
     assert total > 0, "these poses are meant to exceed the row tables"
+
+
+def test_pack_inside_the_sweep_kernel_gives_the_same_bits(dev, monkeypatch):
+    """PDEPTH_CORR_FUSE_PACK=1: the NCHW entry runs the channel statistics and ONE sweep kernel that packs batch item b + 1
+    while it sweeps item b (csrc/sweep_corr.hip; off by default: measured slower).  Same arithmetic
+    (csrc/pack_body.hpp), so the same bits as the pack kernel in front -- call after call on one workspace with new data
+    (a stale line of the previous call's packed source in some XCD's L2 would show), several views, ragged sizes."""
+    for seed, (B, H, W, V, D) in enumerate(((3, 64, 128, 2, 64), (2, 37, 83, 1, 48), (4, 64, 128, 1, 100))):
+        for rep in range(3):
+            b = _offset_batch("uniform8", "mono", B=B, H=H, W=W, V=V, D=D, seed=40 + 7 * seed + rep)
+            d = to_dev(b, dev)
+            args = (d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0)
+            monkeypatch.delenv("PDEPTH_CORR_FUSE_PACK", raising=False)
+            want = ops.sweep_dpv(*args, algo="corr", want_cost=True)
+            monkeypatch.setenv("PDEPTH_CORR_FUSE_PACK", "1")
+            got = ops.sweep_dpv(*args, algo="corr", want_cost=True)
+            for g, w_ in zip(got, want):
+                assert torch.equal(g.nan_to_num(nan=-7.0), w_.nan_to_num(nan=-7.0)), (B, H, W, V, rep)
+    monkeypatch.delenv("PDEPTH_CORR_FUSE_PACK", raising=False)

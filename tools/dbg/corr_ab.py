@@ -1,4 +1,4 @@
-"""Packed-entry timings (mono / stereo, config 2 shape) of several library builds in one process each: python corr_ab.py"""
+"""Packed-entry and NCHW-entry timings (mono / stereo, config 2 shape) of several library builds in one process each: python corr_ab.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -13,5 +13,6 @@ for pose in ("mono", "stereo"):
     dc = ops.d_candi_tensor(d["d_candi"], "cuda")
     ps = ops.pack_source(d["src"], 64, "corr")
     g = lambda: ops.sweep_dpv(d["ref"], ps, d["K"], d["R"], d["t"], d["rays"], d["cxcy"], dc, 10.0, algo="corr")
-    out.append("%s %.4f" % (pose, min(timeit(g, steps=20) for _ in range(3))))
+    f = lambda: ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], dc, 10.0, algo="corr")
+    out.append("%s packed %.4f nchw %.4f" % (pose, min(timeit(g, steps=20) for _ in range(3)), min(timeit(f, steps=20) for _ in range(3))))
 print("%-46s %s" % (os.environ.get("PDEPTH_LIB", "product"), "  ".join(out)), flush=True)
