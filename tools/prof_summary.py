@@ -9,7 +9,7 @@ for f in find("trace/**/*kernel_stats.csv"):
     print("== kernel stats:", os.path.relpath(f, root))
     for i, row in enumerate(csv.reader(open(f))):
         if i < 8: print("  ", ", ".join(row[:8]))
-for sub in ("pmc1", "pmc2", "pmc3", "pmc4"):
+for sub in ("pmc1", "pmc2", "pmc3", "pmc4", "pmc5", "pmc6"):
     for f in find(sub + "/**/*counter_collection.csv"):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for row in csv.DictReader(open(f)):
