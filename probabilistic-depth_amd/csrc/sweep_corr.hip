@@ -16,23 +16,30 @@
 //
 //   how.  X' for 16 neighbouring pixels x 16 consecutive texels of a source row is a 16 x 16 x C matrix product:
 //       v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation).  The 64 (128) planes of the 16 pixels are spread
-//       over the 256 threads of a workgroup -- thread (pixel n, tq) owns PPT = 4 (8) consecutive planes -- so every
-//       phase of a pixel block is a few instructions long per wave, and four to five workgroups per CU interleave:
+//       over the 256 threads of a workgroup -- thread (pixel n, tq) owns planes 4 tq .. 4 tq + 3 of each group of 64 (a
+//       PASS = one source view x one group of 64 planes) -- so every phase of a pass is a few instructions long per wave,
+//       and four workgroups per CU (three at D > 64) interleave:
 //         positions   bit-faithful sample positions (geometry.hpp), two planes per packed instruction;
 //         row table   per source row the run of texels any sample touches: LDS min / max, rows indexed modulo 64; one
-//                     barrier; every wave then cuts the runs into blocks of 16 texels (same result in every wave);
+//                     barrier; wave 0 cuts the runs into blocks of 16 texels while the others fetch the block's reference
+//                     features from LDS; one barrier;
 //         X           wave w multiplies blocks w, w + 4, ...: texel features by buffer_load_dwordx4 from the packed
-//                     source (out-of-image texels: out-of-range offset = 0), the pixels' reference features held in
-//                     registers as the B operand, X[pixel][slot] and the Gram records of the slots to LDS; one barrier;
-//         combine     per (pixel, plane): 4 X values, the Gram terms of the cell, the bilinear weights;
+//                     source (out-of-image texels: out-of-range offset = 0), half a block's loads in flight under the
+//                     other half's MFMAs, the pixels' centred reference features in registers as the B operand;
+//                     X[pixel][slot] to LDS; the Gram records (and <s', mu>) of the slots straight from memory to LDS
+//                     (buffer_load ... lds); one barrier;
+//         combine     per (pixel, plane): 4 X values, the Gram terms of the cell, the bilinear weights; the border term;
 //         epilogue    cost store; log-softmax over D and E[d]: per wave partial (max, sum, sum d) of each pixel, merged
 //                     across the four waves through LDS (one barrier).
-//       A pixel block whose planes need more than MAXB blocks is split into passes over plane ranges; one that does not
-//       fit even plane by plane (extreme poses) is evaluated directly by the same workgroup (direct_block): the kernel
-//       needs no tile flags and no second launch.
-//   scheduling.  Persistent workgroups pull 16x4 tiles (four pixel blocks; single blocks on small problems) from per-XCD
-//       queues, balanced partition as described at decode(); the last workgroup to leave zeroes the queue counters, so a
-//       call on an already packed source is this one launch.
+//       A pass whose planes need more than MAXB blocks or 64 rows (extreme poses: epipolar segments of hundreds of texels)
+//       is evaluated directly by the same workgroup behind the view loop, in the reference's own form on the centred
+//       features (16-byte taps from the packed source): the kernel needs no tile flags and no second launch.
+//   scheduling.  Persistent workgroups pull 16x4 tiles (four pixel blocks one after the other; single blocks on small
+//       problems: CORR_SPI1_BELOW) from per-XCD queues, balanced partition as described at decode(); the last workgroup
+//       to leave zeroes the queue counters, so a call on an already packed source is this one launch.
+//   registers.  128 VGPRs (four waves per SIMD) is the budget everything above is written against: one straight-line pass
+//       (no adaptive plane ranges, no early exits from the view loop), the per-view uniforms and the reference features
+//       re-read from LDS per pass instead of held, lane-derived invariants re-derived per block (opaque_v).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -939,7 +946,7 @@ hipError_t launch_inst(const SweepArgs& a, const float4* packed, const float* mu
     // small problems: one pixel block per item, so that every CU gets work
     ca.spi = (long long)tiles * a.B < CORR_SPI1_BELOW * nblk ? 1 : 4;
     const long long need = 8ll * ((tiles + 7) / 8) * (4 / ca.spi) * a.B;   // a workgroup per item of the largest XCD band, times 8
-    if (need <= nblk) nblk = need;
+    if (need <= CORR_ONE_EACH_X * nblk) nblk = need;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, stream, ca);
     return hipGetLastError();
 }

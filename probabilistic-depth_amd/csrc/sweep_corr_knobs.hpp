@@ -11,6 +11,9 @@
 #ifndef CORR_STORE_AUX   // cache policy of the output stores: 2 = nt (written once, read by nobody in this launch: -2 % on the
 #define CORR_STORE_AUX 2 // forward-motion pose, whose 8x2 pixel blocks store 32-byte runs)
 #endif
+#ifndef CORR_ONE_EACH_X   // a workgroup per item, no queue, while the items are at most this many times the workgroups the chip holds at once
+#define CORR_ONE_EACH_X 2
+#endif
 #ifndef CORR_SPI1_BELOW   // queue items are single pixel blocks (not 16x4 tiles of four) while there are fewer tiles than this many per workgroup
 #define CORR_SPI1_BELOW 2
 #endif

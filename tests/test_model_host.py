@@ -89,6 +89,12 @@ def test_get_model_contract():
     cfg.data["model_name"] = "nope"
     with pytest.raises(NotImplementedError):
         get_model(cfg, 0)
+    # 'packnet' (models/get_model.py:9-10): the host object exists; the PackNet CNN is the caller's to plug in
+    cfg.data["model_name"] = "packnet"
+    pk = get_model(cfg, 0)
+    assert type(pk).__name__ == "PacknetModel" and pk.sigma_soft_max == cfg.var.sigma_soft_max
+    with pytest.raises(NotImplementedError, match="base_encoder"):
+        pk.forward({"rgb": torch.zeros(1, 2, 3, 8, 8)})
     m = get_model(synth.default_cfg("default"), 0)
     m.set_viz(None)
     m.init_weights()

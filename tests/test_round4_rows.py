@@ -16,7 +16,7 @@ import pytest
 import torch
 
 import pdepth_amd  # noqa: F401
-from pdepth_amd import ops, synth
+from pdepth_amd import harness, ops, synth
 from oracle import ref_cpu as O
 from util import golden, golden_blas
 
@@ -117,3 +117,53 @@ def test_rccl_path_initialises_on_the_hardware():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = json.loads([l for l in p.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["value"] > 0 and line["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+def test_packnet_model_with_a_plugged_in_network():
+    """get_model('packnet') (models/get_model.py:9-10, models/packnet.py:304-406): with a stand-in for the PackNet CNN
+    (a strided convolution as base_encoder, an interpolation as base_decoder) the host object returns the reference's
+    dictionary, its log-DPV is the oracle's sweep -> log_softmax chain on the encoder's own feature maps (:362-394) and the
+    feature_set has the reference's [view][level] layout."""
+    from pdepth_amd.models import get_model
+    from util import oracle_batch
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = torch.nn.Conv2d(3, 8, 3, stride=2, padding=1)
+            self.c2 = torch.nn.Conv2d(8, 13, 3, stride=2, padding=1)
+
+        def forward(self, rgb):
+            a = torch.relu(self.c1(rgb))
+            b = self.c2(a)
+            return [a, b], b
+
+    class Dec(torch.nn.Module):
+        def forward(self, dpv, feats):
+            assert len(feats) == 2 and feats[1].shape[1] == 13
+            return torch.log_softmax(torch.nn.functional.interpolate(torch.log(dpv.clamp_min(1e-30)), scale_factor=2.0), dim=1)
+
+    torch.manual_seed(3)
+    cfg = synth.default_cfg("default")
+    cfg.data["model_name"] = "packnet"
+    model = get_model(cfg, 0).attach_networks(Enc(), Dec()).to(DEV).eval()
+    inp = harness.move_input(synth.make_model_input(11, B=2, V=2, H=96, W=160, D=48, pose="mono"), DEV)
+    out = model(inp)
+    assert set(out) == {"output", "output_refined", "flow", "flow_refined"} and out["flow"] is None
+    BV = out["output"][0]
+    assert BV.shape == (2, 48, 24, 40) and out["output_refined"][0].shape == (2, 48, 48, 80)
+    # the reference's chain on the same feature maps, on the CPU
+    with torch.no_grad():
+        rgb = inp["rgb"]
+        flat = rgb.reshape(-1, 3, 96, 160)
+        feat = model.base_encoder(flat)[1]
+        both = torch.cat((feat, torch.nn.functional.avg_pool2d(flat, 4)), dim=1).view(2, 3, 16, 24, 40).cpu()
+    poses = inp["src_cam_poses"].cpu()
+    K = inp["intrinsics"].cpu()
+    b = {"ref": both[:, -1], "src": both[:, :-1], "K": K, "R": poses[:, :-1, :3, :3], "t": poses[:, :-1, :3, 3],
+         "rays": inp["unit_ray"].cpu(), "cxcy": K[:, :2, 2].contiguous(), "d_candi": inp["d_candi"]}
+    _, ologp, _ = oracle_batch(b, sigma=cfg.var.sigma_soft_max)
+    np.testing.assert_allclose(BV.cpu().numpy(), ologp.numpy(), rtol=0, atol=5e-5)
+    BV2, feature_set = model.forward_encoder(inp)
+    assert torch.equal(BV2, BV) and len(feature_set) == 3 and [tuple(t.shape) for t in feature_set[-1]] == [(2, 8, 48, 80), (2, 13, 24, 40)]
