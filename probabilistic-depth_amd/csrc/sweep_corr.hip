@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
         const int rem = iq - b_ * per_b, ti = rem >> msh;
         sub0_ = (rem & (m - 1)) * spi;
         int tile = band_first_of(q_) + ti;
-        if (rr8 == 0 && tiles_y_ % 16 == 0 && tiles_y_ * tiles_x == ntile) {
+        if (CORR_HALF_BANDS && rr8 == 0 && tiles_y_ % 16 == 0 && tiles_y_ * tiles_x == ntile) {
             // XCD q owns half-bands q and 8 + q of the image's 16: on a forward motion the cost of a tile grows with its
             // distance from the image centre, and this way every XCD gets the same mix; the heavier half first and, inside
             // a half, columns from both image borders inwards.  (Any static partition is valid: dry queues steal.)
@@ -690,6 +690,8 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                             }
                         };
                         // the first block's loads and the Gram records are in flight while the slots are looked up
+                        // (a wave in the matrix phase issues ahead of waves in the vector phases: its loads are the longest wait of a pass)
+                        if (CORR_XPRIO) __builtin_amdgcn_s_setprio(CORR_XPRIO);
                         if (go) { prep(wave); load_a(); load_b(); }
                         // the two X / Gram slots of this thread's planes and the border flags of their cells, one register each
 #pragma unroll
@@ -716,6 +718,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                             if (i + 1 < BPW) load_b();
                             *reinterpret_cast<v4f*>(&L.Xs[n * XSTRIDE + 16 * bi + 4 * kq]) = acc0 + acc1;   // X[texel][pixel] of the block
                         }
+                        if (CORR_XPRIO) __builtin_amdgcn_s_setprio(0);
                         CSTAMP(6)   // X: loads + multiplications
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's Gram records have landed in LDS
                         }

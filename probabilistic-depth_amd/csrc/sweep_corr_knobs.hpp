@@ -11,6 +11,12 @@
 #ifndef CORR_STORE_AUX   // cache policy of the output stores: 2 = nt (written once, read by nobody in this launch: -2 % on the
 #define CORR_STORE_AUX 2 // forward-motion pose, whose 8x2 pixel blocks store 32-byte runs)
 #endif
+#ifndef CORR_HALF_BANDS   // XCD q owns half-bands q and 8 + q of the image (balanced on a forward motion); 0: one band of rows per XCD
+#define CORR_HALF_BANDS 1
+#endif
+#ifndef CORR_XPRIO        // wave priority while a wave is in the matrix phase (its loads go out first)
+#define CORR_XPRIO 1
+#endif
 #ifndef CORR_ONE_EACH_X   // a workgroup per item, no queue, while the items are at most this many times the workgroups the chip holds at once
 #define CORR_ONE_EACH_X 2
 #endif
