@@ -718,11 +718,11 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                             if (i + 1 < BPW) load_b();
                             *reinterpret_cast<v4f*>(&L.Xs[n * XSTRIDE + 16 * bi + 4 * kq]) = acc0 + acc1;   // X[texel][pixel] of the block
                         }
-                        if (CORR_XPRIO) __builtin_amdgcn_s_setprio(0);
                         CSTAMP(6)   // X: loads + multiplications
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's Gram records have landed in LDS
                         }
                     }
+                    if (CORR_XPRIO) __builtin_amdgcn_s_setprio(0);
                     CSTAMP(7)   // wait for the Gram records
                     LDS_BARRIER();   // X and the Gram records of the pass are complete (or: every wave has seen that it does not fit)
                     ++pt;
