@@ -167,3 +167,44 @@ def test_packnet_model_with_a_plugged_in_network():
     np.testing.assert_allclose(BV.cpu().numpy(), ologp.numpy(), rtol=0, atol=5e-5)
     BV2, feature_set = model.forward_encoder(inp)
     assert torch.equal(BV2, BV) and len(feature_set) == 3 and [tuple(t.shape) for t in feature_set[-1]] == [(2, 8, 48, 80), (2, 13, 24, 40)]
+
+
+@pytest.mark.gpu
+def test_packed_entry_is_one_capturable_launch():
+    """the per-item call of models/models.py:528-550 as the host model issues it -- a sweep on an already
+    packed source -- is ONE kernel launch with no host synchronisation, no allocation and no clearing launch in front: it
+    can be captured into a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed on new reference features, camera poses and
+    an unchanged workspace, with the results of the eager call bit for bit."""
+    b = synth.make_batch(5, 1, C=67, D=64, H=64, W=128, V=1, pose="mono")
+    d = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    dc = ops.d_candi_tensor(d["d_candi"], DEV)
+    ps = ops.pack_source(d["src"], 64)
+    ref, R, t = d["ref"].clone(), d["R"].clone(), d["t"].clone()
+    run = lambda: ops.sweep_dpv(ref, ps, d["K"], R, t, d["rays"], d["cxcy"], dc, 10.0)
+    want0 = [x.clone() for x in run()[1:]]           # (also warms the per-device caches of the launcher: not capturable work)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = run()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[1], want0[0]) and torch.equal(out[2], want0[1])
+    # new inputs in the captured buffers: another frame's reference features and pose
+    b2 = synth.make_batch(6, 1, C=67, D=64, H=64, W=128, V=1, pose="mono")
+    ref.copy_(b2["ref"].to(DEV)); R.copy_(b2["R"].to(DEV)); t.copy_(b2["t"].to(DEV))
+    graph.replay()
+    torch.cuda.synchronize()
+    got = [out[1].clone(), out[2].clone()]
+    want = run()
+    assert torch.equal(got[0], want[1]) and torch.equal(got[1], want[2])
+    import time
+    t0 = time.perf_counter()
+    for _ in range(200):
+        graph.replay()
+    torch.cuda.synchronize()
+    print("graph replay of the packed-entry sweep, B=1 64x128: %.1f us per call (wall, back to back)" % ((time.perf_counter() - t0) / 200 * 1e6))
