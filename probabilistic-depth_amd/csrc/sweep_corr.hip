@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
     constexpr int NCH = NPL / 4, NTL = NPL % 4;   // chunks of 16 channels (4 MFMAs per 16-byte load), left-over planes of 4
     constexpr int LA = (NCH + 1) / 2, LB = NCH - LA;   // a block's loads in two halves: chunks [0, LA) | chunks [LA, NCH) + left-overs
     constexpr int MCH = (4 * NPL + 15) / 16;      // channels per thread of the cooperative reference load
-    constexpr int MAXB = NH == 1 ? CORR_MAXB1 : 32;
+    constexpr int MAXB = NH == 1 ? CORR_MAXB1 : CORR_MAXB2;
     constexpr int BPW = (MAXB + 3) / 4;           // blocks per wave and pass
     constexpr int NC = 4 * NH;                    // planes (costs) per thread
     typedef CorrLds<MAXB, NPL> Lds;

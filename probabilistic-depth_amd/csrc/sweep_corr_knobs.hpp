@@ -26,6 +26,9 @@
 #ifndef CORR_PACK_AUX   // cache policy of the in-kernel pack's stores: 16 = sc1 (write-through to memory: the other XCDs read them)
 #define CORR_PACK_AUX 16
 #endif
+#ifndef CORR_MAXB2   // ... at D > 64 (two groups of 64 planes per view, each a pass)
+#define CORR_MAXB2 32
+#endif
 #ifndef CORR_MAXB1   // blocks of 16 texels a pass can take, D <= 64 (LDS: 4 workgroups per CU)
 #define CORR_MAXB1 22
 #endif
