@@ -174,3 +174,39 @@ def test_pack_inside_the_sweep_kernel_gives_the_same_bits(dev, monkeypatch):
             for g, w_ in zip(got, want):
                 assert torch.equal(g.nan_to_num(nan=-7.0), w_.nan_to_num(nan=-7.0)), (B, H, W, V, rep)
     monkeypatch.delenv("PDEPTH_CORR_FUSE_PACK", raising=False)
+
+
+def test_extremes_of_the_default_kernel(dev):
+    """The corners of the shape range sweep_corr_supports() admits -- one channel, one plane, images smaller than a tile, the
+    widest features (C = 72: 18 packed planes), D = 65 (a second plane group with one plane in it), 8 source views, more than
+    64 batch items (the per-item block-shape table holds 64) -- against the oracle, with offset features; and just beyond
+    them (9 views, C = 73, D = 129) `auto` still answers (the LDS-tiled kernel) while the forced selector says no."""
+    cases = [dict(B=1, C=1, D=1, H=3, W=5, V=1), dict(B=2, C=72, D=65, H=9, W=33, V=8), dict(B=70, C=5, D=7, H=4, W=16, V=1),
+             dict(B=1, C=4, D=64, H=1, W=130, V=2), dict(B=1, C=67, D=128, H=21, W=19, V=3)]
+    for i, c in enumerate(cases):
+        b = synth.make_batch(300 + i, c["B"], C=c["C"], D=c["D"], H=c["H"], W=c["W"], V=c["V"], pose=("mono", "stereo", "wide")[i % 3])
+        g = torch.Generator().manual_seed(i)
+        mu = (torch.rand(c["C"], generator=g) * 2 - 1) * 4.0
+        b["ref"] = b["ref"] + mu[None, :, None, None]
+        b["src"] = b["src"] + mu[None, None, :, None, None]
+        ocost, ologp, odepth = oracle_batch(b)
+        d = to_dev(b, dev)
+        for algo in ("corr", "auto"):
+            cost, logp, depth = ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0,
+                                              algo=algo, want_cost=True)
+            fin = torch.isfinite(ocost)
+            assert torch.equal(torch.isfinite(cost.cpu()), fin), (algo, c)
+            np.testing.assert_allclose(cost.cpu()[fin].numpy(), ocost[fin].numpy(), rtol=COST_RTOL, atol=COST_ATOL * c["V"], err_msg=f"{algo} {c}")
+            dfin = torch.isfinite(odepth)
+            if bool(dfin.any()):
+                assert (depth.cpu()[dfin] - odepth[dfin]).abs().max().item() <= DEPTH_ATOL * max(1.0, c["V"] / 2), (algo, c)
+    for c in (dict(C=8, D=16, V=9), dict(C=73, D=16, V=1), dict(C=8, D=129, V=1)):
+        b = synth.make_batch(400, 1, C=c["C"], D=c["D"], H=12, W=20, V=c["V"], pose="mono")
+        ocost, ologp, odepth = oracle_batch(b)
+        d = to_dev(b, dev)
+        args = (d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0)
+        cost = ops.sweep_dpv(*args, algo="auto", want_cost=True)[0]
+        fin = torch.isfinite(ocost)
+        np.testing.assert_allclose(cost.cpu()[fin].numpy(), ocost[fin].numpy(), rtol=COST_RTOL, atol=COST_ATOL * c["V"], err_msg=str(c))
+        with pytest.raises(RuntimeError):
+            ops.sweep_dpv(*args, algo="corr")
