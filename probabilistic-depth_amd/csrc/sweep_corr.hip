@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                     if (wave == 0) {
                         const int yb = __builtin_amdgcn_readfirstlane(L.ired[par][0]), yt = __builtin_amdgcn_readfirstlane(L.ired[par][1]);
                         int nb_ = 0;
-                        bool fits_ = true;
+                        bool fits_ = true, border_ = false;   // border_: a cell of the pass lies on the image border (the <s', mu> records are needed)
                         if (yb <= yt) {
                             const int ncell = yt - yb + 1;
                             if (ncell + 1 > MAXB) {   // (every texel row takes a block; also keeps the modulo-64 rows apart)
@@ -566,6 +566,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                                     hi = max(hi, L.cmax[par][(yb + lane - 1) & 63]);
                                 }
                                 const int nblk = lo <= hi ? (hi - lo + 2 + 15) >> 4 : 0;   // texels lo .. hi + 1
+                                border_ = yb < 0 || yt >= H - 1 || __builtin_amdgcn_ballot_w64(lo <= hi && (lo < 0 || hi >= W - 1)) != 0;
                                 const int incl = wave_scan_incl(nblk);
                                 nb_ = __builtin_amdgcn_readlane(incl, 63);
                                 fits_ = nb_ <= MAXB;
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                                 }
                             }
                         }
-                        if (lane == 0) { L.tab[0] = nb_; L.tab[1] = fits_ ? 1 : 0; L.tab[2] = yb; }
+                        if (lane == 0) { L.tab[0] = nb_; L.tab[1] = fits_ ? 1 : 0; L.tab[2] = yb; L.tab[3] = border_ ? 1 : 0; }
                         // (only this wave reads the min / max tables: they are dead now)
                         L.cmin[par][lane] = INT_MAX; L.cmax[par][lane] = INT_MIN;
                         if (lane == 0) { L.ired[par][0] = INT_MAX; L.ired[par][1] = INT_MIN; }
@@ -612,6 +613,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                     CSTAMP(5)   // scan
                     // ---- X' = <r', s'> for the blocks of the pass, on the matrix pipe ---------------------------------------
                     const bool go = fits && nb > 0;
+                    const bool border = __builtin_amdgcn_readfirstlane(L.tab[3]) != 0;
                     int sl[4];
                     {
                         const int myblk = L.blk[min(lane, MAXB + BLK_PAD - 1)];   // the block list in a register: entry l in lane l
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
                                     const bool ok = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && slot < 16 * nb;
                                     const int vg = ok ? (yy * W + xx) * 16 : OOB;
                                     dma_b128(rs4, lds_addr_of(&L.G4s[c64 * 4]), vg, NPL * HW * 16);
-                                    dma_b32(rs4, lds_addr_of(&L.Ms[c64]), vg, (NPL + 1) * HW * 16);
+                                    if (CORR_MS_ALWAYS || border) dma_b32(rs4, lds_addr_of(&L.Ms[c64]), vg, (NPL + 1) * HW * 16);
                                 }
                             }
                         }

@@ -14,6 +14,9 @@
 #ifndef CORR_HALF_BANDS   // XCD q owns half-bands q and 8 + q of the image (balanced on a forward motion); 0: one band of rows per XCD
 #define CORR_HALF_BANDS 1
 #endif
+#ifndef CORR_MS_ALWAYS    // fetch the <s', mu> records of a pass's slots even when none of its cells lies on the image border
+#define CORR_MS_ALWAYS 0
+#endif
 #ifndef CORR_XPRIO        // wave priority while a wave is in the matrix phase (its loads go out first)
 #define CORR_XPRIO 1
 #endif
