@@ -119,3 +119,23 @@ def test_product_path_has_no_cpu_fallback():
                 body = open(os.path.join(root, f)).read()
                 assert "import oracle" not in body and "from oracle" not in body, f"{f} must not use the oracle"
     assert "oracle" not in src
+
+
+def test_product_library_carries_no_lab_bench():
+    """the default build holds the product kernels only -- the kernels of earlier rounds and their
+    experiment switches live under csrc/lab/ (make LAB=1) --, a product sweep source has at most five preprocessor
+    conditionals (diagnostic builds), and the shipped library does not answer the lab selectors."""
+    import re
+    csrc = os.path.join(REPO, "probabilistic-depth_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    srcs = re.search(r"^SRCS = (.*)$", mk, re.M).group(1).split()
+    assert not any(s.startswith("lab/") for s in srcs) and "sweep_corr.hip" in srcs and "ifdef LAB" in mk
+    for f in srcs:
+        if f.startswith("sweep_"):
+            n = len(re.findall(r"^\s*#\s*if", open(os.path.join(csrc, f)).read(), re.M))
+            assert n <= 5, f"{f}: {n} preprocessor conditionals"
+    lib = _native.load()
+    names = {"pdepth_sweep_centres_source", "pdepth_sweep_dpv_packed_f32"}
+    for n in names:
+        assert hasattr(lib, n)
+    assert _native.ALGO_CORR == 6
