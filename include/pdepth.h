@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PDEPTH_ABI_VERSION 4   /* 4: PDEPTH_ALGO_CORR, pdepth_sweep_centres_source, workspace tail with channel statistics */
+#define PDEPTH_ABI_VERSION 5   /* 5: PDEPTH_ALGO_DIST (what AUTO runs), pdepth_sweep_source_layout, layout tag in the workspace */
 
 enum {
     PDEPTH_OK = 0,
@@ -66,8 +66,19 @@ enum {
     PDEPTH_ALGO_TILED_2 = 3, /* LDS-tiled band kernel, two tiles per block (D <= 64)                    */
     PDEPTH_ALGO_CELLS = 4,   /* lab builds only (make LAB=1): cell-list kernels of round 2 (L2, D <= 128)           */
     PDEPTH_ALGO_MFMA = 5,    /* lab builds only: matrix-pipe kernel of round 3 (L2, D <= 128, C <= 72)              */
-    PDEPTH_ALGO_CORR = 6     /* correlation form on mean-centred features, matrix pipe (L2 metric, D <= 128, C <= 72;
-                                other inputs: PDEPTH_E_ARG): what AUTO runs on those shapes                      */
+    PDEPTH_ALGO_CORR = 6,    /* correlation form on mean-centred features, fp32 matrix instructions (L2 metric, D <= 128,
+                                C <= 72; other inputs: PDEPTH_E_ARG): the default of ABI 4, kept as an independent check */
+    PDEPTH_ALGO_DIST = 7     /* distance form sum_t w_t |s_t - r|^2 - Q on fp16 high / low parts, matrix pipe (L2 metric,
+                                D <= 128, C <= 72, V <= 8; other inputs: PDEPTH_E_ARG): what AUTO runs on those shapes  */
+};
+
+/* staging layouts of the packed source (pdepth_sweep_source_layout) */
+enum {
+    PDEPTH_LAYOUT_NONE = 0,        /* the descriptor does not run on a packed source                                   */
+    PDEPTH_LAYOUT_C4 = 1,          /* channel-group-planar float4 + Gram planes (LDS-tiled kernel)                     */
+    PDEPTH_LAYOUT_C4_CENTRED = 2,  /* the same on mean-centred features (PDEPTH_ALGO_CORR)                             */
+    PDEPTH_LAYOUT_DIST16 = 3       /* fp16 high / low planes in matrix-operand order + neighbour differences, ring of
+                                      zero-feature texels (PDEPTH_ALGO_DIST; csrc/dist_layout.hpp)                     */
 };
 
 /* Geometry + layout of one batched sweep call. */
@@ -169,6 +180,12 @@ size_t pdepth_sweep_workspace_bytes(const pdepth_sweep_desc *desc);
  * plain layout differ; the library cannot tell them apart from the host).  No reference counterpart: the reference
  * never re-lays its features (warping/homography.py:123-129 works on the NCHW tensors). */
 int pdepth_sweep_centres_source(const pdepth_sweep_desc *desc);
+
+/* Which staging layout (PDEPTH_LAYOUT_*) the packing entry points write for `desc`, i.e. which kernel family the sweep it
+ * selects belongs to.  A packed workspace must be swept with a descriptor for which this answer is the same.  The pack
+ * kernels also write the answer into the workspace, and a sweep kernel that finds another family's tag there fills its
+ * outputs with NaN instead of returning numbers computed from the wrong bytes.  No reference counterpart (as above). */
+int pdepth_sweep_source_layout(const pdepth_sweep_desc *desc);
 
 /*
  * DPV reduction: logits [B,D,H,W] -> logp [B,D,H,W] (may alias logits, may be NULL) and

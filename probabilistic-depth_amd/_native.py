@@ -17,7 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpdepth_hip.so")
 
 METRIC_L2, METRIC_L1 = 0, 1
-ALGO_AUTO, ALGO_DIRECT, ALGO_TILED_1, ALGO_TILED_2, ALGO_CELLS, ALGO_MFMA, ALGO_CORR = 0, 1, 2, 3, 4, 5, 6
+ALGO_AUTO, ALGO_DIRECT, ALGO_TILED_1, ALGO_TILED_2, ALGO_CELLS, ALGO_MFMA, ALGO_CORR, ALGO_DIST = 0, 1, 2, 3, 4, 5, 6, 7
+LAYOUT_NONE, LAYOUT_C4, LAYOUT_C4_CENTRED, LAYOUT_DIST16 = 0, 1, 2, 3
 BLAS_FMA, BLAS_SEPARATE = 0, 1
 
 # every symbol include/pdepth.h declares (tests check the library exports all of them)
@@ -30,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "pdepth_pack_source_f32", "pdepth_sweep_dpv_packed_f32", "pdepth_dpv_reduce_ex_f32",
     "pdepth_ufield_workspace_bytes", "pdepth_ufield_f32",
     "pdepth_correlation_output_size", "pdepth_correlation_forward_f16", "pdepth_correlation_backward_f16",
-    "pdepth_pack_views_f32", "pdepth_sweep_centres_source",
+    "pdepth_pack_views_f32", "pdepth_sweep_centres_source", "pdepth_sweep_source_layout",
 )
 
 
@@ -148,7 +149,9 @@ def load():
         getattr(lib, fn).restype = c_int
     lib.pdepth_sweep_centres_source.restype = c_int
     lib.pdepth_sweep_centres_source.argtypes = [POINTER(SweepDesc)]
-    if lib.pdepth_abi_version() != 4:
+    lib.pdepth_sweep_source_layout.restype = c_int
+    lib.pdepth_sweep_source_layout.argtypes = [POINTER(SweepDesc)]
+    if lib.pdepth_abi_version() != 5:
         raise RuntimeError("libpdepth_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -210,9 +213,14 @@ class PackedSource:
     sweep() in place of src, for callers that sweep the same source features more than once or write them once per
     frame.  Owns its device memory; do not use it from two streams at once."""
 
-    def __init__(self, ws, shape, centred=False):
+    def __init__(self, ws, shape, layout=LAYOUT_C4):
         self.ws, self.shape = ws, tuple(shape)   # shape = (B, V, C, H, W)
-        self.centred = bool(centred)             # the channel means were subtracted (pdepth_sweep_centres_source)
+        self.layout = int(layout)                # LAYOUT_* : the kernel family it was packed for (pdepth_sweep_source_layout)
+
+    @property
+    def centred(self):
+        """The channel means were subtracted (pdepth_sweep_centres_source)."""
+        return self.layout in (LAYOUT_C4_CENTRED, LAYOUT_DIST16)
 
 
 def pack_source(src, n_planes=64, algo=ALGO_AUTO, metric=METRIC_L2):
@@ -233,7 +241,7 @@ def pack_source(src, n_planes=64, algo=ALGO_AUTO, metric=METRIC_L2):
     with torch.cuda.device(src.device):
         rc = lib.pdepth_pack_source_f32(ctypes.byref(desc), _dev(src, "src"), ws.data_ptr(), ws_bytes, _stream(src.device))
     _check(rc, lib)
-    return PackedSource(ws, (B, V, C, H, W), lib.pdepth_sweep_centres_source(ctypes.byref(desc)))
+    return PackedSource(ws, (B, V, C, H, W), lib.pdepth_sweep_source_layout(ctypes.byref(desc)))
 
 
 def pack_views(feat, rgb, n_views, n_planes=64):
@@ -264,7 +272,7 @@ def pack_views(feat, rgb, n_views, n_planes=64):
         rc = lib.pdepth_pack_views_f32(ctypes.byref(desc), feat.data_ptr(), rgb.data_ptr(), rate, ref.data_ptr(), ws.data_ptr(),
                                        ws_bytes, _stream(feat.device))
     _check(rc, lib)
-    return PackedSource(ws, (B, V, C, h, w), lib.pdepth_sweep_centres_source(ctypes.byref(desc))), ref
+    return PackedSource(ws, (B, V, C, h, w), lib.pdepth_sweep_source_layout(ctypes.byref(desc))), ref
 
 
 def sweep(ref, src, K, R, t, rays, cxcy, d_candi, sigma, metric=METRIC_L2, algo=ALGO_AUTO,
@@ -311,9 +319,9 @@ def sweep(ref, src, K, R, t, rays, cxcy, d_candi, sigma, metric=METRIC_L2, algo=
     if packed:
         if ws_bytes == 0 or packed.ws.numel() < ws_bytes:
             raise RuntimeError("sweep: this shape / algorithm does not run on a packed source")
-        if bool(lib.pdepth_sweep_centres_source(ctypes.byref(desc))) != packed.centred:
-            raise RuntimeError("sweep: the source was packed for another kernel family (centred: %s); pack it with the "
-                               "algo / n_planes / metric it will be swept with" % packed.centred)
+        if lib.pdepth_sweep_source_layout(ctypes.byref(desc)) != packed.layout:
+            raise RuntimeError("sweep: the source was packed for another kernel family (layout %d, centred: %s); pack it with "
+                               "the algo / n_planes / metric it will be swept with" % (packed.layout, packed.centred))
         ws = packed.ws
     else:
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev) if ws_bytes else None

@@ -51,22 +51,26 @@ pdepth::SweepArgs make_args(const pdepth_sweep_desc* d, const pdepth_camera* cam
     return a;
 }
 
-// Implementation behind ALGO_AUTO.  L2 metric, C <= 72, D <= 128: the correlation-form kernel on mean-centred features
-// (sweep_corr.hip).  Everything else that fits the packed layout (L1 has no correlation form; wider features; more planes):
-// the LDS-tiled kernel (sweep_tiled.hip).  PDEPTH_SWEEP_IMPL=tiled (read once per process) forces the tiled kernel for AUTO
-// (A/B timing); lab builds (-DPDEPTH_LAB) also know mfma | cells, the kernels of earlier rounds kept as independent checks.
-enum { IMPL_DEFAULT = 0, IMPL_CELLS = 1, IMPL_TILED = 2, IMPL_MFMA = 3 };
+// Implementation behind ALGO_AUTO.  L2 metric, C <= 72, D <= 128, at most 8 views: the distance-form kernel on the matrix
+// pipe (sweep_dist.hip).  Everything else that fits a packed layout (L1 has no such form; wider features; more planes): the
+// LDS-tiled kernel (sweep_tiled.hip).  Lab builds (-DPDEPTH_LAB) read PDEPTH_SWEEP_IMPL once per process to put another
+// implementation behind AUTO for A/B timing: corr | tiled | mfma | cells (the kernels of earlier rounds, kept as
+// independent checks); the product library has no such switch.
+enum { IMPL_DEFAULT = 0, IMPL_CELLS = 1, IMPL_TILED = 2, IMPL_MFMA = 3, IMPL_CORR = 4 };
 int sweep_impl() {
+#ifdef PDEPTH_LAB
     static const int impl = [] {
         const char* f = getenv("PDEPTH_SWEEP_IMPL");
         if (!f) return (int)IMPL_DEFAULT;
-#ifdef PDEPTH_LAB
         if (f[0] == 'c' && f[1] == 'e') return (int)IMPL_CELLS;
+        if (f[0] == 'c' && f[1] == 'o') return (int)IMPL_CORR;
         if (f[0] == 'm') return (int)IMPL_MFMA;
-#endif
         return f[0] == 't' ? (int)IMPL_TILED : (int)IMPL_DEFAULT;
     }();
     return impl;
+#else
+    return IMPL_DEFAULT;
+#endif
 }
 
 int launched(hipError_t e, const char* who) {
@@ -80,20 +84,36 @@ size_t tiled_ws_bytes(const pdepth_sweep_desc* d) {
     return pdepth::sweep_tiled_workspace_bytes(d->B, d->V, d->C, d->H, d->W);
 }
 
-// does ALGO_AUTO run on the packed (channel-group-planar) copy of the source for this shape?
+// does ALGO_AUTO run on a packed copy of the source for this shape?
 bool uses_packed_source(const pdepth_sweep_desc* d) {
     return d->algo != PDEPTH_ALGO_DIRECT && d->D <= pdepth::sweep_tiled_max_planes() && d->W <= 32767 && d->H <= 32767 &&
            (long long)((d->C + 3) / 4 + 2) * d->H * d->W * 16 < (1ll << 31);
 }
 
-// does this call run the correlation-form kernel (and its pre-pass centre the packed source)?  A pure function of the
-// descriptor: the packing entry points and the sweep that follows decide alike.
-bool uses_corr(const pdepth_sweep_desc* d) {
-    if (!uses_packed_source(d) || d->metric != PDEPTH_METRIC_L2) return false;
-    if (d->algo != PDEPTH_ALGO_CORR && !(d->algo == PDEPTH_ALGO_AUTO && sweep_impl() == IMPL_DEFAULT)) return false;
+pdepth::SweepArgs shape_args(const pdepth_sweep_desc* d) {
     pdepth::SweepArgs a{};
     a.B = d->B; a.V = d->V; a.C = d->C; a.D = d->D; a.H = d->H; a.W = d->W; a.metric = d->metric;
-    return pdepth::sweep_corr_supports(a);
+    return a;
+}
+
+// Which sweep kernel family -- and with it which staging layout of the source -- a descriptor selects.  A pure function of
+// the descriptor: the packing entry points and the sweep that follows decide alike.
+//   distance form (sweep_dist.hip; layout dist_layout.hpp): what AUTO runs for L2, D <= 128, C <= 72, V <= 8
+bool uses_dist(const pdepth_sweep_desc* d) {
+    if (!uses_packed_source(d) || d->metric != PDEPTH_METRIC_L2) return false;
+    if (d->algo != PDEPTH_ALGO_DIST && !(d->algo == PDEPTH_ALGO_AUTO && sweep_impl() == IMPL_DEFAULT)) return false;
+    return pdepth::sweep_dist_supports(shape_args(d));
+}
+//   correlation form on mean-centred features (sweep_corr.hip; centred channel-group-planar layout): on request
+bool uses_corr(const pdepth_sweep_desc* d) {
+    if (!uses_packed_source(d) || d->metric != PDEPTH_METRIC_L2) return false;
+    if (d->algo != PDEPTH_ALGO_CORR && !(d->algo == PDEPTH_ALGO_AUTO && sweep_impl() == IMPL_CORR)) return false;
+    return pdepth::sweep_corr_supports(shape_args(d));
+}
+int source_layout(const pdepth_sweep_desc* d) {
+    if (!uses_packed_source(d)) return PDEPTH_LAYOUT_NONE;
+    if (uses_dist(d)) return PDEPTH_LAYOUT_DIST16;
+    return uses_corr(d) ? PDEPTH_LAYOUT_C4_CENTRED : PDEPTH_LAYOUT_C4;
 }
 
 // packed_ready: src is NULL and the workspace already holds the packed source (pdepth_pack_source_f32)
@@ -107,7 +127,7 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
     if (!cost && !logp && !depth) return fail(PDEPTH_E_ARG, "%s: no output requested", who);
     if (d->metric != PDEPTH_METRIC_L2 && d->metric != PDEPTH_METRIC_L1)
         return fail(PDEPTH_E_ARG, "%s: undefined metric for feature distance (%d)", who, d->metric);
-    if (d->algo < PDEPTH_ALGO_AUTO || d->algo > PDEPTH_ALGO_CORR)
+    if (d->algo < PDEPTH_ALGO_AUTO || d->algo > PDEPTH_ALGO_DIST)
         return fail(PDEPTH_E_ARG, "%s: unknown algo %d", who, d->algo);
 #ifdef PDEPTH_LAB
     if (d->algo == PDEPTH_ALGO_CELLS && (d->metric != PDEPTH_METRIC_L2 || d->D > pdepth::sweep_cells_max_planes()))
@@ -123,6 +143,8 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
 #endif
     if (d->algo == PDEPTH_ALGO_CORR && !uses_corr(d))
         return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_CORR needs the L2 metric, D <= 128 and C <= 72", who);
+    if (d->algo == PDEPTH_ALGO_DIST && !uses_dist(d))
+        return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_DIST needs the L2 metric, D <= 128, C <= 72 and at most 8 source views", who);
     if (d->algo == PDEPTH_ALGO_TILED_2 && d->D > 64)
         return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_TILED_2 needs D <= 64", who);
     if (d->algo >= PDEPTH_ALGO_TILED_1 && !uses_packed_source(d))
@@ -147,6 +169,7 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
             return launched(pdepth::launch_sweep_tiled_n1(a, workspace, (hipStream_t)stream, packed_ready), who);
         if (d->algo == PDEPTH_ALGO_TILED_2)
             return launched(pdepth::launch_sweep_tiled_n2(a, workspace, (hipStream_t)stream, packed_ready), who);
+        if (uses_dist(d)) return launched(pdepth::launch_sweep_dist(a, workspace, (hipStream_t)stream, packed_ready), who);
         if (uses_corr(d)) return launched(pdepth::launch_sweep_corr(a, workspace, (hipStream_t)stream, packed_ready), who);
 #ifdef PDEPTH_LAB
         if (d->algo == PDEPTH_ALGO_MFMA || (d->algo == PDEPTH_ALGO_AUTO && sweep_impl() == IMPL_MFMA && pdepth::sweep_mfma_supports(a)))
@@ -173,9 +196,14 @@ size_t pdepth_sweep_workspace_bytes(const pdepth_sweep_desc* desc) {
     return tiled_ws_bytes(desc);
 }
 
+int pdepth_sweep_source_layout(const pdepth_sweep_desc* desc) {
+    if (!desc || desc->B <= 0 || desc->V <= 0 || desc->C <= 0 || desc->D <= 0 || desc->H <= 0 || desc->W <= 0) return PDEPTH_LAYOUT_NONE;
+    return source_layout(desc);
+}
+
 int pdepth_sweep_centres_source(const pdepth_sweep_desc* desc) {
-    if (!desc || desc->B <= 0 || desc->V <= 0 || desc->C <= 0 || desc->D <= 0 || desc->H <= 0 || desc->W <= 0) return 0;
-    return uses_corr(desc) ? 1 : 0;
+    const int l = pdepth_sweep_source_layout(desc);
+    return (l == PDEPTH_LAYOUT_C4_CENTRED || l == PDEPTH_LAYOUT_DIST16) ? 1 : 0;
 }
 
 int pdepth_sweep_cost_f32(const pdepth_sweep_desc* desc, const pdepth_camera* cam, const float* ref,
@@ -212,6 +240,7 @@ int pdepth_pack_source_f32(const pdepth_sweep_desc* desc, const float* src, void
     a.src = src;
     a.B = desc->B; a.V = desc->V; a.C = desc->C; a.D = desc->D; a.H = desc->H; a.W = desc->W;
     a.src_bstride = desc->src_bstride; a.src_vstride = desc->src_vstride;
+    if (uses_dist(desc)) return launched(pdepth::launch_pack_dist(a, workspace, (hipStream_t)stream), who);
     return launched(pdepth::launch_pack_c4(a, workspace, (hipStream_t)stream, uses_corr(desc)), who);
 }
 
@@ -232,6 +261,9 @@ int pdepth_pack_views_f32(const pdepth_sweep_desc* desc, const float* feat, cons
         return fail(PDEPTH_E_WORKSPACE, "%s: workspace must be 256-byte aligned", who);
     pdepth::SweepArgs a{};
     a.B = desc->B; a.V = desc->V; a.C = desc->C; a.D = desc->D; a.H = desc->H; a.W = desc->W;
+    if (uses_dist(desc))
+        return launched(pdepth::launch_pack_views_dist(a, feat, rgb, pool_rate, desc->H * pool_rate, desc->W * pool_rate, ref_out, workspace,
+                                                       (hipStream_t)stream), who);
     return launched(pdepth::launch_pack_views(a, feat, rgb, pool_rate, desc->H * pool_rate, desc->W * pool_rate, ref_out, workspace,
                                               (hipStream_t)stream, uses_corr(desc)), who);
 }

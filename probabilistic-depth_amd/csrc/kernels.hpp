@@ -42,8 +42,17 @@ constexpr int CORR_DIRECT_SLOT = 53;       // ... pixel blocks evaluated directl
 constexpr int CORR_DIRECT_LAST_SLOT = 54;
 constexpr int CORR_PACK_TIMEOUT_SLOT = 55;   // ... workgroups that gave up waiting for the in-kernel pack (never, unless the counters were corrupted)
 // channel statistics of the source (workspace tail, sweep_pack.hip): per batch item mu[c] at +0, var[c] at +STATS_VAR, the
-// squared offset that was NOT subtracted at +STATS_OFF
-constexpr int STATS_VAR = 80, STATS_OFF = 160, STATS_STRIDE = 240;
+// squared offset that was NOT subtracted at +STATS_OFF, the largest sampled |x| at +STATS_AMAX, half the mean squared
+// difference of samples STATS_LAG_PX texels apart at +STATS_LAG (the spread of a channel at the distance of a plane sweep:
+// equal to var[c] for white features, smaller for smooth ones), and STATS_NFLAG ints at +STATS_FLAGS: [0] != 0 = a feature
+// of the item did not fit the fp16 range of the distance-form layout (pack_dist.hip)
+constexpr int STATS_VAR = 80, STATS_OFF = 160, STATS_AMAX = 240, STATS_LAG = 320, STATS_FLAGS = 400, STATS_NFLAG = 16, STATS_STRIDE = 416;
+constexpr int STATS_LAG_PX = 16;
+// which staging layout the packed-source region holds (written by the pack kernels, checked by the sweep kernels: a sweep on
+// another family's layout fills its outputs with NaN instead of returning numbers computed from the wrong bytes)
+constexpr int LAYOUT_SLOT = 56;
+constexpr int LAYOUT_C4 = 1, LAYOUT_C4_CENTRED = 2, LAYOUT_DIST16 = 3;   // (0: nothing packed yet)
+constexpr int DIST_DONE_SLOT = 57, DIST_DIRECT_SLOT = 58, DIST_DIRECT_LAST_SLOT = 59;   // sweep_dist.hip: as the CORR_ slots
 constexpr int PICK_SKIP_IF_SET = 1, PICK_RUN_IF_SET = 2;
 constexpr int PH_PRE = 1, PH_KERNEL = 2, PH_GATHER = 4, PH_ALL = 7;   // phases of a sweep launcher: pre-pass / flag clear, kernel, gather
 
@@ -80,6 +89,17 @@ int sweep_device_cus();
 size_t sweep_ws_flag_only_bytes(int B, int H, int W);
 size_t sweep_ws_flag_bytes(int B, int H, int W);
 size_t sweep_ws_stats_offset(int B, int V, int C, int H, int W);
+
+// sweep_pack.hip: the channel statistics alone (mean-centring on), for the pack kernels of pack_dist.hip
+hipError_t launch_feature_stats(const SweepArgs& a, float* stats, hipStream_t stream);
+hipError_t launch_view_stats(const SweepArgs& a, const float* feat, const float* rgb, int rate, int img_h, int img_w, float* stats, hipStream_t stream);
+// pack_dist.hip: statistics + the source views in the distance-form kernel's layout (dist_layout.hpp)
+hipError_t launch_pack_dist(const SweepArgs& a, void* workspace, hipStream_t stream);
+hipError_t launch_pack_views_dist(const SweepArgs& a, const float* feat, const float* rgb, int rate, int img_h, int img_w, float* ref_out,
+                                  void* workspace, hipStream_t stream);
+// sweep_dist.hip (L2 only): distance form sum_t w_t |s_t - r|^2 - Q on the matrix pipe (fp16 high / low parts), C <= 72, D <= 128
+bool sweep_dist_supports(const SweepArgs& a);
+hipError_t launch_sweep_dist(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready = false);
 
 // sweep_corr.hip (L2 only): correlation form on mean-centred features, one workgroup per block of 16 pixels
 bool sweep_corr_supports(const SweepArgs& a);

@@ -1,0 +1,769 @@
+// Plane sweep in the distance form of the L2 cost, one workgroup per block of 16 pixels: the default path of
+// pdepth_sweep_{cost,dpv}_f32 for the L2 metric (C <= 72, D <= 128, at most 8 source views).
+//
+//   what is computed.  est_swp_volume_v4 (warping/homography.py:98-135) evaluates, per pixel p and plane k,
+//           cost = | sum_t w_t s_t - r |^2 / sigma     (img_dis_L2_pard :80-82; t = the four bilinear taps :197, zero outside)
+//       and with sum_t w_t = 1 (dist_layout.hpp)
+//           | sum_t w_t s_t - r |^2 = sum_t w_t Y_t - Q,    Y_t = |s_t - r|^2,    Q = sum_{t<t'} w_t w_t' |s_t - s_t'|^2.
+//       Y for 16 neighbouring pixels x 16 consecutive texels of a source row is one 16 x 16 x K matrix product on fp16
+//       high / low parts of the centred, power-of-two scaled features (v_mfma_f32_16x16x32_f16, fp32 accumulation: 7
+//       instructions per block at C = 67, products exact, the sum as accurate as the fp32 matrix instruction's --
+//       tools/mb_split16.hip); Q = five squared neighbour differences per source cell from the pre-pass (pack_dist.hip).
+//       The source image carries a ring of zero-feature texels: no border cases.
+//
+//   how.  The 64 (128) planes of the 16 pixels are spread over the 256 threads of a workgroup -- thread (pixel n, tq) owns
+//       planes 4 tq .. 4 tq + 3 of each group of 64 (a PASS = one source view x one group of 64 planes):
+//         positions   bit-faithful sample positions (geometry.hpp), two planes per packed instruction;
+//         row table   per source row the run of texels any sample touches: LDS min / max, rows indexed modulo 64; barrier;
+//                     EVERY wave cuts the runs into blocks of 16 texels for itself (a prefix sum over the rows in registers:
+//                     no serial phase, no block list in LDS; a sample finds its slot with two ds_bpermute);
+//         Y           wave w multiplies blocks w, w + 4, ...: a block's texel operands are 2 NCHK + 1 16-byte loads per lane
+//                     whose only per-block address part is a scalar offset; two blocks in flight; Y[pixel][slot] to LDS; the
+//                     Q records of the block's 16 cells straight from memory to LDS (buffer_load ... lds); barrier;
+//         combine     per (pixel, plane): 4 Y values, 5 Q values, the bilinear weights;
+//         epilogue    cost store; log-softmax over D and E[d]: per wave partial (max, sum, sum d) of each pixel, merged
+//                     across the four waves through LDS (one barrier per pixel block).
+//       A pass whose planes need more than MAXB blocks or 64 rows (extreme poses), and every pass of a batch item whose
+//       statistics put it outside the domain of the distance form (guard below), is evaluated directly by the same
+//       workgroup behind the view loop, in the reference's own form on the packed features.
+//   scheduling.  Persistent workgroups pull 16x4 tiles from per-XCD queues (balanced half-bands, stealing); the last
+//       workgroup to leave zeroes the queue counters: a call on an already packed source is this one launch.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdlib>
+
+#include "dist_layout.hpp"
+#include "geometry.hpp"
+#include "kernels.hpp"
+#include "pick.hpp"
+#include "wave_util.hpp"
+
+#ifndef DIST_MAXB1
+#define DIST_MAXB1 22      // blocks of 16 texels a pass can take, D <= 64
+#endif
+#ifndef DIST_MAXB2
+#define DIST_MAXB2 32      // ... D > 64
+#endif
+#ifndef DIST_OCC1
+#define DIST_OCC1 4
+#endif
+#ifndef DIST_OCC2
+#define DIST_OCC2 3
+#endif
+#ifndef DIST_XPRIO
+#define DIST_XPRIO 1
+#endif
+#ifndef DIST_STORE_AUX
+#define DIST_STORE_AUX 2   // nt: the outputs are written once and not read by this kernel
+#endif
+#ifndef DIST_SPI1_BELOW
+#define DIST_SPI1_BELOW 2  // single pixel blocks as queue items below this many tiles per workgroup
+#endif
+#ifndef DIST_ONE_EACH_X
+#define DIST_ONE_EACH_X 2  // no queue up to this many items per resident workgroup
+#endif
+#ifndef DIST_GUARD_RATIO
+#define DIST_GUARD_RATIO 6.0f   // spread energy / lagged spread beyond which an item is evaluated directly (guard below)
+#endif
+
+namespace pdepth {
+
+namespace {
+
+using namespace wv;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+constexpr int DIST_MAXV = 8;   // source views whose homography terms a workgroup keeps in LDS
+
+struct DistArgs {
+    SweepArgs a;
+    const char* packed;
+    const float* stats;
+    int* queue;
+    int tiles_x, ntile, spi;
+};
+#define KARG(type, field) kernarg_at<type>(offsetof(DistArgs, field))
+
+template <int MAXB, int NAC>
+struct __attribute__((aligned(16))) DistLds {
+    static constexpr int XSTRIDE = MAXB * 16 + 4;   // floats per pixel of the Y buffer (stride / 4 odd: conflict-free b128 stores)
+    float Ys[16 * XSTRIDE];      // Y[pixel][slot]
+    float Qs[MAXB * 64 + 8];     // Q record (Dx0, Dy0, Dd, Dx1) per slot
+    _Float16 Bs[NAC * 4 * 16 * 8];   // pixel-side operands of the block's 16 pixels: [chunk][kq][pixel][8], -2 x (high | low) parts
+    float rp[4 * 16 * 2];        // per wave and pixel: partial |r'|^2, |r|^2 (scaled)
+    float mus[dist::MAX_C + 8];  // channel means x scale of the batch item in work
+    float xf[DIST_MAXV * 12];    // per view: K@R (9), K@t (3)
+    float cst[8];                // cx, cy, 1/cx, 1/cy, W/2, H/2, scale, 2^(-2e)/sigma
+    float red[4 * 16 * 4];       // epilogue exchange: (max, sum, sum d) per wave and pixel
+    float dcl[128];              // depth candidates
+    int cmin[2][64], cmax[2][64];   // per cell row (modulo 64): min / max x0; two sets, alternating by pass
+    int ired[2][2];              // min / max cell row of the pass; two sets
+    int item[2];                 // work item: current / next
+    int iflag;                   // the batch item in work: 1 = fp16 overflow in the pack, 2 = outside the domain (guard)
+    unsigned char wide[64];      // per batch item: pixel blocks are 16x1 (else 8x2)
+};
+
+// NCHK = chunks of 32 channels (dist_layout.hpp); NH = groups of 64 planes (ceil(D / 64): 1 or 2), each a pass of its own per
+// view: thread (n, tq) owns planes 64 h + 4 tq .. + 3 of pass h.
+template <int NCHK, int NH>
+__global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_dist_kernel(DistArgs da) {
+    constexpr int NAC = 2 * NCHK + 1;              // operand chunks of a texel / pixel: high[NCHK], low[NCHK], tail
+    constexpr int CPAD = 32 * NCHK + 8;            // channels, padded
+    constexpr int MCH = (CPAD + 15) / 16;          // channels per thread of the cooperative reference load
+    constexpr int MAXB = NH == 1 ? DIST_MAXB1 : DIST_MAXB2;
+    constexpr int BPW = (MAXB + 3) / 4;            // blocks per wave and pass
+    constexpr int NC = 4 * NH;                     // planes (costs) per thread
+    constexpr int QPL = 8 * NCHK + 4;              // the Q plane
+    typedef DistLds<MAXB, NAC> Lds;
+    constexpr int XSTRIDE = Lds::XSTRIDE;
+    __shared__ Lds L;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = KARG(int, a.D), H = KARG(int, a.H), W = KARG(int, a.W), V = KARG(int, a.V), C = KARG(int, a.C);
+    const int Wp = dist::wp(W);
+    const int PB = (int)dist::plane_bytes(H, W);   // (sweep_dist_supports: a view's planes lie below 2^31 bytes)
+
+    {
+        const float* dc = KARG(const float*, a.d_candi);
+        for (int k = tid; k < 64 * NH; k += 256) L.dcl[k] = dc[min(k, D - 1)];
+    }
+    if (tid < 64) {
+        L.cmin[0][tid] = INT_MAX; L.cmax[0][tid] = INT_MIN;
+        L.cmin[1][tid] = INT_MAX; L.cmax[1][tid] = INT_MIN;
+        L.wide[tid] = 1;
+    }
+    if (tid < 2) { L.ired[tid][0] = INT_MAX; L.ired[tid][1] = INT_MIN; }
+    __syncthreads();
+    // Shape of the pixel blocks of a batch item: 16x1 where the epipolar lines of view 0 run along the source rows (a
+    // rectified pair: the 16 pixels of a row share two source rows), else 8x2 (pick.hpp; any choice is correct).
+    if ((int)(tid >> 2) < min(KARG(int, a.B), 64) && epipolar_probe_is_steep(da.a, tid >> 2, tid & 3)) L.wide[tid >> 2] = 0;
+
+    // ---- work queue (per XCD) -------------------------------------------------------------------------------------------
+    // Workgroups are dealt round-robin over the 8 XCDs; XCD q owns the tiles of band q (its own queue counter), so that
+    // neighbouring tiles, whose source texels overlap, meet in that XCD's L2.  A workgroup whose queue is exhausted takes
+    // items of the others.  m = items per tile (1: a tile's four pixel blocks in sequence; 4: one block per item).
+    const int xcd = blockIdx.x & 7;
+    auto band_tiles_of = [&](int q) { const int nt = KARG(int, ntile); return (nt >> 3) + (q < (nt & 7) ? 1 : 0); };
+    auto band_first_of = [&](int q) {
+        const int nt = KARG(int, ntile), qq = nt >> 3, rr8 = nt & 7;
+        return q < rr8 ? q * (qq + 1) : rr8 * (qq + 1) + (q - rr8) * qq;
+    };
+    bool own_done = false;
+    auto steal = [&]() -> int {   // (queue << 28) | index in the queue, or -1: every queue is exhausted
+        int* queue = KARG(int*, queue);
+        const int mB = (4 / da.spi) * KARG(int, a.B);
+        for (int j = 1; j < 8; ++j) {
+            const int q = (xcd + j) & 7, nq = band_tiles_of(q) * mB;
+            if (*(volatile int*)&queue[q] >= nq) continue;
+            const int got = atomicAdd(&queue[q], 1);
+            if (got < nq) return (q << 28) | got;
+        }
+        return -1;
+    };
+    auto resolve = [&](int got) -> int {
+        const int n_own = band_tiles_of(xcd) * (4 / da.spi) * KARG(int, a.B);
+        if (!own_done && got < n_own) return (xcd << 28) | got;
+        own_done = true;
+        return steal();
+    };
+    // floor(nn / dd) for 0 <= nn < 2^22, 0 < dd (an integer divide costs ~40 dependent instructions)
+    auto fdiv = [](int nn, int dd) { return (int)(((float)nn + 0.5f) * __builtin_amdgcn_rcpf((float)dd)); };
+    auto decode = [&](int item, int& b_, int& tx_, int& ty_, int& sub0_) {
+        const int ntile = KARG(int, ntile), tiles_x = KARG(int, tiles_x), spi = da.spi;
+        const int m = 4 / spi, msh = spi == 1 ? 2 : 0, qq = ntile >> 3, rr8 = ntile & 7;
+        const bool small_idx = (long long)ntile * m * KARG(int, a.B) < (1ll << 22);
+        const int tiles_y_ = (H + 3) / 4;
+        const int q_ = item >> 28, iq = item & 0x0fffffff, band_tiles = band_tiles_of(q_), per_b = band_tiles * m;
+        b_ = small_idx ? fdiv(iq, per_b) : iq / per_b;
+        const int rem = iq - b_ * per_b, ti = rem >> msh;
+        sub0_ = (rem & (m - 1)) * spi;
+        int tile = band_first_of(q_) + ti;
+        if (rr8 == 0 && tiles_y_ % 16 == 0 && tiles_y_ * tiles_x == ntile) {
+            // XCD q owns half-bands q and 8 + q of the image's 16: on a forward motion the cost of a tile grows with its
+            // distance from the image centre, and this way every XCD gets the same mix; the heavier half first and, inside
+            // a half, columns from both image borders inwards.  (Any static partition is valid: dry queues steal.)
+            const int hb_rows = tiles_y_ / 16, half_tiles = hb_rows * tiles_x;
+            const int second = ti >= half_tiles ? 1 : 0, tih = ti - second * half_tiles;
+            const int hbi = (q_ < 4) == (second == 0) ? q_ : 8 + q_;
+            const int cc = small_idx ? fdiv(tih, hb_rows) : tih / hb_rows, r_ = tih - cc * hb_rows;
+            const int col = (cc & 1) ? tiles_x - 1 - (cc >> 1) : (cc >> 1);
+            tile = (hbi * hb_rows + r_) * tiles_x + col;
+        } else if (rr8 == 0 && qq % tiles_x == 0) {   // the band is a whole number of tile rows: column by column
+            const int band_rows = qq / tiles_x, tc = small_idx ? fdiv(ti, band_rows) : ti / band_rows;
+            tile = (q_ * band_rows + (ti - tc * band_rows)) * tiles_x + tc;
+        }
+        ty_ = small_idx ? fdiv(tile, tiles_x) : tile / tiles_x;
+        tx_ = tile - ty_ * tiles_x;
+    };
+    // (when the grid covers every item -- small problems -- workgroup i takes item i of its XCD's band: no atomics)
+    const bool one_each = (long long)gridDim.x >= 8ll * ((KARG(int, ntile) + 7) / 8) * (4 / da.spi) * KARG(int, a.B);
+    __syncthreads();
+
+    int slot_par = 0;
+    int pt = 0;           // running pass counter: selects the set of row-table arrays
+    int n_direct = 0;     // (thread 0) pixel blocks evaluated directly
+    int b_tables = -1;    // batch item whose tables (means, homography terms, camera constants) are in LDS
+    // (thread 0) the atomic on the own queue is issued at the top of an item and its result looked at when the item is done
+    int got_own = (tid == 0 && !one_each) ? atomicAdd(&KARG(int*, queue)[xcd], 1) : (int)(blockIdx.x >> 3);
+    bool first = true;
+
+    for (;;) {
+        if (tid == 0) {
+            const int n_own = band_tiles_of(xcd) * (4 / da.spi) * KARG(int, a.B);
+            L.item[slot_par] = one_each ? (first && got_own < n_own ? (xcd << 28) | got_own : -1) : resolve(got_own);
+        }
+        first = false;
+        PDEPTH_LDS_BARRIER();   // the item is published; every wave is done with the previous one's LDS
+        const int item = __builtin_amdgcn_readfirstlane(*(volatile int*)&L.item[slot_par]);
+        slot_par ^= 1;
+        if (item < 0) break;
+        if (tid == 0 && !one_each && !own_done) got_own = atomicAdd(&KARG(int*, queue)[xcd], 1);
+        int b, tx, ty, sub0;
+        decode(item, b, tx, ty, sub0);
+        // per BATCH item, for every wave: scaled channel means, the views' homography terms, the camera constants, the item's
+        // flags (visible behind the barrier in front of the first block's centring).  Items come out of the queues batch item
+        // by batch item: the tables are rebuilt a few times per launch, not once per tile.
+        const bool new_b = b != b_tables;
+        if (new_b) {
+            b_tables = b;
+            const float* st = da.stats + (size_t)b * STATS_STRIDE;
+            if (wave == 0) {
+                // the scale (dist_layout.hpp: the same function of the same numbers as in the pack kernel) and the guard
+                float am = st[STATS_AMAX + lane], sv = st[STATS_VAR + lane], sl = st[STATS_LAG + lane];
+                if (lane + 64 < STATS_VAR) { am = fmaxf(am, st[STATS_AMAX + lane + 64]); sv += st[STATS_VAR + lane + 64]; sl += st[STATS_LAG + lane + 64]; }
+#pragma unroll
+                for (int sh = 32; sh >= 1; sh >>= 1) {
+                    am = fmaxf(am, __shfl_xor(am, sh)); sv += __shfl_xor(sv, sh); sl += __shfl_xor(sl, sh);
+                }
+                const int e = dist::scale_exponent(am);
+                const float sc = ldexpf(1.0f, e);
+                // Guard.  The rounding error of Y = N - 2X + |r'|^2 grows with the energy of the centred features, the cost with
+                // their spread at the distance of a sweep: where the first exceeds the second by more than DIST_GUARD_RATIO
+                // (strong trends across the image that a constant per channel cannot remove) the item is evaluated directly.
+                const bool outside = sv > DIST_GUARD_RATIO * sl && sl >= 0.0f;
+                if (lane == 0) {
+                    const float sg = KARG(float, a.sigma);
+                    L.cst[6] = sc; L.cst[7] = ldexpf(refined_rcp(sg), -2 * e);
+                    const int pf = reinterpret_cast<const int*>(st + STATS_FLAGS)[0];
+                    L.iflag = (pf != 0 ? 1 : 0) | (outside ? 2 : 0);
+                }
+                for (int c = lane; c < dist::MAX_C + 8; c += 64) L.mus[c] = st[c] * sc;
+            }
+            if (tid >= 128 && tid < 128 + V) {
+                const int v = tid - 128;
+                ViewXform xf;
+                make_view_xform(KARG(const float*, a.K) + b * 9, KARG(const float*, a.R) + ((size_t)b * V + v) * 9,
+                                KARG(const float*, a.t) + ((size_t)b * V + v) * 3, da.a.blas_mode, xf);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) L.xf[v * 12 + i] = xf.kr[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) L.xf[v * 12 + 9 + i] = xf.kt[i];
+            }
+            if (tid == 255) {
+                const float* const cxcy_ = KARG(const float*, a.cxcy);
+                const float cx = cxcy_[b * 2 + 0], cy = cxcy_[b * 2 + 1];
+                L.cst[0] = cx; L.cst[1] = cy; L.cst[2] = refined_rcp(cx); L.cst[3] = refined_rcp(cy);
+                L.cst[4] = (float)W / 2.0f; L.cst[5] = (float)H / 2.0f;
+            }
+        }
+        const bool wide = b < 64 ? L.wide[b] != 0 : false;
+        bool item_ready = !new_b;
+        float ray[3], rv[MCH];
+        const int spi = da.spi;
+
+        for (int sub = sub0; sub < sub0 + spi; ++sub) {
+            if ((wide ? ty * 4 + sub : ty * 4 + 2 * (sub >> 1)) >= H) continue;   // the block lies below the image (uniform)
+            // lane roles: in the vector phases thread (n, tq) owns pixel n of the block and planes 64 h + 4 tq .. + 3; in the
+            // matrix phase lane (n, kq) of a wave feeds texel / pixel n and K slice kq.  (opaque: the optimiser otherwise
+            // hoists every lane-derived invariant of the phases to the top of the kernel and spills them)
+            const int tid = opaque_v((int)threadIdx.x), lane = tid & 63;   // (shadow the kernel's: re-derived per pixel block)
+            const int n = lane & 15, kq = lane >> 4, tq = wave * 4 + kq;
+            const int HW = opaque_s(H * W);
+            const int x = wide ? tx * 16 + n : tx * 16 + 8 * (sub & 1) + (n & 7);
+            const int y = wide ? ty * 4 + sub : ty * 4 + 2 * (sub >> 1) + (n >> 3);
+            const bool xlive = x < W && y < H;
+            const int p = min(y, H - 1) * W + min(x, W - 1);
+            // the pixel's ray, and this thread's share of the block's reference features: channels tq, tq + 16, ... of pixel n
+            // (buffer loads: 32-bit offsets, the channel as the scalar offset; channels beyond C = 0)
+            {
+                const __amdgpu_buffer_rsrc_t rray =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(da.a.rays + (size_t)b * 3 * HW), 0, 3 * HW * 4, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) ray[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rray, p * 4, i * HW * 4, 0));
+                const __amdgpu_buffer_rsrc_t rref =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(da.a.ref + (size_t)b * da.a.ref_bstride), 0, C * HW * 4, 0x00020000);
+#pragma unroll
+                for (int mm = 0; mm < MCH; ++mm)
+                    rv[mm] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rref, tq + 16 * mm < C ? (tq * HW + p) * 4 : OOB, 16 * mm * HW * 4, 0));
+            }
+            float rr = 0.0f, zc = 0.0f;    // |r'|^2 and |r|^2 of the pixel, scaled (set with the first pass)
+            bool centred = false;
+            unsigned failmask = 0;         // uniform over the workgroup: passes (view v, plane group h) left to the direct evaluation
+
+            float cost[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) cost[j] = 0.0f;
+
+            for (int v = 0; v < V; ++v) {
+                const char* srcv = da.packed + (size_t)((size_t)b * V + v) * dist::view_bytes(C, H, W);
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)srcv, 0, (int)dist::view_bytes(C, H, W), 0x00020000);
+
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const int par = pt & 1;
+                    if (!item_ready) { PDEPTH_LDS_BARRIER(); item_ready = true; }   // (the item's tables above are in LDS)
+                    // ---- sample positions of this thread's planes of the pass (NO_CELL: no tap in the image, plane beyond D,
+                    //      pixel beyond the image)
+                    int cell[4];
+                    float fw[4], fn[4];
+                    {
+                        ViewXform xf;
+                        float t2a, t2b, t2c;
+                        {
+                            const v4f k0 = *reinterpret_cast<const v4f*>(&L.xf[v * 12]), k1 = *reinterpret_cast<const v4f*>(&L.xf[v * 12 + 4]),
+                                      k2 = *reinterpret_cast<const v4f*>(&L.xf[v * 12 + 8]);
+                            xf.kr[0] = k0.x; xf.kr[1] = k0.y; xf.kr[2] = k0.z; xf.kr[3] = k0.w; xf.kr[4] = k1.x; xf.kr[5] = k1.y;
+                            xf.kr[6] = k1.z; xf.kr[7] = k1.w; xf.kr[8] = k2.x; xf.kt[0] = k2.y; xf.kt[1] = k2.z; xf.kt[2] = k2.w;
+                            xf.separate = da.a.blas_mode;
+                            ray_term2(xf, ray[0], ray[1], ray[2], t2a, t2b, t2c);
+                        }
+                        const v4f c0 = *reinterpret_cast<const v4f*>(&L.cst[0]);
+                        const v2f c1 = *reinterpret_cast<const v2f*>(&L.cst[4]);
+#pragma unroll
+                        for (int j = 0; j < 4; j += 2) {
+                            const int k = 64 * h + 4 * tq + j;
+                            v2f ix, iy;
+#ifdef DIST_PACKED_POS
+                            plane_sample_pos_fast2(xf, t2a, t2b, t2c, v2f{L.dcl[k], L.dcl[k + 1]}, c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ix, iy);
+#else
+                            // (scalar instructions: packed fp32 -- two planes per v_pk_* instruction -- now and then loses the low
+                            //  half of a result in lanes 48..63 in this kernel on gfx950: wave_util.hpp)
+                            {
+                                float ax, ay, bx, by;
+                                plane_sample_pos_fast(xf, t2a, t2b, t2c, L.dcl[k], c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ax, ay);
+                                plane_sample_pos_fast(xf, t2a, t2b, t2c, L.dcl[k + 1], c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, bx, by);
+                                ix = v2f{ax, bx}; iy = v2f{ay, by};
+                            }
+#endif
+                            cell[j] = cell_of(ix.x, iy.x, W, H, fw[j], fn[j]);
+                            cell[j + 1] = cell_of(ix.y, iy.y, W, H, fw[j + 1], fn[j + 1]);
+                            if (k >= D || !xlive) cell[j] = NO_CELL;
+                            if (k + 1 >= D || !xlive) cell[j + 1] = NO_CELL;
+                        }
+                        // (pinned: the optimiser otherwise carries the positions AND their floors to the combine instead of the fractions)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(fw[j])); asm volatile("" : "+v"(fn[j])); }
+                    }
+                    // ---- row table: contributions of this thread's planes --------------------------------------------------
+                    {
+                        int lmin = INT_MAX, lmax = INT_MIN;
+                        int run = INT_MIN, rmin = 0, rmax = 0;   // consecutive planes of equal row are folded first
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (cell[j] != NO_CELL) {
+                                const int cyy = cell_y(cell[j]), cxx = cell_x(cell[j]);
+                                lmin = min(lmin, cyy); lmax = max(lmax, cyy);
+                                if (cyy != run) {
+                                    if (run != INT_MIN) { atomicMin(&L.cmin[par][run & 63], rmin); atomicMax(&L.cmax[par][run & 63], rmax); }
+                                    run = cyy; rmin = cxx; rmax = cxx;
+                                } else {
+                                    rmin = min(rmin, cxx); rmax = max(rmax, cxx);
+                                }
+                            }
+                        }
+                        if (run != INT_MIN) { atomicMin(&L.cmin[par][run & 63], rmin); atomicMax(&L.cmax[par][run & 63], rmax); }
+                        const int wmin = wave_min_i(lmin), wmax = wave_max_i(lmax);
+                        if (lane == 0 && wmin <= wmax) { atomicMin(&L.ired[par][0], wmin); atomicMax(&L.ired[par][1], wmax); }
+                    }
+                    if (!centred) {
+                        // (first pass of the block) this thread's channels of pixel n: x' = (r - mu) 2^e, split into fp16 high and
+                        // low parts, times -2, into the pixel-side operand image of the block; and its share of |r'|^2 and |r|^2.
+                        // Channel c = tq + 16 mm: chunk (c >> 5) for c < 32 NCHK, K slot c & 31; else the tail chunk: K slots t (its
+                        // high part, against the texel's high part), 8 + t (high, against the texel's low part), 16 + t (low).
+                        const float sc = L.cst[6];
+                        float pr = 0.0f, pz = 0.0f;
+#pragma unroll
+                        for (int mm = 0; mm < MCH; ++mm) {
+                            const int c = tq + 16 * mm;
+                            const bool has = c < CPAD;   // (only the last round can fall beyond the padded channels)
+                            const float m = L.mus[min(c, dist::MAX_C + 7)];
+                            const float xs = has ? __builtin_fmaf(rv[mm], sc, -m) : 0.0f;
+                            const float rs = has ? rv[mm] * sc : 0.0f;
+                            pr = __builtin_fmaf(xs, xs, pr);
+                            pz = __builtin_fmaf(rs, rs, pz);
+                            const float xc = fminf(fmaxf(xs, -32000.0f), 32000.0f);
+                            const _Float16 hh = (_Float16)xc;
+                            const _Float16 ll = (_Float16)(xc - (float)hh);
+                            const _Float16 bh = (_Float16)(-2.0f * (float)hh), bl = (_Float16)(-2.0f * (float)ll);
+                            if (16 * mm < 32 * NCHK) {   // (compile time: the round lies in a chunk of 32)
+                                const int chunk = (16 * mm) >> 5, kqq = 2 * (mm & 1) + (tq >> 3), jj = tq & 7;
+                                L.Bs[((chunk * 4 + kqq) * 16 + n) * 8 + jj] = bh;
+                                L.Bs[(((NCHK + chunk) * 4 + kqq) * 16 + n) * 8 + jj] = bl;
+                            } else if (has) {
+                                const int t = tq;   // (c - 32 NCHK)
+                                L.Bs[(((2 * NCHK) * 4 + 0) * 16 + n) * 8 + t] = bh;
+                                L.Bs[(((2 * NCHK) * 4 + 1) * 16 + n) * 8 + t] = bh;
+                                L.Bs[(((2 * NCHK) * 4 + 2) * 16 + n) * 8 + t] = bl;
+                            }
+                        }
+                        pr = pr + __shfl_xor(pr, 16); pr = pr + __shfl_xor(pr, 32);
+                        pz = pz + __shfl_xor(pz, 16); pz = pz + __shfl_xor(pz, 32);
+                        if (kq == 0) *reinterpret_cast<v2f*>(&L.rp[(wave * 16 + n) * 2]) = v2f{pr, pz};
+                    }
+                    PDEPTH_LDS_BARRIER();   // tables (and the operand image) complete
+                    if (!centred) {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const v2f pp = *reinterpret_cast<const v2f*>(&L.rp[(w * 16 + n) * 2]);
+                            rr = rr + pp.x; zc = zc + pp.y;
+                        }
+                        centred = true;
+                    }
+                    // the pixel-side operands of lane (n, kq): high[NCHK], low[NCHK], tail -- from LDS every pass (they would
+                    // otherwise occupy registers through the vector phases of every further pass)
+                    h8 Bv[NAC];
+#pragma unroll
+                    for (int i = 0; i < NAC; ++i) Bv[i] = *reinterpret_cast<const h8*>(&L.Bs[((i * 4 + kq) * 16 + n) * 8]);
+                    {
+                        // the specials of the tail chunk (K slots 24..31 = lanes kq == 3): the constants that multiply the texel's
+                        // pieces of N, and |r'|^2 as three fp16 pieces against the texel's constants (dist_layout.hpp)
+                        const dist::Pieces pq = dist::split_pieces(fminf(rr, 2.0e9f));
+                        h8 sp;
+                        sp[0] = (_Float16)dist::PIECE_C1; sp[1] = (_Float16)dist::PIECE_C2; sp[2] = (_Float16)dist::PIECE_C3;
+                        sp[3] = pq.p1; sp[4] = pq.p2; sp[5] = pq.p3; sp[6] = (_Float16)0.f; sp[7] = (_Float16)0.f;
+                        if (kq == 3) Bv[NAC - 1] = sp;
+                    }
+                    // ---- the row table, cut into blocks of 16 texels: every wave for itself, lane = texel row yb + lane -------
+                    const int yb = __builtin_amdgcn_readfirstlane(L.ired[par][0]), yt = __builtin_amdgcn_readfirstlane(L.ired[par][1]);
+                    int nb = 0, lo = INT_MAX, hi = INT_MIN, nblk = 0, fb = 0;
+                    bool fits = true;
+                    if (yb <= yt) {
+                        const int ncell = yt - yb + 1;
+                        if (ncell + 1 > 64 || ncell + 1 > MAXB) {   // (every texel row takes a block; rows are kept modulo 64)
+                            fits = false;
+                        } else {
+                            // the cells of rows lane - 1 and lane touch texel row lane
+                            if (lane < ncell) { lo = L.cmin[par][(yb + lane) & 63]; hi = L.cmax[par][(yb + lane) & 63]; }
+                            if (lane >= 1 && lane <= ncell) {
+                                lo = min(lo, L.cmin[par][(yb + lane - 1) & 63]);
+                                hi = max(hi, L.cmax[par][(yb + lane - 1) & 63]);
+                            }
+                            nblk = lo <= hi ? (hi - lo + 2 + 15) >> 4 : 0;   // texels lo .. hi + 1
+                            const int incl = wave_scan_incl(nblk);
+                            nb = __builtin_amdgcn_readlane(incl, 63);
+                            fits = nb <= MAXB;
+                            fb = incl - nblk;
+                        }
+                    }
+                    if (L.iflag != 0) fits = false;   // (the item is evaluated directly)
+                    const int rowoff = 16 * fb - lo;    // slot of texel x of this lane's row = x + rowoff
+                    const bool go = fits && nb > 0;
+                    // ---- Y = |s' - r'|^2 for the blocks of the pass, on the matrix pipe --------------------------------------
+                    int sl[4];   // slots of the top (low 16 bits) / bottom row of this thread's cells; < 0: no cell
+                    {
+                        v4i rs4;   // the descriptor of rsrc, spelled out for the inline asm
+                        {
+                            const unsigned long long pa = reinterpret_cast<unsigned long long>(srcv);
+                            rs4.x = (int)(unsigned)pa; rs4.y = (int)(unsigned)(pa >> 32) & 0xffff; rs4.z = (int)dist::view_bytes(C, H, W); rs4.w = 0x00020000;
+                        }
+                        const int voffA = opaque_v(n * 16 + kq * PB);
+                        // a block's texel operands in consumption order: (high c, low c) for c < NCHK, tail; ONE register set, every
+                        // chunk refilled with the next block's right behind its last multiplication (a block in flight per wave)
+                        h8 S[NAC];
+                        // block bi of the pass: its row = the lane with fb <= bi < fb + nblk, its first texel lo + 16 (bi - fb);
+                        // the scalar byte offset of that texel in plane 0
+                        auto prep = [&](int bi) -> int {
+                            const unsigned long long mk = __builtin_amdgcn_ballot_w64(nblk > 0 && bi >= fb && bi < fb + nblk);
+                            const int rho = (int)__builtin_ctzll(mk | (1ull << 63));
+                            const int xs = __builtin_amdgcn_readlane(lo, rho) + 16 * (bi - __builtin_amdgcn_readlane(fb, rho));
+                            return ((yb + rho + dist::RING) * Wp + xs + dist::RING) * 16;
+                        };
+                        auto fetch = [&](int i, int soff) {   // chunk i: planes 4 i .. 4 i + 3 (the lane's: + kq, in voffA)
+                            S[i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffA, soff + i * 4 * PB, 0));
+                        };
+                        // the Q records of the block's 16 cells, from memory straight to LDS
+#ifdef DIST_Q_NODMA
+                        auto fetch_q = [&](int bi, int soff) {
+                            if (lane < 16) *reinterpret_cast<v4f*>(&L.Qs[bi * 64 + lane * 4]) =
+                                __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, soff + QPL * PB, 0));
+                        };
+#else
+                        auto fetch_q = [&](int bi, int soff) { if (lane < 16) dma_b128(rs4, lds_addr_of(&L.Qs[bi * 64]), lane * 16, soff + QPL * PB); };
+#endif
+                        if (DIST_XPRIO) __builtin_amdgcn_s_setprio(DIST_XPRIO);
+                        if (go && wave < nb) {
+                            const int soff = prep(wave);
+#pragma unroll
+                            for (int c = 0; c < NCHK; ++c) { fetch(c, soff); fetch(NCHK + c, soff); }
+                            fetch(NAC - 1, soff);
+                            fetch_q(wave, soff);
+                        }
+                        // the slots of this thread's cells (under the first block's loads)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool has = fits && cell[j] != NO_CELL;
+                            const int r = has ? cell_y(cell[j]) - yb : 0;
+                            const int o0 = __builtin_amdgcn_ds_bpermute(4 * r, rowoff), o1 = __builtin_amdgcn_ds_bpermute(4 * r + 4, rowoff);
+                            const int cxx = cell_x(cell[j]);
+                            sl[j] = has ? (cxx + o0) | ((cxx + o1) << 16) : -1;
+                        }
+                        if (go) {
+                            // wave w: blocks w, w + 4, ...
+#pragma unroll
+                            for (int i = 0; i < BPW; ++i) {
+                                const int bi = wave + 4 * i;
+                                if (bi >= nb) break;
+                                const bool more = i + 1 < BPW && bi + 4 < nb;   // uniform
+                                const int soff = more ? prep(bi + 4) : 0;
+                                if (more) fetch_q(bi + 4, soff);
+                                v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                                for (int c = 0; c < NCHK; ++c) {
+                                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(S[c], Bv[c], acc, 0, 0, 0);
+                                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(S[c], Bv[NCHK + c], acc, 0, 0, 0);
+                                    if (more) fetch(c, soff);
+                                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(S[NCHK + c], Bv[c], acc, 0, 0, 0);
+                                    if (more) fetch(NCHK + c, soff);
+                                }
+                                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(S[NAC - 1], Bv[NAC - 1], acc, 0, 0, 0);
+                                if (more) fetch(NAC - 1, soff);
+                                *reinterpret_cast<v4f*>(&L.Ys[n * XSTRIDE + 16 * bi + 4 * kq]) = acc;   // Y[texel 4 kq ..][pixel n] of the block
+                            }
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's Q records have landed in LDS
+                        }
+                        if (DIST_XPRIO) __builtin_amdgcn_s_setprio(0);
+                    }
+                    PDEPTH_LDS_BARRIER();   // Y and the Q records of the pass are complete
+                    ++pt;
+                    // (every wave has read the tables of this pass: wave 1 cleans them for the pass after the next)
+                    if (wave == 1) {
+                        L.cmin[par][lane] = INT_MAX; L.cmax[par][lane] = INT_MIN;
+                        if (lane == 0) { L.ired[par][0] = INT_MAX; L.ired[par][1] = INT_MIN; }
+                    }
+
+                    // ---- combine: cost of this thread's planes of the pass ------------------------------------------------
+                    if (!fits) {
+                        failmask |= 1u << (v * NH + h);   // (evaluated directly behind the view loop)
+                    } else {
+                        const float cinv = L.cst[7];
+                        const float* yr = &L.Ys[n * XSTRIDE];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            // (no tap inside the image: the taps read zero, cost = |r|^2 -- and NaN where the position itself
+                            //  is not finite, as the reference's weights inf - floor(inf) make it)
+                            float q = zc + (fw[j] + fn[j]) * 0.0f;
+                            if (sl[j] >= 0) {
+                                const int s0 = sl[j] & 0xffff, s1 = sl[j] >> 16;
+                                const float Y00 = yr[s0], Y01 = yr[s0 + 1], Y10 = yr[s1], Y11 = yr[s1 + 1];
+                                const v4f qa = *reinterpret_cast<const v4f*>(&L.Qs[s0 * 4]);   // Dx0, Dy0, Dd, Dx1
+                                const float dy1 = L.Qs[s0 * 4 + 5];                            // Dy0 of the right neighbour
+                                const float ex = 1.0f - fw[j], ey = 1.0f - fn[j];
+                                const float w00 = ey * ex, w01 = ey * fw[j], w10 = fn[j] * ex, w11 = fn[j] * fw[j];
+                                const float ys = __builtin_fmaf(w11, Y11, __builtin_fmaf(w10, Y10, __builtin_fmaf(w01, Y01, w00 * Y00)));
+                                const float qi = __builtin_fmaf(w11, qa.z, __builtin_fmaf(w10, qa.y, w01 * qa.x));
+                                const float qo = __builtin_fmaf(w01, dy1, w10 * qa.w);
+                                q = ys - __builtin_fmaf(w11, qo, w00 * qi);
+                            }
+                            cost[4 * h + j] = cost[4 * h + j] + q * cinv;
+                        }
+                    }
+                }
+            }
+
+            if (failmask != 0) {
+                // Passes left to the direct evaluation: the reference's own form on the packed features -- per plane the four
+                // taps of every group of 8 channels by two 16-byte loads each (high + low parts), the pixel's centred reference
+                // features from the operand image in LDS.  An item whose features did not fit the fp16 range: NaN.
+                const v4f c0 = *reinterpret_cast<const v4f*>(&L.cst[0]), c1 = *reinterpret_cast<const v4f*>(&L.cst[4]);
+                const bool ovf = (L.iflag & 1) != 0;
+#pragma unroll 1
+                for (int vh = 0; vh < V * NH; ++vh) {
+                    if (!(failmask >> vh & 1u)) continue;
+                    if (tid == 0) ++n_direct;
+                    const int v = vh / NH, h = vh - v * NH;
+                    ViewXform xf;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) xf.kr[i] = L.xf[v * 12 + i];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) xf.kt[i] = L.xf[v * 12 + 9 + i];
+                    xf.separate = da.a.blas_mode;
+                    float t2a, t2b, t2c;
+                    ray_term2(xf, ray[0], ray[1], ray[2], t2a, t2b, t2c);
+                    const char* srcv = da.packed + (size_t)((size_t)b * V + v) * dist::view_bytes(C, H, W);
+#pragma unroll 1
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = 64 * h + 4 * tq + j;
+                        float ix, iy, fwj, fnj;
+                        plane_sample_pos_fast(xf, t2a, t2b, t2c, L.dcl[k], c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ix, iy);
+                        int cellj = cell_of(ix, iy, W, H, fwj, fnj);
+                        if (k >= D || !xlive) cellj = NO_CELL;
+                        float q = zc + (fwj + fnj) * 0.0f;   // (no tap inside the image)
+                        if (cellj != NO_CELL) {
+                            const int cxx = cell_x(cellj), cyy = cell_y(cellj);
+                            const float ex = 1.0f - fwj, ey = 1.0f - fnj;
+                            const float w00 = ey * ex, w01 = ey * fwj, w10 = fnj * ex, w11 = fnj * fwj;
+                            const size_t t00 = ((size_t)(cyy + dist::RING) * Wp + cxx + dist::RING) * 16;
+                            float part = 0.0f;
+#pragma unroll 1
+                            for (int g = 0; g < 4 * NCHK + 1; ++g) {
+                                // planes of the group's high and low parts; the pixel's: chunk g >> 2 (tail: 2 NCHK), K slice g & 3 (tail: 0 | 2)
+                                const bool tail = g == 4 * NCHK;
+                                const char* ph = srcv + (size_t)(tail ? 8 * NCHK : g) * PB + t00;
+                                const char* pl = srcv + (size_t)(tail ? 8 * NCHK + 1 : 4 * NCHK + g) * PB + t00;
+                                const h8 a00 = *reinterpret_cast<const h8*>(ph), a01 = *reinterpret_cast<const h8*>(ph + 16);
+                                const h8 a10 = *reinterpret_cast<const h8*>(ph + (size_t)Wp * 16), a11 = *reinterpret_cast<const h8*>(ph + (size_t)Wp * 16 + 16);
+                                const h8 l00 = *reinterpret_cast<const h8*>(pl), l01 = *reinterpret_cast<const h8*>(pl + 16);
+                                const h8 l10 = *reinterpret_cast<const h8*>(pl + (size_t)Wp * 16), l11 = *reinterpret_cast<const h8*>(pl + (size_t)Wp * 16 + 16);
+                                const h8 rh = *reinterpret_cast<const h8*>(&L.Bs[(((tail ? 2 * NCHK : (g >> 2)) * 4 + (tail ? 0 : (g & 3))) * 16 + n) * 8]);
+                                const h8 rl = *reinterpret_cast<const h8*>(&L.Bs[(((tail ? 2 * NCHK : NCHK + (g >> 2)) * 4 + (tail ? 2 : (g & 3))) * 16 + n) * 8]);
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    float val = ((float)a00[i] + (float)l00[i]) * w00;
+                                    val = __builtin_fmaf((float)a01[i] + (float)l01[i], w01, val);
+                                    val = __builtin_fmaf((float)a10[i] + (float)l10[i], w10, val);
+                                    val = __builtin_fmaf((float)a11[i] + (float)l11[i], w11, val);
+                                    const float rq = -0.5f * ((float)rh[i] + (float)rl[i]);
+                                    const float diff = val - rq;
+                                    part = __builtin_fmaf(diff, diff, part);
+                                }
+                            }
+                            q = part + (fwj + fnj) * 0.0f;
+                        }
+                        if (ovf) q = __builtin_nanf("");
+                        const float cj = q * L.cst[7];
+#pragma unroll
+                        for (int jj = 0; jj < NC; ++jj) cost[jj] = cost[jj] + (jj == 4 * h + j ? cj : 0.0f);
+                    }
+                }
+            }
+            // ---- epilogue: cost store, log-softmax over D, expectation ----------------------------------------------------
+            // (buffer stores: one 32-bit lane offset, the plane as the scalar offset: plane 64 h + 16 wave + 4 kq + j)
+            const int ovoff = xlive ? (4 * kq * HW + p) * 4 : OOB;
+            float* const cost_out = da.a.cost_out;
+            float* const logp_out = da.a.logp_out;
+            float* const depth_out = da.a.depth_out;
+            if (cost_out) {
+                const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(cost_out + (size_t)b * D * HW), 0, D * HW * 4, 0x00020000);
+#pragma unroll
+                for (int j = 0; j < NC; ++j)   // (planes beyond D lie beyond the descriptor: dropped)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cost[j]), rc, ovoff, (64 * (j >> 2) + 16 * wave + (j & 3)) * HW * 4, DIST_STORE_AUX);
+            }
+            if (logp_out || depth_out) {
+                // per wave: max, sum exp, sum d exp over its planes of pixel n; merged over the four waves through LDS
+                float mx = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < NC; ++j)
+                    if (64 * (j >> 2) + 4 * tq + (j & 3) < D) mx = fmaxf(mx, cost[j]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float ssum = 0.0f, esum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    const int k = 64 * (j >> 2) + 4 * tq + (j & 3);
+                    const float ek = k < D ? exp_nonpos(cost[j] - mx) : 0.0f;
+                    ssum = ssum + ek;
+                    esum = __builtin_fmaf(L.dcl[k], ek, esum);
+                }
+                ssum = ssum + __shfl_xor(ssum, 16); ssum = ssum + __shfl_xor(ssum, 32);
+                esum = esum + __shfl_xor(esum, 16); esum = esum + __shfl_xor(esum, 32);
+                if (kq == 0) *reinterpret_cast<v4f*>(&L.red[(wave * 16 + n) * 4]) = v4f{mx, ssum, esum, 0.0f};
+                PDEPTH_LDS_BARRIER();
+                float M = -INFINITY;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) M = fmaxf(M, L.red[(w * 16 + n) * 4]);
+                float S = 0.0f, E = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const v4f part = *reinterpret_cast<const v4f*>(&L.red[(w * 16 + n) * 4]);
+                    // (a wave whose planes all lie beyond D: max -inf, sums 0)
+                    const float scw = part.x == -INFINITY ? 0.0f : exp_nonpos(part.x - M);
+                    S = __builtin_fmaf(part.y, scw, S);
+                    E = __builtin_fmaf(part.z, scw, E);
+                }
+                const float ls = logf(S);
+                if (logp_out) {
+                    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(logp_out + (size_t)b * D * HW), 0, D * HW * 4, 0x00020000);
+#pragma unroll
+                    for (int j = 0; j < NC; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (cost[j] - M) - ls), rl, ovoff,
+                                                              (64 * (j >> 2) + 16 * wave + (j & 3)) * HW * 4, DIST_STORE_AUX);
+                }
+                if (depth_out && xlive && tq == 0) depth_out[(size_t)b * HW + p] = E / S;
+            } else {
+                PDEPTH_LDS_BARRIER();   // (every wave is done with the block's operand image before the next block's centring)
+            }
+        }   // pixel blocks of the item
+    }   // items
+
+    // the last workgroup to leave zeroes the queue counters: the next call on this workspace needs no clearing launch
+    if (tid == 0) {
+        int* queue = KARG(int*, queue);
+        if (n_direct) atomicAdd(&queue[DIST_DIRECT_SLOT], n_direct);
+        const int done = atomicAdd(&queue[DIST_DONE_SLOT], 1);
+        if (done == (int)gridDim.x - 1) {
+            const int nd = atomicAdd(&queue[DIST_DIRECT_SLOT], 0);
+            for (int q = 0; q < 8; ++q) queue[q] = 0;
+            queue[DIST_DONE_SLOT] = 0;
+            queue[DIST_DIRECT_SLOT] = 0;
+            queue[DIST_DIRECT_LAST_SLOT] = nd;   // diagnostics: pixel blocks of this call evaluated directly
+        }
+    }
+}
+
+template <int NCHK, int NH>
+hipError_t launch_inst(const SweepArgs& a, const char* packed, const float* stats, int* queue, int tiles_x, int tiles, hipStream_t stream) {
+    auto kern = sweep_dist_kernel<NCHK, NH>;
+    // persistent grid: as many workgroups as the chip holds at once (registers and LDS decide: asked once per
+    // instantiation and device), a multiple of 8; fewer when there is less work
+    static int per_cu[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (per_cu[dev] == 0) {
+        int nbk = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbk, kern, 256, 0) != hipSuccess || nbk <= 0) nbk = 2;
+        per_cu[dev] = nbk > 5 ? 5 : nbk;
+    }
+    long long nblk = ((long long)sweep_device_cus() * per_cu[dev] + 7) & ~7ll;
+    DistArgs da;
+    da.a = a; da.packed = packed; da.stats = stats; da.queue = queue; da.tiles_x = tiles_x; da.ntile = tiles;
+    // small problems: one pixel block per item, so that every CU gets work
+    da.spi = (long long)tiles * a.B < DIST_SPI1_BELOW * nblk ? 1 : 4;
+    const long long need = 8ll * ((tiles + 7) / 8) * (4 / da.spi) * a.B;   // a workgroup per item of the largest XCD band, times 8
+    if (need <= DIST_ONE_EACH_X * nblk) nblk = need;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, stream, da);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// shapes the kernel is built for: L2, D <= 128, C <= 72, at most 8 source views; a view's planes within 2^31 bytes
+bool sweep_dist_supports(const SweepArgs& a) {
+    const long long hw = (long long)a.H * a.W;
+    return a.metric == 0 && a.D <= 128 && a.C <= dist::MAX_C && a.V <= DIST_MAXV && a.W <= 32760 && a.H <= 32760 &&
+           hw * a.D * 4 < (1ll << 31) && hw * a.C * 4 < (1ll << 31) && dist::view_bytes(a.C, a.H, a.W) < (1ll << 31) && hw * 12 < (1ll << 31);
+}
+
+// NCHW entry: channel statistics + pack kernel (launch_pack_dist), then the sweep kernel.  Packed entry: the sweep kernel alone.
+hipError_t launch_sweep_dist(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready) {
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + 3) / 4, tiles = tiles_x * tiles_y;
+    const char* packed = static_cast<const char*>(workspace) + sweep_ws_flag_bytes(a.B, a.H, a.W);
+    int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + sweep_ws_flag_only_bytes(a.B, a.H, a.W));
+    const float* stats = reinterpret_cast<const float*>(static_cast<char*>(workspace) + sweep_ws_stats_offset(a.B, a.V, a.C, a.H, a.W));
+    if (!packed_ready) {
+        hipError_t e = launch_pack_dist(a, workspace, stream);
+        if (e != hipSuccess) return e;
+    }
+    const int nck = dist::nchk(a.C);
+    if (a.D <= 64) {
+        if (nck == 0) return launch_inst<0, 1>(a, packed, stats, queue, tiles_x, tiles, stream);
+        if (nck == 1) return launch_inst<1, 1>(a, packed, stats, queue, tiles_x, tiles, stream);
+        return launch_inst<2, 1>(a, packed, stats, queue, tiles_x, tiles, stream);
+    }
+    if (nck == 0) return launch_inst<0, 2>(a, packed, stats, queue, tiles_x, tiles, stream);
+    if (nck == 1) return launch_inst<1, 2>(a, packed, stats, queue, tiles_x, tiles, stream);
+    return launch_inst<2, 2>(a, packed, stats, queue, tiles_x, tiles, stream);
+}
+
+}  // namespace pdepth

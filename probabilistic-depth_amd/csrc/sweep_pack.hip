@@ -17,6 +17,7 @@
 // NONCENTRED_SLOT when sum mu^2 > sum var / 2, and the tiled kernel then evaluates every plane directly.
 #include <hip/hip_runtime.h>
 
+#include "dist_layout.hpp"
 #include "kernels.hpp"
 #include "pack_body.hpp"
 #include "pick.hpp"
@@ -43,36 +44,57 @@ __device__ __forceinline__ int stats_row(int i, int nrows, int H) { return min(H
 // Block (c, b): mean and variance of channel c of item b over the sampled rows.  POOLED: the channel is avg_pool2d(rgb, rate)
 // of the encoder epilogue (pack_views_kernel), computed on the fly like there.  The samples of a thread are independent
 // loads issued together (32 at a time), then summed: the kernel is a few microseconds of latency, not a dependent chain.
+__device__ __forceinline__ float block_max_256(float v, float* scratch) {
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) v = fmaxf(v, __shfl_xor(v, sh));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+}
+
 template <bool POOLED>
 __device__ __forceinline__ void channel_stats(const float* __restrict__ plane, int H, int W, int rate, int IW, float* __restrict__ mu_out,
                                               float* __restrict__ var_out, int centre) {
     __shared__ float scratch[4];
     const int nrows = min(H, STATS_ROWS), total = nrows * W;
-    float s = 0.0f, s2 = 0.0f;
-    constexpr int NU = 32;   // samples of a thread in flight together
+    // the partner of a sample for the lagged spread: STATS_LAG_PX texels to the right (to the left in the last columns)
+    const int lag = W > 2 * STATS_LAG_PX ? STATS_LAG_PX : (W > 1 ? W / 2 : 0);
+    float s = 0.0f, s2 = 0.0f, am = 0.0f, dl = 0.0f;
+    constexpr int NU = 16;   // samples of a thread in flight together (and as many partners)
     for (int i0 = threadIdx.x; i0 < total; i0 += 256 * NU) {
-        float v[NU];
+        float v[NU], w[NU];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int i = i0 + 256 * u;
-            v[u] = 0.0f;
+            v[u] = 0.0f; w[u] = 0.0f;
             if (i < total) {
                 const int r = i / W, x = i - r * W, y = stats_row(r, nrows, H);
+                const int x2 = x + lag < W ? x + lag : x - lag;
                 if (POOLED) {
                     // (the mean of the pooled channel = the mean of the image itself: one image row per sampled map row, every
-                    //  rate-th column -- the variance, which only feeds the tiled kernel's guard, is the image's, an upper bound)
+                    //  rate-th column -- the variance, which only feeds the guards, is the image's, an upper bound)
                     v[u] = plane[((size_t)y * rate) * IW + (size_t)x * rate];
+                    w[u] = plane[((size_t)y * rate) * IW + (size_t)x2 * rate];
                 } else {
                     v[u] = plane[(size_t)y * W + x];
+                    w[u] = plane[(size_t)y * W + x2];
                 }
             }
         }
 #pragma unroll
-        for (int u = 0; u < NU; ++u) { s += v[u]; s2 = __builtin_fmaf(v[u], v[u], s2); }
+        for (int u = 0; u < NU; ++u) {
+            s += v[u]; s2 = __builtin_fmaf(v[u], v[u], s2);
+            am = fmaxf(am, fabsf(v[u]));
+            const float d = v[u] - w[u];
+            dl = __builtin_fmaf(d, d, dl);
+        }
     }
     const float cnt = (float)total;
     const float mean = block_sum_256(s, scratch) / cnt;
     const float msq = block_sum_256(s2, scratch) / cnt;
+    const float amax = block_max_256(am, scratch);
+    const float dlag = block_sum_256(dl, scratch) / cnt;
     if (threadIdx.x == 0) {
         // (non-finite features: no centring -- the statistics would poison every pixel of the item)
         const bool fin = fabsf(mean) < 1.0e30f && msq < 1.0e30f;
@@ -80,6 +102,9 @@ __device__ __forceinline__ void channel_stats(const float* __restrict__ plane, i
         // spread around the constant that is subtracted, and the offset that is NOT removed (for the tiled kernel's guard)
         var_out[0] = fin ? fmaxf(msq - mean * mean, 0.0f) : 0.0f;
         var_out[STATS_OFF - STATS_VAR] = (centre || !fin) ? 0.0f : mean * mean;
+        // (NaN / inf features: amax as it comes out -- the distance-form kernels then take the scale 1)
+        var_out[STATS_AMAX - STATS_VAR] = amax + (centre && fin ? fabsf(mean) : 0.0f);
+        var_out[STATS_LAG - STATS_VAR] = fin && lag > 0 ? 0.5f * dlag : var_out[0];
     }
 }
 
@@ -98,7 +123,9 @@ __global__ __launch_bounds__(256) void feature_stats_kernel(const float* __restr
     float* st = stats + (size_t)b * STATS_STRIDE;
     if (c == 0 && threadIdx.x < STATS_VAR - C && C + (int)threadIdx.x < STATS_VAR) {   // channels beyond C
         st[C + threadIdx.x] = 0.0f; st[STATS_VAR + C + threadIdx.x] = 0.0f; st[STATS_OFF + C + threadIdx.x] = 0.0f;
+        st[STATS_AMAX + C + threadIdx.x] = 0.0f; st[STATS_LAG + C + threadIdx.x] = 0.0f;
     }
+    if (c == 0 && threadIdx.x < STATS_NFLAG) reinterpret_cast<int*>(st + STATS_FLAGS)[threadIdx.x] = 0;
     if (c >= STATS_VAR) return;   // (only the first 80 channels are recorded: the centring kernels take C <= 72)
     channel_stats<false>(src + (size_t)b * bstride + (size_t)c * H * W, H, W, 1, W, st + c, st + STATS_VAR + c, centre);
 }
@@ -110,7 +137,9 @@ __global__ __launch_bounds__(256) void view_stats_kernel(const float* __restrict
     float* st = stats + (size_t)b * STATS_STRIDE;
     if (c == 0 && threadIdx.x < STATS_VAR - C && C + (int)threadIdx.x < STATS_VAR) {
         st[C + threadIdx.x] = 0.0f; st[STATS_VAR + C + threadIdx.x] = 0.0f; st[STATS_OFF + C + threadIdx.x] = 0.0f;
+        st[STATS_AMAX + C + threadIdx.x] = 0.0f; st[STATS_LAG + C + threadIdx.x] = 0.0f;
     }
+    if (c == 0 && threadIdx.x < STATS_NFLAG) reinterpret_cast<int*>(st + STATS_FLAGS)[threadIdx.x] = 0;
     if (c >= STATS_VAR) return;
     const size_t bv = (size_t)b * (V + 1);
     if (c < Cf) channel_stats<false>(feat + (bv * Cf + c) * H * W, H, W, 1, W, st + c, st + STATS_VAR + c, centre);
@@ -118,8 +147,8 @@ __global__ __launch_bounds__(256) void view_stats_kernel(const float* __restrict
 }
 
 // the first block of a pack kernel: queue counters and slots cleared, the tiled kernel's guard set (header)
-__device__ __forceinline__ void reset_queue_and_guard(int* __restrict__ queue, const float* __restrict__ stats, int B) {
-    if (threadIdx.x < 64 && threadIdx.x != PICK_SLOT) queue[threadIdx.x] = 0;
+__device__ __forceinline__ void reset_queue_and_guard(int* __restrict__ queue, const float* __restrict__ stats, int B, int layout) {
+    if (threadIdx.x < 64 && threadIdx.x != PICK_SLOT) queue[threadIdx.x] = threadIdx.x == LAYOUT_SLOT ? layout : 0;
     float off = 0.0f, var = 0.0f;
     for (int i = threadIdx.x; i < B * STATS_VAR; i += 256) {
         const int b = i / STATS_VAR, c = i - b * STATS_VAR;
@@ -148,7 +177,7 @@ __global__ __launch_bounds__(256) void pack_c4_kernel(const float* __restrict__ 
     // also clears the tile flags of this call (saves a memset launch)
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < nflags; i += gridDim.x * gridDim.y * 256) flags[i] = 0;
     if (blockIdx.x == 0 && blockIdx.y == 0) {
-        reset_queue_and_guard(queue, stats, pa.B);
+        reset_queue_and_guard(queue, stats, pa.B, CENTRE ? LAYOUT_C4_CENTRED : LAYOUT_C4);
         if (threadIdx.x == 0) queue[PICK_SLOT] = 0;
         __syncthreads();
         if (pa.pick != 0) pick_for_launch(pa, queue, threadIdx.x, 256);
@@ -187,11 +216,11 @@ __global__ __launch_bounds__(256) void pack_c4_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void pack_views_kernel(const float* __restrict__ feat, const float* __restrict__ rgb, int V, int Cf,
                                                          int H, int W, int rate, int IH, int IW, float4* __restrict__ out,
                                                          float* __restrict__ ref_out, int* __restrict__ flags, int nflags, int* queue,
-                                                         const float* __restrict__ stats, int B) {
+                                                         const float* __restrict__ stats, int B, int centred) {
     const int HW = H * W, C = Cf + 3;
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < nflags; i += gridDim.x * gridDim.y * 256) flags[i] = 0;
     if (blockIdx.x == 0 && blockIdx.y == 0) {
-        reset_queue_and_guard(queue, stats, B);
+        reset_queue_and_guard(queue, stats, B, centred ? LAYOUT_C4_CENTRED : LAYOUT_C4);
         if (threadIdx.x == 0) queue[PICK_SLOT] = 0;
     }
     const int nb = gridDim.x, xcd = blockIdx.x & 7, qq = nb >> 3, rr = nb & 7;   // XCD-aware block order, as pack_c4_kernel
@@ -303,7 +332,7 @@ __global__ __launch_bounds__(256) void pack_views_kernel(const float* __restrict
 // flag clear of a call on an already packed source when the kernel is chosen on the device (lab builds; else: a memset)
 __global__ __launch_bounds__(256) void clear_and_pick_kernel(SweepArgs pa, int* flags, int nflags, int* queue) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nflags; i += gridDim.x * 256)
-        if (flags + i != queue + PICK_SLOT && flags + i != queue + NONCENTRED_SLOT) flags[i] = 0;
+        if (flags + i != queue + PICK_SLOT && flags + i != queue + NONCENTRED_SLOT && flags + i != queue + LAYOUT_SLOT) flags[i] = 0;
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) queue[PICK_SLOT] = 0;
         __syncthreads();
@@ -314,7 +343,7 @@ __global__ __launch_bounds__(256) void clear_and_pick_kernel(SweepArgs pa, int* 
 // flag clear that keeps the guard slot the pre-pass wrote
 __global__ __launch_bounds__(256) void clear_flags_kernel(int* flags, int nflags, int* queue) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nflags; i += gridDim.x * 256)
-        if (flags + i != queue + NONCENTRED_SLOT) flags[i] = 0;
+        if (flags + i != queue + NONCENTRED_SLOT && flags + i != queue + LAYOUT_SLOT) flags[i] = 0;
 }
 
 size_t flag_only_bytes(int B, int H, int W) {
@@ -322,7 +351,12 @@ size_t flag_only_bytes(int B, int H, int W) {
     return ((size_t)B * tiles * sizeof(int) + 255) & ~(size_t)255;
 }
 size_t flag_bytes(int B, int H, int W) { return flag_only_bytes(B, H, W) + 256; }
-size_t packed_bytes(int B, int V, int C, int H, int W) { return (size_t)B * V * ((C + 3) / 4 + 2) * H * W * sizeof(float4); }
+// (the larger of the two staging layouts: channel-group-planar float4 + Gram planes | the distance-form kernel's fp16 planes, dist_layout.hpp)
+size_t packed_bytes(int B, int V, int C, int H, int W) {
+    const size_t c4 = (size_t)B * V * ((C + 3) / 4 + 2) * H * W * sizeof(float4);
+    const size_t d16 = C <= dist::MAX_C ? (((size_t)B * V * (size_t)dist::view_bytes(C, H, W) + 255) & ~(size_t)255) : 0;
+    return c4 > d16 ? c4 : d16;
+}
 
 }  // namespace
 
@@ -357,6 +391,17 @@ hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t strea
     return hipGetLastError();
 }
 
+hipError_t launch_feature_stats(const SweepArgs& a, float* stats, hipStream_t stream) {
+    hipLaunchKernelGGL(feature_stats_kernel, dim3(a.C < STATS_VAR ? a.C : STATS_VAR, a.B), dim3(256), 0, stream, a.src, a.src_bstride, a.C,
+                       a.H, a.W, stats, 1, (int*)nullptr, 0, (int*)nullptr, 0);
+    return hipGetLastError();
+}
+hipError_t launch_view_stats(const SweepArgs& a, const float* feat, const float* rgb, int rate, int img_h, int img_w, float* stats, hipStream_t stream) {
+    hipLaunchKernelGGL(view_stats_kernel, dim3(a.C < STATS_VAR ? a.C : STATS_VAR, a.B), dim3(256), 0, stream, feat, rgb, a.V, a.C - 3, a.H,
+                       a.W, rate, img_h, img_w, stats, 1);
+    return hipGetLastError();
+}
+
 // Pre-pass of a call whose sweep kernel packs the source itself (sweep_corr.hip): the channel statistics, and the workspace
 // bookkeeping the pack kernel otherwise does.  The pack counters (two ints per batch item) live in the tile-list region.
 bool sweep_ws_holds_pack_counters(int B, int H, int W) { return (size_t)2 * B * sizeof(int) <= flag_only_bytes(B, H, W); }
@@ -385,7 +430,7 @@ hipError_t launch_pack_views(const SweepArgs& a, const float* feat, const float*
     if (e != hipSuccess) return e;
     dim3 pgrid((HW + 255) / 256, a.B * (a.V + 1));
     hipLaunchKernelGGL(pack_views_kernel, pgrid, dim3(256), 0, stream, feat, rgb, a.V, a.C - 3, a.H, a.W, rate, img_h, img_w, packed, ref_out,
-                       flags, (int)(flag_only_bytes(a.B, a.H, a.W) / sizeof(int)), queue, stats, a.B);
+                       flags, (int)(flag_only_bytes(a.B, a.H, a.W) / sizeof(int)), queue, stats, a.B, centre ? 1 : 0);
     return hipGetLastError();
 }
 

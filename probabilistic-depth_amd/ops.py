@@ -13,7 +13,7 @@ from . import _native
 METRICS = {"L2": _native.METRIC_L2, "L1": _native.METRIC_L1}
 # "tiled1" / "tiled2" / "cells" force one of the implementations behind "auto" (parity tests, A/B timing)
 ALGOS = {"auto": _native.ALGO_AUTO, "direct": _native.ALGO_DIRECT, "tiled1": _native.ALGO_TILED_1,
-         "tiled2": _native.ALGO_TILED_2, "cells": _native.ALGO_CELLS, "mfma": _native.ALGO_MFMA, "corr": _native.ALGO_CORR}
+         "tiled2": _native.ALGO_TILED_2, "cells": _native.ALGO_CELLS, "mfma": _native.ALGO_MFMA, "corr": _native.ALGO_CORR, "dist": _native.ALGO_DIST}
 BLAS_MODES = {"fma": _native.BLAS_FMA, "separate": _native.BLAS_SEPARATE, None: None}
 
 

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = _native.load()
     for sym in _declared_symbols():
         assert hasattr(lib, sym), f"{sym} declared in include/pdepth.h but not exported"
-    assert lib.pdepth_abi_version() == 4
+    assert lib.pdepth_abi_version() == 5
 
 
 def test_argument_validation_without_gpu():
