@@ -85,6 +85,13 @@ struct DistArgs {
 };
 #define KARG(type, field) kernarg_at<type>(offsetof(DistArgs, field))
 
+// phase stamps (-DDIST_STAMPS): shader-clock cycles per phase, summed per wave, added into the queue ints 8..31 on the way out
+#ifdef DIST_STAMPS
+#define DSTAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += t_ - stamp_t; stamp_t = t_; }
+#else
+#define DSTAMP(i)
+#endif
+
 template <int MAXB, int NAC>
 struct __attribute__((aligned(16))) DistLds {
     static constexpr int XSTRIDE = MAXB * 16 + 4;   // floats per pixel of the Y buffer (stride / 4 odd: conflict-free b128 stores)
@@ -200,6 +207,10 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     const bool one_each = (long long)gridDim.x >= 8ll * ((KARG(int, ntile) + 7) / 8) * (4 / da.spi) * KARG(int, a.B);
     __syncthreads();
 
+#ifdef DIST_STAMPS
+    unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#endif
     int slot_par = 0;
     int pt = 0;           // running pass counter: selects the set of row-table arrays
     int n_direct = 0;     // (thread 0) pixel blocks evaluated directly
@@ -219,6 +230,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         slot_par ^= 1;
         if (item < 0) break;
         if (tid == 0 && !one_each && !own_done) got_own = atomicAdd(&KARG(int*, queue)[xcd], 1);
+        DSTAMP(0)   // queue: publish + barrier
         int b, tx, ty, sub0;
         decode(item, b, tx, ty, sub0);
         // per BATCH item, for every wave: scaled channel means, the views' homography terms, the camera constants, the item's
@@ -298,6 +310,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                     rv[mm] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                         rref, tq + 16 * mm < C ? (tq * HW + p) * 4 : OOB, 16 * mm * HW * 4, 0));
             }
+            DSTAMP(1)   // item set-up, pixel loads issued
             float rr = 0.0f, zc = 0.0f;    // |r'|^2 and |r|^2 of the pixel, scaled (set with the first pass)
             bool centred = false;
             unsigned failmask = 0;         // uniform over the workgroup: passes (view v, plane group h) left to the direct evaluation
@@ -356,6 +369,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(fw[j])); asm volatile("" : "+v"(fn[j])); }
                     }
+                    DSTAMP(2)   // (wait for the ray) sample positions
                     // ---- row table: contributions of this thread's planes --------------------------------------------------
                     {
                         int lmin = INT_MAX, lmax = INT_MIN;
@@ -412,7 +426,9 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                         pz = pz + __shfl_xor(pz, 16); pz = pz + __shfl_xor(pz, 32);
                         if (kq == 0) *reinterpret_cast<v2f*>(&L.rp[(wave * 16 + n) * 2]) = v2f{pr, pz};
                     }
+                    DSTAMP(3)   // table atomics, (wait for the reference features) centring
                     PDEPTH_LDS_BARRIER();   // tables (and the operand image) complete
+                    DSTAMP(4)   // barrier
                     if (!centred) {
 #pragma unroll
                         for (int w = 0; w < 4; ++w) {
@@ -460,6 +476,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                     if (L.iflag != 0) fits = false;   // (the item is evaluated directly)
                     const int rowoff = 16 * fb - lo;    // slot of texel x of this lane's row = x + rowoff
                     const bool go = fits && nb > 0;
+                    DSTAMP(5)   // operands from LDS, row table cut into blocks
                     // ---- Y = |s' - r'|^2 for the blocks of the pass, on the matrix pipe --------------------------------------
                     int sl[4];   // slots of the top (low 16 bits) / bottom row of this thread's cells; < 0: no cell
                     {
@@ -531,11 +548,14 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                                 if (more) fetch(NAC - 1, soff);
                                 *reinterpret_cast<v4f*>(&L.Ys[n * XSTRIDE + 16 * bi + 4 * kq]) = acc;   // Y[texel 4 kq ..][pixel n] of the block
                             }
+                            DSTAMP(6)   // slots, loads + multiplications
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's Q records have landed in LDS
                         }
                         if (DIST_XPRIO) __builtin_amdgcn_s_setprio(0);
                     }
+                    DSTAMP(7)   // wait for the Q records
                     PDEPTH_LDS_BARRIER();   // Y and the Q records of the pass are complete
+                    DSTAMP(8)   // barrier
                     ++pt;
                     // (every wave has read the tables of this pass: wave 1 cleans them for the pass after the next)
                     if (wave == 1) {
@@ -572,6 +592,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 }
             }
 
+            DSTAMP(9)   // combine
             if (failmask != 0) {
                 // Passes left to the direct evaluation: the reference's own form on the packed features -- per plane the four
                 // taps of every group of 8 channels by two 16-byte loads each (high + low parts), the pixel's centred reference
@@ -669,6 +690,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 ssum = ssum + __shfl_xor(ssum, 16); ssum = ssum + __shfl_xor(ssum, 32);
                 esum = esum + __shfl_xor(esum, 16); esum = esum + __shfl_xor(esum, 32);
                 if (kq == 0) *reinterpret_cast<v4f*>(&L.red[(wave * 16 + n) * 4]) = v4f{mx, ssum, esum, 0.0f};
+                DSTAMP(10)   // cost stores, partial softmax
                 PDEPTH_LDS_BARRIER();
                 float M = -INFINITY;
 #pragma unroll
@@ -694,8 +716,13 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
             } else {
                 PDEPTH_LDS_BARRIER();   // (every wave is done with the block's operand image before the next block's centring)
             }
+            DSTAMP(11)   // barrier + merge + stores
         }   // pixel blocks of the item
     }   // items
+#ifdef DIST_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(int*, queue) + 8) + i, stamp_acc[i]);
+#endif
 
     // the last workgroup to leave zeroes the queue counters: the next call on this workspace needs no clearing launch
     if (tid == 0) {
