@@ -44,7 +44,8 @@ constexpr float F16_MAX = 65504.0f;
 
 __host__ __device__ inline int nchk(int C) { return C <= 8 ? 0 : (C <= 40 ? 1 : 2); }
 __host__ __device__ inline int nplanes(int C) { return 8 * nchk(C) + 4 + 1; }
-__host__ __device__ inline int wp(int W) { return W + 2 * RING; }
+// (rows padded to a multiple of 4 texels: a block of 16 texels that starts at a multiple of 4 is read as whole 64-byte pieces)
+__host__ __device__ inline int wp(int W) { return (W + 2 * RING + 3) & ~3; }
 __host__ __device__ inline int hp(int H) { return H + 2 * RING; }
 // bytes of one plane / one view; a view's planes are followed by 256 bytes that a block of 16 texels starting at the
 // last texels of the image may read (never used)

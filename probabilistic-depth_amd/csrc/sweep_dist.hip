@@ -46,10 +46,10 @@
 #define DIST_MAXB2 32      // ... D > 64
 #endif
 #ifndef DIST_OCC1
-#define DIST_OCC1 4
+#define DIST_OCC1 2        // workgroups per CU at D <= 64: 256 registers per lane, nothing spilled (4: 128 registers, 23 spilled: slower)
 #endif
 #ifndef DIST_OCC2
-#define DIST_OCC2 3
+#define DIST_OCC2 2
 #endif
 #ifndef DIST_XPRIO
 #define DIST_XPRIO 1
@@ -65,6 +65,22 @@
 #endif
 #ifndef DIST_GUARD_RATIO
 #define DIST_GUARD_RATIO 6.0f   // spread energy / lagged spread beyond which an item is evaluated directly (guard below)
+#endif
+
+#ifdef ABL_NO_MFMA
+#define DIST_MFMA(a, b, c) ((c) + __builtin_bit_cast(wv::v4f, a) * 1e-30f + __builtin_bit_cast(wv::v4f, b) * 1e-30f)
+#elif defined(DIST_MFMA16)
+// two K = 16 instructions per K = 32 operand pair (the sum over the K slots is the same)
+typedef _Float16 pdepth_h4 __attribute__((ext_vector_type(4)));
+#define DIST_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_shufflevector(a, a, 4, 5, 6, 7), __builtin_shufflevector(b, b, 4, 5, 6, 7), \
+                               __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_shufflevector(a, a, 0, 1, 2, 3), __builtin_shufflevector(b, b, 0, 1, 2, 3), c, 0, 0, 0), 0, 0, 0)
+#else
+#define DIST_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#endif
+#ifdef ABL_NO_BARRIER
+#define DIST_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define DIST_BARRIER() PDEPTH_LDS_BARRIER()
 #endif
 
 namespace pdepth {
@@ -92,6 +108,18 @@ struct DistArgs {
 #define DSTAMP(i)
 #endif
 
+// exp(x) for x <= 0 (softmax terms): the hardware 2^t on the rounded product t = x log2(e).  The product's rounding error
+// (2^-24 |t|) is a relative error |t| ln2 2^-24 of the result: 4e-7 for the terms within a factor 1000 of the largest one,
+// which are the ones that carry a depth map or a normaliser; geometry.hpp's exp_nonpos (12 instructions) keeps 1.5 ulp
+// for every term (DIST_EXACT_EXP restores it).
+__device__ __forceinline__ float dist_exp(float x) {
+#ifdef DIST_EXACT_EXP
+    return exp_nonpos(x);
+#else
+    return __builtin_amdgcn_exp2f(fmaxf(x, -1000.0f) * 1.44269502162933349609375f);
+#endif
+}
+
 template <int MAXB, int NAC>
 struct __attribute__((aligned(16))) DistLds {
     static constexpr int XSTRIDE = MAXB * 16 + 4;   // floats per pixel of the Y buffer (stride / 4 odd: conflict-free b128 stores)
@@ -106,6 +134,7 @@ struct __attribute__((aligned(16))) DistLds {
     float dcl[128];              // depth candidates
     int cmin[2][64], cmax[2][64];   // per cell row (modulo 64): min / max x0; two sets, alternating by pass
     int ired[2][2];              // min / max cell row of the pass; two sets
+    int brow[MAXB + 2];          // per block of the pass: its row (written alike by every wave, read back by the same wave)
     int item[2];                 // work item: current / next
     int iflag;                   // the batch item in work: 1 = fp16 overflow in the pack, 2 = outside the domain (guard)
     unsigned char wide[64];      // per batch item: pixel blocks are 16x1 (else 8x2)
@@ -283,8 +312,50 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         bool item_ready = !new_b;
         float ray[3], rv[MCH];
         const int spi = da.spi;
+        // The pixel loads of a block -- the pixel's ray, and this thread's share of the block's reference features: channels tq,
+        // tq + 16, ... of pixel n (buffer loads: 32-bit offsets, the channel as the scalar offset; channels beyond C = 0) -- are
+        // issued one block ahead: those of the item's first block here, those of block s + 1 at the top of block s.
+        float rayN[3], rvN[MCH];
+        auto block_pixel = [&](int sub_, int lane_, int& x_, int& y_) {
+            const int n_ = lane_ & 15;
+            x_ = wide ? tx * 16 + n_ : tx * 16 + 8 * (sub_ & 1) + (n_ & 7);
+            y_ = wide ? ty * 4 + sub_ : ty * 4 + 2 * (sub_ >> 1) + (n_ >> 3);
+        };
+        auto issue_pixel_loads = [&](int sub_) {
+#ifdef ABL_NO_PIXLOAD
+            for (int i = 0; i < 3; ++i) rayN[i] = 0.001f * (float)(i + 1) + (float)sub_; for (int mm = 0; mm < MCH; ++mm) rvN[mm] = 0.5f; return;
+#endif
+            const int lane_ = opaque_v((int)threadIdx.x) & 63, tq_ = wave * 4 + (lane_ >> 4);
+            const int HW_ = opaque_s(H * W);
+            int x_, y_;
+            block_pixel(sub_, lane_, x_, y_);
+            const int p_ = min(y_, H - 1) * W + min(x_, W - 1);
+            const __amdgpu_buffer_rsrc_t rray =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(da.a.rays + (size_t)b * 3 * HW_), 0, 3 * HW_ * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) rayN[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rray, p_ * 4, i * HW_ * 4, 0));
+            const __amdgpu_buffer_rsrc_t rref =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(da.a.ref + (size_t)b * da.a.ref_bstride), 0, C * HW_ * 4, 0x00020000);
+#pragma unroll
+            for (int mm = 0; mm < MCH; ++mm)
+                rvN[mm] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rref, tq_ + 16 * mm < C ? (tq_ * HW_ + p_) * 4 : OOB, 16 * mm * HW_ * 4, 0));
+        };
+#ifdef DIST_PREFETCH
+        issue_pixel_loads(sub0);
+#endif
 
         for (int sub = sub0; sub < sub0 + spi; ++sub) {
+#ifndef DIST_PREFETCH
+            issue_pixel_loads(sub);
+#endif
+#pragma unroll
+            for (int i = 0; i < 3; ++i) ray[i] = rayN[i];
+#pragma unroll
+            for (int mm = 0; mm < MCH; ++mm) rv[mm] = rvN[mm];
+#ifdef DIST_PREFETCH
+            if (sub + 1 < sub0 + spi) issue_pixel_loads(sub + 1);
+#endif
             if ((wide ? ty * 4 + sub : ty * 4 + 2 * (sub >> 1)) >= H) continue;   // the block lies below the image (uniform)
             // lane roles: in the vector phases thread (n, tq) owns pixel n of the block and planes 64 h + 4 tq .. + 3; in the
             // matrix phase lane (n, kq) of a wave feeds texel / pixel n and K slice kq.  (opaque: the optimiser otherwise
@@ -292,24 +363,10 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
             const int tid = opaque_v((int)threadIdx.x), lane = tid & 63;   // (shadow the kernel's: re-derived per pixel block)
             const int n = lane & 15, kq = lane >> 4, tq = wave * 4 + kq;
             const int HW = opaque_s(H * W);
-            const int x = wide ? tx * 16 + n : tx * 16 + 8 * (sub & 1) + (n & 7);
-            const int y = wide ? ty * 4 + sub : ty * 4 + 2 * (sub >> 1) + (n >> 3);
+            int x, y;
+            block_pixel(sub, lane, x, y);
             const bool xlive = x < W && y < H;
             const int p = min(y, H - 1) * W + min(x, W - 1);
-            // the pixel's ray, and this thread's share of the block's reference features: channels tq, tq + 16, ... of pixel n
-            // (buffer loads: 32-bit offsets, the channel as the scalar offset; channels beyond C = 0)
-            {
-                const __amdgpu_buffer_rsrc_t rray =
-                    __builtin_amdgcn_make_buffer_rsrc((void*)(da.a.rays + (size_t)b * 3 * HW), 0, 3 * HW * 4, 0x00020000);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) ray[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rray, p * 4, i * HW * 4, 0));
-                const __amdgpu_buffer_rsrc_t rref =
-                    __builtin_amdgcn_make_buffer_rsrc((void*)(da.a.ref + (size_t)b * da.a.ref_bstride), 0, C * HW * 4, 0x00020000);
-#pragma unroll
-                for (int mm = 0; mm < MCH; ++mm)
-                    rv[mm] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rref, tq + 16 * mm < C ? (tq * HW + p) * 4 : OOB, 16 * mm * HW * 4, 0));
-            }
             DSTAMP(1)   // item set-up, pixel loads issued
             float rr = 0.0f, zc = 0.0f;    // |r'|^2 and |r|^2 of the pixel, scaled (set with the first pass)
             bool centred = false;
@@ -326,7 +383,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
                     const int par = pt & 1;
-                    if (!item_ready) { PDEPTH_LDS_BARRIER(); item_ready = true; }   // (the item's tables above are in LDS)
+                    if (!item_ready) { DIST_BARRIER(); item_ready = true; }   // (the item's tables above are in LDS)
                     // ---- sample positions of this thread's planes of the pass (NO_CELL: no tap in the image, plane beyond D,
                     //      pixel beyond the image)
                     int cell[4];
@@ -348,7 +405,11 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                         for (int j = 0; j < 4; j += 2) {
                             const int k = 64 * h + 4 * tq + j;
                             v2f ix, iy;
-#ifdef DIST_PACKED_POS
+#ifdef ABL_CHEAP_POS
+                            { const float dk0 = L.dcl[k], dk1 = L.dcl[k + 1];
+                              ix = v2f{(float)x + 0.25f + dk0 * 0.3f, (float)x + 0.25f + dk1 * 0.3f}; iy = v2f{(float)y + 0.25f + dk0 * 0.1f, (float)y + 0.25f + dk1 * 0.1f};
+                              asm volatile("" :: "v"(t2a), "v"(t2b), "v"(t2c)); }
+#elif defined(DIST_PACKED_POS)
                             plane_sample_pos_fast2(xf, t2a, t2b, t2c, v2f{L.dcl[k], L.dcl[k + 1]}, c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ix, iy);
 #else
                             // (scalar instructions: packed fp32 -- two planes per v_pk_* instruction -- now and then loses the low
@@ -391,26 +452,30 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                         const int wmin = wave_min_i(lmin), wmax = wave_max_i(lmax);
                         if (lane == 0 && wmin <= wmax) { atomicMin(&L.ired[par][0], wmin); atomicMax(&L.ired[par][1], wmax); }
                     }
+#ifdef ABL_NO_CENTRING
+                    if (false) {
+#else
                     if (!centred) {
+#endif
                         // (first pass of the block) this thread's channels of pixel n: x' = (r - mu) 2^e, split into fp16 high and
                         // low parts, times -2, into the pixel-side operand image of the block; and its share of |r'|^2 and |r|^2.
                         // Channel c = tq + 16 mm: chunk (c >> 5) for c < 32 NCHK, K slot c & 31; else the tail chunk: K slots t (its
                         // high part, against the texel's high part), 8 + t (high, against the texel's low part), 16 + t (low).
-                        const float sc = L.cst[6];
+                        const float sc = L.cst[6], sm2 = -2.0f * sc;
                         float pr = 0.0f, pz = 0.0f;
 #pragma unroll
                         for (int mm = 0; mm < MCH; ++mm) {
                             const int c = tq + 16 * mm;
                             const bool has = c < CPAD;   // (only the last round can fall beyond the padded channels)
-                            const float m = L.mus[min(c, dist::MAX_C + 7)];
-                            const float xs = has ? __builtin_fmaf(rv[mm], sc, -m) : 0.0f;
+                            const float m2 = 2.0f * L.mus[min(c, dist::MAX_C + 7)];
+                            // -2 x' in one rounding (scaling by a power of two commutes with the rounding of x' = (r - mu) 2^e)
+                            const float xm = has ? __builtin_fmaf(rv[mm], sm2, m2) : 0.0f;
                             const float rs = has ? rv[mm] * sc : 0.0f;
-                            pr = __builtin_fmaf(xs, xs, pr);
+                            pr = __builtin_fmaf(xm, xm, pr);
                             pz = __builtin_fmaf(rs, rs, pz);
-                            const float xc = fminf(fmaxf(xs, -32000.0f), 32000.0f);
-                            const _Float16 hh = (_Float16)xc;
-                            const _Float16 ll = (_Float16)(xc - (float)hh);
-                            const _Float16 bh = (_Float16)(-2.0f * (float)hh), bl = (_Float16)(-2.0f * (float)ll);
+                            const float xc = __builtin_amdgcn_fmed3f(xm, -64000.0f, 64000.0f);
+                            const _Float16 bh = (_Float16)xc;
+                            const _Float16 bl = (_Float16)(xc - (float)bh);
                             if (16 * mm < 32 * NCHK) {   // (compile time: the round lies in a chunk of 32)
                                 const int chunk = (16 * mm) >> 5, kqq = 2 * (mm & 1) + (tq >> 3), jj = tq & 7;
                                 L.Bs[((chunk * 4 + kqq) * 16 + n) * 8 + jj] = bh;
@@ -422,12 +487,13 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                                 L.Bs[(((2 * NCHK) * 4 + 2) * 16 + n) * 8 + t] = bl;
                             }
                         }
+                        pr = 0.25f * pr;
                         pr = pr + __shfl_xor(pr, 16); pr = pr + __shfl_xor(pr, 32);
                         pz = pz + __shfl_xor(pz, 16); pz = pz + __shfl_xor(pz, 32);
                         if (kq == 0) *reinterpret_cast<v2f*>(&L.rp[(wave * 16 + n) * 2]) = v2f{pr, pz};
                     }
                     DSTAMP(3)   // table atomics, (wait for the reference features) centring
-                    PDEPTH_LDS_BARRIER();   // tables (and the operand image) complete
+                    DIST_BARRIER();   // tables (and the operand image) complete
                     DSTAMP(4)   // barrier
                     if (!centred) {
 #pragma unroll
@@ -466,6 +532,10 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                                 lo = min(lo, L.cmin[par][(yb + lane - 1) & 63]);
                                 hi = max(hi, L.cmax[par][(yb + lane - 1) & 63]);
                             }
+#ifndef DIST_UNALIGNED_BLOCKS
+                            // (blocks start at a multiple of 4 texels of the padded row: 64-byte pieces for the loads of four lanes)
+                            if (lo <= hi) lo = ((lo + dist::RING) & ~3) - dist::RING;
+#endif
                             nblk = lo <= hi ? (hi - lo + 2 + 15) >> 4 : 0;   // texels lo .. hi + 1
                             const int incl = wave_scan_incl(nblk);
                             nb = __builtin_amdgcn_readlane(incl, 63);
@@ -489,34 +559,68 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                         // a block's texel operands in consumption order: (high c, low c) for c < NCHK, tail; ONE register set, every
                         // chunk refilled with the next block's right behind its last multiplication (a block in flight per wave)
                         h8 S[NAC];
-                        // block bi of the pass: its row = the lane with fb <= bi < fb + nblk, its first texel lo + 16 (bi - fb);
-                        // the scalar byte offset of that texel in plane 0
-                        auto prep = [&](int bi) -> int {
-                            const unsigned long long mk = __builtin_amdgcn_ballot_w64(nblk > 0 && bi >= fb && bi < fb + nblk);
-                            const int rho = (int)__builtin_ctzll(mk | (1ull << 63));
-                            const int xs = __builtin_amdgcn_readlane(lo, rho) + 16 * (bi - __builtin_amdgcn_readlane(fb, rho));
-                            return ((yb + rho + dist::RING) * Wp + xs + dist::RING) * 16;
-                        };
-                        auto fetch = [&](int i, int soff) {   // chunk i: planes 4 i .. 4 i + 3 (the lane's: + kq, in voffA)
-                            S[i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffA, soff + i * 4 * PB, 0));
-                        };
-                        // the Q records of the block's 16 cells, from memory straight to LDS
-#ifdef DIST_Q_NODMA
-                        auto fetch_q = [&](int bi, int soff) {
-                            if (lane < 16) *reinterpret_cast<v4f*>(&L.Qs[bi * 64 + lane * 4]) =
-                                __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, soff + QPL * PB, 0));
-                        };
-#else
-                        auto fetch_q = [&](int bi, int soff) { if (lane < 16) dma_b128(rs4, lds_addr_of(&L.Qs[bi * 64]), lane * 16, soff + QPL * PB); };
-#endif
-                        if (DIST_XPRIO) __builtin_amdgcn_s_setprio(DIST_XPRIO);
-                        if (go && wave < nb) {
-                            const int soff = prep(wave);
+                        // Block j of the pass (lane j): the byte offset of its first texel in plane 0.  Its row = the lane rho with
+                        // fb <= j < fb + nblk: the row lanes scatter their index through LDS (every wave writes the same values and
+                        // reads back what it wrote), its first texel lo[rho] + 16 (j - fb[rho]).
+                        int boff = 0;
+                        if (go) {
 #pragma unroll
-                            for (int c = 0; c < NCHK; ++c) { fetch(c, soff); fetch(NCHK + c, soff); }
-                            fetch(NAC - 1, soff);
-                            fetch_q(wave, soff);
+                            for (int i = 0; i < 2; ++i)   // (a row rarely needs more than two blocks: no loop for those)
+                                if (i < nblk) L.brow[fb + i] = lane;
+                            for (int i = 2; i < nblk; ++i) L.brow[fb + i] = lane;
+                            const int rho = L.brow[min(lane, MAXB - 1)];
+                            const int xs = __builtin_amdgcn_ds_bpermute(4 * rho, lo) + 16 * (lane - __builtin_amdgcn_ds_bpermute(4 * rho, fb));
+                            boff = lane < nb ? ((yb + rho + dist::RING) * Wp + xs + dist::RING) * 16 : OOB;
                         }
+                        auto fetch = [&](int i, int soff) {   // chunk i: planes 4 i .. 4 i + 3 (the lane's: + kq, in voffA)
+#ifdef ABL_NO_ALOAD
+                            S[i] = __builtin_bit_cast(h8, v4i{soff, voffA, i, 1});
+#else
+                            S[i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffA, soff + i * 4 * PB, 0));
+#endif
+                        };
+                        // wave w: blocks w q .. w q + q - 1 (consecutive blocks: consecutive slots)
+                        const int q = (nb + 3) >> 2, b0 = wave * q, b1 = min(nb, b0 + q);
+                        if (DIST_XPRIO) __builtin_amdgcn_s_setprio(DIST_XPRIO);
+#ifdef ABL_NO_X
+                        if (false) {
+#else
+                        if (go) {
+#endif
+                            // the Q records of the pass's cells, from memory straight to LDS: blocks 4 g .. 4 g + 3 per instruction
+                            // (lane = (block, texel)); wave w moves groups w and w + 4
+#pragma unroll
+                            for (int gq = 0; gq < (MAXB + 15) / 16; ++gq) {
+                                const int g = wave + 4 * gq;
+                                if (4 * g < nb) {   // uniform
+                                    const int bo = __builtin_amdgcn_ds_bpermute(4 * (4 * g + kq), boff);
+                                    const int vq = 4 * g + kq < nb ? bo + n * 16 : OOB;
+                                    dma_b128(rs4, lds_addr_of(&L.Qs[g * 256]), vq, QPL * PB);
+                                }
+                            }
+#ifdef DIST_FAT
+                        }
+                        // (256-register build: every block of the wave in flight at once)
+                        h8 SF[BPW][NAC];
+                        if (go) {
+#pragma unroll
+                            for (int i = 0; i < BPW; ++i)
+                                if (b0 + i < b1) {
+                                    const int soff = __builtin_amdgcn_readlane(boff, b0 + i);
+#pragma unroll
+                                    for (int c = 0; c < NAC; ++c)
+                                        SF[i][c] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffA, soff + c * 4 * PB, 0));
+                                }
+                        }
+#else
+                            if (b0 < b1) {
+                                const int soff = __builtin_amdgcn_readlane(boff, b0);
+#pragma unroll
+                                for (int c = 0; c < NCHK; ++c) { fetch(c, soff); fetch(NCHK + c, soff); }
+                                fetch(NAC - 1, soff);
+                            }
+                        }
+#endif
                         // the slots of this thread's cells (under the first block's loads)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -526,35 +630,54 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                             const int cxx = cell_x(cell[j]);
                             sl[j] = has ? (cxx + o0) | ((cxx + o1) << 16) : -1;
                         }
+#ifdef ABL_NO_X
+                        if (false) {
+#else
                         if (go) {
-                            // wave w: blocks w, w + 4, ...
+#endif
+#ifdef DIST_FAT
 #pragma unroll
                             for (int i = 0; i < BPW; ++i) {
-                                const int bi = wave + 4 * i;
-                                if (bi >= nb) break;
-                                const bool more = i + 1 < BPW && bi + 4 < nb;   // uniform
-                                const int soff = more ? prep(bi + 4) : 0;
-                                if (more) fetch_q(bi + 4, soff);
+                                const int bi = b0 + i;
+                                if (bi >= b1) break;
                                 v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                                 for (int c = 0; c < NCHK; ++c) {
-                                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(S[c], Bv[c], acc, 0, 0, 0);
-                                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(S[c], Bv[NCHK + c], acc, 0, 0, 0);
+                                    acc = DIST_MFMA(SF[i][c], Bv[c], acc);
+                                    acc = DIST_MFMA(SF[i][c], Bv[NCHK + c], acc);
+                                    acc = DIST_MFMA(SF[i][NCHK + c], Bv[c], acc);
+                                }
+                                acc = DIST_MFMA(SF[i][NAC - 1], Bv[NAC - 1], acc);
+                                *reinterpret_cast<v4f*>(&L.Ys[n * XSTRIDE + 16 * bi + 4 * kq]) = acc;
+                            }
+#else
+#pragma unroll
+                            for (int i = 0; i < BPW; ++i) {
+                                const int bi = b0 + i;
+                                if (bi >= b1) break;
+                                const bool more = i + 1 < BPW && bi + 1 < b1;   // uniform
+                                const int soff = more ? __builtin_amdgcn_readlane(boff, bi + 1) : 0;
+                                v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                                for (int c = 0; c < NCHK; ++c) {
+                                    acc = DIST_MFMA(S[c], Bv[c], acc);
+                                    acc = DIST_MFMA(S[c], Bv[NCHK + c], acc);
                                     if (more) fetch(c, soff);
-                                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(S[NCHK + c], Bv[c], acc, 0, 0, 0);
+                                    acc = DIST_MFMA(S[NCHK + c], Bv[c], acc);
                                     if (more) fetch(NCHK + c, soff);
                                 }
-                                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(S[NAC - 1], Bv[NAC - 1], acc, 0, 0, 0);
+                                acc = DIST_MFMA(S[NAC - 1], Bv[NAC - 1], acc);
                                 if (more) fetch(NAC - 1, soff);
                                 *reinterpret_cast<v4f*>(&L.Ys[n * XSTRIDE + 16 * bi + 4 * kq]) = acc;   // Y[texel 4 kq ..][pixel n] of the block
                             }
+#endif
                             DSTAMP(6)   // slots, loads + multiplications
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's Q records have landed in LDS
                         }
                         if (DIST_XPRIO) __builtin_amdgcn_s_setprio(0);
                     }
                     DSTAMP(7)   // wait for the Q records
-                    PDEPTH_LDS_BARRIER();   // Y and the Q records of the pass are complete
+                    DIST_BARRIER();   // Y and the Q records of the pass are complete
                     DSTAMP(8)   // barrier
                     ++pt;
                     // (every wave has read the tables of this pass: wave 1 cleans them for the pass after the next)
@@ -564,6 +687,9 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                     }
 
                     // ---- combine: cost of this thread's planes of the pass ------------------------------------------------
+#ifdef ABL_NO_COMBINE
+                    if (true) { for (int j = 0; j < 4; ++j) cost[4 * h + j] += fw[j] + fn[j] + (float)sl[j]; } else
+#endif
                     if (!fits) {
                         failmask |= 1u << (v * NH + h);   // (evaluated directly behind the view loop)
                     } else {
@@ -659,6 +785,14 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                     }
                 }
             }
+#ifdef DIST_PREFETCH
+            // (the next block's pixel loads have long arrived: have them counted as arrived HERE, in front of this block's output
+            //  stores -- a wait placed behind the stores, at their first use in the next block, would wait for the stores as well)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(rayN[i]));
+#pragma unroll
+            for (int mm = 0; mm < MCH; ++mm) asm volatile("" : "+v"(rvN[mm]));
+#endif
             // ---- epilogue: cost store, log-softmax over D, expectation ----------------------------------------------------
             // (buffer stores: one 32-bit lane offset, the plane as the scalar offset: plane 64 h + 16 wave + 4 kq + j)
             const int ovoff = xlive ? (4 * kq * HW + p) * 4 : OOB;
@@ -671,7 +805,12 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 for (int j = 0; j < NC; ++j)   // (planes beyond D lie beyond the descriptor: dropped)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cost[j]), rc, ovoff, (64 * (j >> 2) + 16 * wave + (j & 3)) * HW * 4, DIST_STORE_AUX);
             }
+#ifdef ABL_NO_EPILOGUE
+            { float t_ = 0.f; for (int j = 0; j < NC; ++j) t_ += cost[j]; if (t_ == 12345.678f && depth_out) depth_out[0] = t_; DIST_BARRIER(); }
+            if (false) {
+#else
             if (logp_out || depth_out) {
+#endif
                 // per wave: max, sum exp, sum d exp over its planes of pixel n; merged over the four waves through LDS
                 float mx = -INFINITY;
 #pragma unroll
@@ -683,7 +822,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     const int k = 64 * (j >> 2) + 4 * tq + (j & 3);
-                    const float ek = k < D ? exp_nonpos(cost[j] - mx) : 0.0f;
+                    const float ek = k < D ? dist_exp(cost[j] - mx) : 0.0f;
                     ssum = ssum + ek;
                     esum = __builtin_fmaf(L.dcl[k], ek, esum);
                 }
@@ -691,7 +830,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 esum = esum + __shfl_xor(esum, 16); esum = esum + __shfl_xor(esum, 32);
                 if (kq == 0) *reinterpret_cast<v4f*>(&L.red[(wave * 16 + n) * 4]) = v4f{mx, ssum, esum, 0.0f};
                 DSTAMP(10)   // cost stores, partial softmax
-                PDEPTH_LDS_BARRIER();
+                DIST_BARRIER();
                 float M = -INFINITY;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) M = fmaxf(M, L.red[(w * 16 + n) * 4]);
@@ -700,7 +839,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 for (int w = 0; w < 4; ++w) {
                     const v4f part = *reinterpret_cast<const v4f*>(&L.red[(w * 16 + n) * 4]);
                     // (a wave whose planes all lie beyond D: max -inf, sums 0)
-                    const float scw = part.x == -INFINITY ? 0.0f : exp_nonpos(part.x - M);
+                    const float scw = part.x == -INFINITY ? 0.0f : dist_exp(part.x - M);
                     S = __builtin_fmaf(part.y, scw, S);
                     E = __builtin_fmaf(part.z, scw, E);
                 }
@@ -714,7 +853,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 }
                 if (depth_out && xlive && tq == 0) depth_out[(size_t)b * HW + p] = E / S;
             } else {
-                PDEPTH_LDS_BARRIER();   // (every wave is done with the block's operand image before the next block's centring)
+                DIST_BARRIER();   // (every wave is done with the block's operand image before the next block's centring)
             }
             DSTAMP(11)   // barrier + merge + stores
         }   // pixel blocks of the item
