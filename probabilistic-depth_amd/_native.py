@@ -363,13 +363,17 @@ def noncentred_guard(B, H, W):
 
 
 def fallback_tiles(B, H, W, gather_flag=1):
-    """Diagnostics: how much of the last sweep left the fast path.  After the correlation-form kernel (ALGO_AUTO / 'corr' on
-    its shapes): pixel blocks of 16 pixels it evaluated directly; after the LDS-tiled kernel: 16x4 tiles left to the gather
-    kernel (flag 1; lab builds: the cell-list path flags 1 = redone by its generic kernel, 2 = gather kernel)."""
+    """Diagnostics: how much of the last sweep left the fast path.  After the distance-form kernel (ALGO_AUTO / 'dist' on its
+    shapes) or the correlation-form kernel ('corr'): passes over a block of 16 pixels they evaluated directly (the kernel
+    that ran zeroes its own count per call; the other's count stays at what its last call left); after the LDS-tiled
+    kernel: 16x4 tiles left to the gather kernel (flag 1; lab builds: the cell-list path flags 1 = redone by its generic
+    kernel, 2 = gather kernel)."""
     if _last_workspace is None:
         return 0
     n = B * ((W + 15) // 16) * ((H + 3) // 4)
-    return int((_last_workspace[: 4 * n].view(torch.int32) == gather_flag).sum().item()) + _queue_slot(B, H, W, 54)
+    layout = _queue_slot(B, H, W, 56)
+    direct = _queue_slot(B, H, W, 59) if layout == LAYOUT_DIST16 else (_queue_slot(B, H, W, 54) if layout == LAYOUT_C4_CENTRED else 0)
+    return int((_last_workspace[: 4 * n].view(torch.int32) == gather_flag).sum().item()) + direct
 
 
 def dpv_reduce(logits, d_candi, want_logp=True, want_depth=True, inplace=False):

@@ -45,6 +45,12 @@
 #ifndef DIST_MAXB2
 #define DIST_MAXB2 32      // ... D > 64
 #endif
+#ifndef DIST_MAXB_NP2
+#define DIST_MAXB_NP2 26   // ... of a pass over two pixel blocks (D <= 64): 75 KB of LDS per workgroup, two per CU
+#endif
+#ifndef DIST_NP2
+#define DIST_NP2 0         // 1: whole tiles at D <= 64 run two pixel blocks per pass (built, parity-green, measured 25 % SLOWER: it
+#endif                     //    saves 4 % of the vector instructions and leaves two workgroups per CU instead of three)
 #ifndef DIST_OCC1
 #define DIST_OCC1 2        // workgroups per CU at D <= 64: 256 registers per lane, nothing spilled (4: 128 registers, 23 spilled: slower)
 #endif
@@ -120,19 +126,19 @@ __device__ __forceinline__ float dist_exp(float x) {
 #endif
 }
 
-template <int MAXB, int NAC>
+template <int MAXB, int NAC, int NP>
 struct __attribute__((aligned(16))) DistLds {
     static constexpr int XSTRIDE = MAXB * 16 + 4;   // floats per pixel of the Y buffer (stride / 4 odd: conflict-free b128 stores)
-    float Ys[16 * XSTRIDE];      // Y[pixel][slot]
-    float Qs[MAXB * 64 + 8];     // Q record (Dx0, Dy0, Dd, Dx1) per slot
-    _Float16 Bs[NAC * 4 * 16 * 8];   // pixel-side operands of the block's 16 pixels: [chunk][kq][pixel][8], -2 x (high | low) parts
-    float rp[4 * 16 * 2];        // per wave and pixel: partial |r'|^2, |r|^2 (scaled)
+    float Ys[NP][16 * XSTRIDE];  // Y[pixel block][pixel][slot]
+    float Qs[(MAXB + 3) / 4 * 256 + 8];   // Q record (Dx0, Dy0, Dd, Dx1) per slot (moved in groups of four blocks: whole groups)
+    _Float16 Bs[NP][NAC * 4 * 16 * 8];   // pixel-side operands of a block's 16 pixels: [chunk][kq][pixel][8], -2 x (high | low) parts
+    float rp[NP][4 * 16 * 2];    // per wave and pixel: partial |r'|^2, |r|^2 (scaled)
     float mus[dist::MAX_C + 8];  // channel means x scale of the batch item in work
     float xf[DIST_MAXV * 12];    // per view: K@R (9), K@t (3)
     float cst[8];                // cx, cy, 1/cx, 1/cy, W/2, H/2, scale, 2^(-2e)/sigma
-    float red[4 * 16 * 4];       // epilogue exchange: (max, sum, sum d) per wave and pixel
+    float red[NP][4 * 16 * 4];   // epilogue exchange: (max, sum, sum d) per wave and pixel
     float dcl[128];              // depth candidates
-    int cmin[2][64], cmax[2][64];   // per cell row (modulo 64): min / max x0; two sets, alternating by pass
+    int cmin[2][64], cmax[2][64];   // per cell row (modulo 64): min / max x0; two sets, alternating by table pass
     int ired[2][2];              // min / max cell row of the pass; two sets
     int brow[MAXB + 2];          // per block of the pass: its row (written alike by every wave, read back by the same wave)
     int item[2];                 // work item: current / next
@@ -141,17 +147,22 @@ struct __attribute__((aligned(16))) DistLds {
 };
 
 // NCHK = chunks of 32 channels (dist_layout.hpp); NH = groups of 64 planes (ceil(D / 64): 1 or 2), each a pass of its own per
-// view: thread (n, tq) owns planes 64 h + 4 tq .. + 3 of pass h.
-template <int NCHK, int NH>
+// view: thread (n, tq) owns planes 64 h + 4 tq .. + 3 of pass h; NP = pixel blocks per pass (1 | 2).
+//
+// NP = 2: a pass covers TWO blocks of 16 pixels -- the 8x2 blocks of a tile stacked to 8x4, or two 16x1 rows -- that share
+// one row table, one cut into texel blocks and every texel load (a block's operands are multiplied against both pixel
+// blocks: 8.2 instead of 12.2 texel blocks per 16 pixels on the forward-motion pose).  The machinery of a pass (set-up,
+// table, scan, three barriers) is what two thirds of the time of a pass went to at NP = 1; here it serves 2048 samples.
+template <int NCHK, int NH, int NP>
 __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_dist_kernel(DistArgs da) {
     constexpr int NAC = 2 * NCHK + 1;              // operand chunks of a texel / pixel: high[NCHK], low[NCHK], tail
     constexpr int CPAD = 32 * NCHK + 8;            // channels, padded
     constexpr int MCH = (CPAD + 15) / 16;          // channels per thread of the cooperative reference load
-    constexpr int MAXB = NH == 1 ? DIST_MAXB1 : DIST_MAXB2;
+    constexpr int MAXB = NP == 2 ? DIST_MAXB_NP2 : (NH == 1 ? DIST_MAXB1 : DIST_MAXB2);
     constexpr int BPW = (MAXB + 3) / 4;            // blocks per wave and pass
-    constexpr int NC = 4 * NH;                     // planes (costs) per thread
+    constexpr int NC = 4 * NH;                     // planes (costs) per thread and pixel block
     constexpr int QPL = 8 * NCHK + 4;              // the Q plane
-    typedef DistLds<MAXB, NAC> Lds;
+    typedef DistLds<MAXB, NAC, NP> Lds;
     constexpr int XSTRIDE = Lds::XSTRIDE;
     __shared__ Lds L;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -241,7 +252,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
     int slot_par = 0;
-    int pt = 0;           // running pass counter: selects the set of row-table arrays
+    int pt = 0;           // running table-pass counter: selects the set of row-table arrays
     int n_direct = 0;     // (thread 0) pixel blocks evaluated directly
     int b_tables = -1;    // batch item whose tables (means, homography terms, camera constants) are in LDS
     // (thread 0) the atomic on the own queue is issued at the top of an item and its result looked at when the item is done
@@ -271,18 +282,18 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
             const float* st = da.stats + (size_t)b * STATS_STRIDE;
             if (wave == 0) {
                 // the scale (dist_layout.hpp: the same function of the same numbers as in the pack kernel) and the guard
-                float am = st[STATS_AMAX + lane], sv = st[STATS_VAR + lane], sl = st[STATS_LAG + lane];
-                if (lane + 64 < STATS_VAR) { am = fmaxf(am, st[STATS_AMAX + lane + 64]); sv += st[STATS_VAR + lane + 64]; sl += st[STATS_LAG + lane + 64]; }
+                float am = st[STATS_AMAX + lane], sv = st[STATS_VAR + lane], sl_ = st[STATS_LAG + lane];
+                if (lane + 64 < STATS_VAR) { am = fmaxf(am, st[STATS_AMAX + lane + 64]); sv += st[STATS_VAR + lane + 64]; sl_ += st[STATS_LAG + lane + 64]; }
 #pragma unroll
                 for (int sh = 32; sh >= 1; sh >>= 1) {
-                    am = fmaxf(am, __shfl_xor(am, sh)); sv += __shfl_xor(sv, sh); sl += __shfl_xor(sl, sh);
+                    am = fmaxf(am, __shfl_xor(am, sh)); sv += __shfl_xor(sv, sh); sl_ += __shfl_xor(sl_, sh);
                 }
                 const int e = dist::scale_exponent(am);
                 const float sc = ldexpf(1.0f, e);
                 // Guard.  The rounding error of Y = N - 2X + |r'|^2 grows with the energy of the centred features, the cost with
                 // their spread at the distance of a sweep: where the first exceeds the second by more than DIST_GUARD_RATIO
                 // (strong trends across the image that a constant per channel cannot remove) the item is evaluated directly.
-                const bool outside = sv > DIST_GUARD_RATIO * sl && sl >= 0.0f;
+                const bool outside = sv > DIST_GUARD_RATIO * sl_ && sl_ >= 0.0f;
                 if (lane == 0) {
                     const float sg = KARG(float, a.sigma);
                     L.cst[6] = sc; L.cst[7] = ldexpf(refined_rcp(sg), -2 * e);
@@ -310,71 +321,56 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         }
         const bool wide = b < 64 ? L.wide[b] != 0 : false;
         bool item_ready = !new_b;
-        float ray[3], rv[MCH];
-        const int spi = da.spi;
-        // The pixel loads of a block -- the pixel's ray, and this thread's share of the block's reference features: channels tq,
-        // tq + 16, ... of pixel n (buffer loads: 32-bit offsets, the channel as the scalar offset; channels beyond C = 0) -- are
-        // issued one block ahead: those of the item's first block here, those of block s + 1 at the top of block s.
-        float rayN[3], rvN[MCH];
-        auto block_pixel = [&](int sub_, int lane_, int& x_, int& y_) {
-            const int n_ = lane_ & 15;
-            x_ = wide ? tx * 16 + n_ : tx * 16 + 8 * (sub_ & 1) + (n_ & 7);
-            y_ = wide ? ty * 4 + sub_ : ty * 4 + 2 * (sub_ >> 1) + (n_ >> 3);
-        };
-        auto issue_pixel_loads = [&](int sub_) {
-#ifdef ABL_NO_PIXLOAD
-            for (int i = 0; i < 3; ++i) rayN[i] = 0.001f * (float)(i + 1) + (float)sub_; for (int mm = 0; mm < MCH; ++mm) rvN[mm] = 0.5f; return;
-#endif
-            const int lane_ = opaque_v((int)threadIdx.x) & 63, tq_ = wave * 4 + (lane_ >> 4);
-            const int HW_ = opaque_s(H * W);
-            int x_, y_;
-            block_pixel(sub_, lane_, x_, y_);
-            const int p_ = min(y_, H - 1) * W + min(x_, W - 1);
-            const __amdgpu_buffer_rsrc_t rray =
-                __builtin_amdgcn_make_buffer_rsrc((void*)(da.a.rays + (size_t)b * 3 * HW_), 0, 3 * HW_ * 4, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) rayN[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rray, p_ * 4, i * HW_ * 4, 0));
-            const __amdgpu_buffer_rsrc_t rref =
-                __builtin_amdgcn_make_buffer_rsrc((void*)(da.a.ref + (size_t)b * da.a.ref_bstride), 0, C * HW_ * 4, 0x00020000);
-#pragma unroll
-            for (int mm = 0; mm < MCH; ++mm)
-                rvN[mm] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                    rref, tq_ + 16 * mm < C ? (tq_ * HW_ + p_) * 4 : OOB, 16 * mm * HW_ * 4, 0));
-        };
-#ifdef DIST_PREFETCH
-        issue_pixel_loads(sub0);
-#endif
+        const int spi = da.spi;   // (NP == 2: 4, the launcher sees to it)
 
-        for (int sub = sub0; sub < sub0 + spi; ++sub) {
-#ifndef DIST_PREFETCH
-            issue_pixel_loads(sub);
-#endif
+        for (int it = 0; it < spi / NP; ++it) {
+            // the pixel blocks of this trip: NP == 1: block sub0 + it; NP == 2: blocks (0, 1), (2, 3) of a tile of four 16x1
+            // rows, blocks (0, 2), (1, 3) of a tile of 8x2 blocks (stacked to 8x4)
+            int subs[NP];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) ray[i] = rayN[i];
-#pragma unroll
-            for (int mm = 0; mm < MCH; ++mm) rv[mm] = rvN[mm];
-#ifdef DIST_PREFETCH
-            if (sub + 1 < sub0 + spi) issue_pixel_loads(sub + 1);
-#endif
-            if ((wide ? ty * 4 + sub : ty * 4 + 2 * (sub >> 1)) >= H) continue;   // the block lies below the image (uniform)
-            // lane roles: in the vector phases thread (n, tq) owns pixel n of the block and planes 64 h + 4 tq .. + 3; in the
+            for (int s = 0; s < NP; ++s) subs[s] = NP == 1 ? sub0 + it : (wide ? 2 * it + s : it + 2 * s);
+            if ((wide ? ty * 4 + subs[0] : ty * 4 + 2 * (subs[0] >> 1)) >= H) continue;   // the blocks lie below the image (uniform)
+            // lane roles: in the vector phases thread (n, tq) owns pixel n of each block and planes 64 h + 4 tq .. + 3; in the
             // matrix phase lane (n, kq) of a wave feeds texel / pixel n and K slice kq.  (opaque: the optimiser otherwise
-            // hoists every lane-derived invariant of the phases to the top of the kernel and spills them)
-            const int tid = opaque_v((int)threadIdx.x), lane = tid & 63;   // (shadow the kernel's: re-derived per pixel block)
+            // hoists every lane-derived invariant of the phases to the top of the kernel)
+            const int tid = opaque_v((int)threadIdx.x), lane = tid & 63;   // (shadow the kernel's: re-derived per trip)
             const int n = lane & 15, kq = lane >> 4, tq = wave * 4 + kq;
             const int HW = opaque_s(H * W);
-            int x, y;
-            block_pixel(sub, lane, x, y);
-            const bool xlive = x < W && y < H;
-            const int p = min(y, H - 1) * W + min(x, W - 1);
-            DSTAMP(1)   // item set-up, pixel loads issued
-            float rr = 0.0f, zc = 0.0f;    // |r'|^2 and |r|^2 of the pixel, scaled (set with the first pass)
-            bool centred = false;
-            unsigned failmask = 0;         // uniform over the workgroup: passes (view v, plane group h) left to the direct evaluation
-
-            float cost[NC];
+            int p[NP];
+            bool xlive[NP];
+            float ray[NP][3], rv[NP][MCH];
+            // the pixels' rays, and this thread's share of the blocks' reference features: channels tq, tq + 16, ... of pixel n
+            // (buffer loads: 32-bit offsets, the channel as the scalar offset; channels beyond C = 0)
+            {
+                const __amdgpu_buffer_rsrc_t rray =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(da.a.rays + (size_t)b * 3 * HW), 0, 3 * HW * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rref =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(da.a.ref + (size_t)b * da.a.ref_bstride), 0, C * HW * 4, 0x00020000);
 #pragma unroll
-            for (int j = 0; j < NC; ++j) cost[j] = 0.0f;
+                for (int s = 0; s < NP; ++s) {
+                    const int x = wide ? tx * 16 + n : tx * 16 + 8 * (subs[s] & 1) + (n & 7);
+                    const int y = wide ? ty * 4 + subs[s] : ty * 4 + 2 * (subs[s] >> 1) + (n >> 3);
+                    xlive[s] = x < W && y < H;
+                    p[s] = min(y, H - 1) * W + min(x, W - 1);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) ray[s][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rray, p[s] * 4, i * HW * 4, 0));
+#pragma unroll
+                    for (int mm = 0; mm < MCH; ++mm)
+                        rv[s][mm] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rref, tq + 16 * mm < C ? (tq * HW + p[s]) * 4 : OOB, 16 * mm * HW * 4, 0));
+                }
+            }
+            DSTAMP(1)   // item set-up, pixel loads issued
+            float rr[NP], zc[NP];          // |r'|^2 and |r|^2 of the pixels, scaled (set with the first pass)
+            bool centred = false;
+            unsigned failmask[NP];         // uniform over the workgroup: passes (view v, plane group h) left to the direct evaluation
+            float cost[NP][NC];
+#pragma unroll
+            for (int s = 0; s < NP; ++s) {
+                rr[s] = 0.0f; zc[s] = 0.0f; failmask[s] = 0;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) cost[s][j] = 0.0f;
+            }
 
             for (int v = 0; v < V; ++v) {
                 const char* srcv = da.packed + (size_t)((size_t)b * V + v) * dist::view_bytes(C, H, W);
@@ -382,344 +378,345 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
 
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
-                    const int par = pt & 1;
-                    if (!item_ready) { DIST_BARRIER(); item_ready = true; }   // (the item's tables above are in LDS)
+                    if (!item_ready) { PDEPTH_LDS_BARRIER(); item_ready = true; }   // (the item's tables above are in LDS)
                     // ---- sample positions of this thread's planes of the pass (NO_CELL: no tap in the image, plane beyond D,
                     //      pixel beyond the image)
-                    int cell[4];
-                    float fw[4], fn[4];
+                    int cell[NP][4];
+                    float fw[NP][4], fn[NP][4];
                     {
                         ViewXform xf;
-                        float t2a, t2b, t2c;
                         {
                             const v4f k0 = *reinterpret_cast<const v4f*>(&L.xf[v * 12]), k1 = *reinterpret_cast<const v4f*>(&L.xf[v * 12 + 4]),
                                       k2 = *reinterpret_cast<const v4f*>(&L.xf[v * 12 + 8]);
                             xf.kr[0] = k0.x; xf.kr[1] = k0.y; xf.kr[2] = k0.z; xf.kr[3] = k0.w; xf.kr[4] = k1.x; xf.kr[5] = k1.y;
                             xf.kr[6] = k1.z; xf.kr[7] = k1.w; xf.kr[8] = k2.x; xf.kt[0] = k2.y; xf.kt[1] = k2.z; xf.kt[2] = k2.w;
                             xf.separate = da.a.blas_mode;
-                            ray_term2(xf, ray[0], ray[1], ray[2], t2a, t2b, t2c);
                         }
                         const v4f c0 = *reinterpret_cast<const v4f*>(&L.cst[0]);
                         const v2f c1 = *reinterpret_cast<const v2f*>(&L.cst[4]);
 #pragma unroll
-                        for (int j = 0; j < 4; j += 2) {
-                            const int k = 64 * h + 4 * tq + j;
-                            v2f ix, iy;
-#ifdef ABL_CHEAP_POS
-                            { const float dk0 = L.dcl[k], dk1 = L.dcl[k + 1];
-                              ix = v2f{(float)x + 0.25f + dk0 * 0.3f, (float)x + 0.25f + dk1 * 0.3f}; iy = v2f{(float)y + 0.25f + dk0 * 0.1f, (float)y + 0.25f + dk1 * 0.1f};
-                              asm volatile("" :: "v"(t2a), "v"(t2b), "v"(t2c)); }
-#elif defined(DIST_PACKED_POS)
-                            plane_sample_pos_fast2(xf, t2a, t2b, t2c, v2f{L.dcl[k], L.dcl[k + 1]}, c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ix, iy);
-#else
-                            // (scalar instructions: packed fp32 -- two planes per v_pk_* instruction -- now and then loses the low
-                            //  half of a result in lanes 48..63 in this kernel on gfx950: wave_util.hpp)
-                            {
-                                float ax, ay, bx, by;
-                                plane_sample_pos_fast(xf, t2a, t2b, t2c, L.dcl[k], c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ax, ay);
-                                plane_sample_pos_fast(xf, t2a, t2b, t2c, L.dcl[k + 1], c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, bx, by);
-                                ix = v2f{ax, bx}; iy = v2f{ay, by};
-                            }
-#endif
-                            cell[j] = cell_of(ix.x, iy.x, W, H, fw[j], fn[j]);
-                            cell[j + 1] = cell_of(ix.y, iy.y, W, H, fw[j + 1], fn[j + 1]);
-                            if (k >= D || !xlive) cell[j] = NO_CELL;
-                            if (k + 1 >= D || !xlive) cell[j + 1] = NO_CELL;
-                        }
-                        // (pinned: the optimiser otherwise carries the positions AND their floors to the combine instead of the fractions)
+                        for (int s = 0; s < NP; ++s) {
+                            float t2a, t2b, t2c;
+                            ray_term2(xf, ray[s][0], ray[s][1], ray[s][2], t2a, t2b, t2c);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(fw[j])); asm volatile("" : "+v"(fn[j])); }
-                    }
-                    DSTAMP(2)   // (wait for the ray) sample positions
-                    // ---- row table: contributions of this thread's planes --------------------------------------------------
-                    {
-                        int lmin = INT_MAX, lmax = INT_MIN;
-                        int run = INT_MIN, rmin = 0, rmax = 0;   // consecutive planes of equal row are folded first
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (cell[j] != NO_CELL) {
-                                const int cyy = cell_y(cell[j]), cxx = cell_x(cell[j]);
-                                lmin = min(lmin, cyy); lmax = max(lmax, cyy);
-                                if (cyy != run) {
-                                    if (run != INT_MIN) { atomicMin(&L.cmin[par][run & 63], rmin); atomicMax(&L.cmax[par][run & 63], rmax); }
-                                    run = cyy; rmin = cxx; rmax = cxx;
-                                } else {
-                                    rmin = min(rmin, cxx); rmax = max(rmax, cxx);
-                                }
+                            for (int j = 0; j < 4; ++j) {
+                                const int k = 64 * h + 4 * tq + j;
+                                float ix, iy;
+                                // (scalar instructions: packed fp32 -- two planes per v_pk_* instruction -- now and then loses the low
+                                //  half of a result in lanes 48..63 beside v_mfma_f32_16x16x32_f16 on gfx950: wave_util.hpp)
+                                plane_sample_pos_fast(xf, t2a, t2b, t2c, L.dcl[k], c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ix, iy);
+                                cell[s][j] = cell_of(ix, iy, W, H, fw[s][j], fn[s][j]);
+                                if (k >= D || !xlive[s]) cell[s][j] = NO_CELL;
                             }
+                            // (pinned: the optimiser otherwise carries the positions AND their floors to the combine instead of the fractions)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(fw[s][j])); asm volatile("" : "+v"(fn[s][j])); }
                         }
-                        if (run != INT_MIN) { atomicMin(&L.cmin[par][run & 63], rmin); atomicMax(&L.cmax[par][run & 63], rmax); }
-                        const int wmin = wave_min_i(lmin), wmax = wave_max_i(lmax);
-                        if (lane == 0 && wmin <= wmax) { atomicMin(&L.ired[par][0], wmin); atomicMax(&L.ired[par][1], wmax); }
                     }
-#ifdef ABL_NO_CENTRING
-                    if (false) {
-#else
+                    DSTAMP(2)   // (wait for the rays) sample positions
                     if (!centred) {
-#endif
-                        // (first pass of the block) this thread's channels of pixel n: x' = (r - mu) 2^e, split into fp16 high and
-                        // low parts, times -2, into the pixel-side operand image of the block; and its share of |r'|^2 and |r|^2.
-                        // Channel c = tq + 16 mm: chunk (c >> 5) for c < 32 NCHK, K slot c & 31; else the tail chunk: K slots t (its
-                        // high part, against the texel's high part), 8 + t (high, against the texel's low part), 16 + t (low).
+                        // (first pass of the trip) this thread's channels of pixel n of each block: -2 x' = -2 (r - mu) 2^e in one
+                        // rounding (scaling by a power of two commutes with it), split into fp16 high and low parts, into the
+                        // pixel-side operand image of the block; and its share of |r'|^2 and |r|^2.  Channel c = tq + 16 mm: chunk
+                        // (c >> 5) for c < 32 NCHK, K slot c & 31; else the tail chunk: K slots t (its high part, against the
+                        // texel's high part), 8 + t (high, against the texel's low part), 16 + t (low).
                         const float sc = L.cst[6], sm2 = -2.0f * sc;
-                        float pr = 0.0f, pz = 0.0f;
 #pragma unroll
-                        for (int mm = 0; mm < MCH; ++mm) {
-                            const int c = tq + 16 * mm;
-                            const bool has = c < CPAD;   // (only the last round can fall beyond the padded channels)
-                            const float m2 = 2.0f * L.mus[min(c, dist::MAX_C + 7)];
-                            // -2 x' in one rounding (scaling by a power of two commutes with the rounding of x' = (r - mu) 2^e)
-                            const float xm = has ? __builtin_fmaf(rv[mm], sm2, m2) : 0.0f;
-                            const float rs = has ? rv[mm] * sc : 0.0f;
-                            pr = __builtin_fmaf(xm, xm, pr);
-                            pz = __builtin_fmaf(rs, rs, pz);
-                            const float xc = __builtin_amdgcn_fmed3f(xm, -64000.0f, 64000.0f);
-                            const _Float16 bh = (_Float16)xc;
-                            const _Float16 bl = (_Float16)(xc - (float)bh);
-                            if (16 * mm < 32 * NCHK) {   // (compile time: the round lies in a chunk of 32)
-                                const int chunk = (16 * mm) >> 5, kqq = 2 * (mm & 1) + (tq >> 3), jj = tq & 7;
-                                L.Bs[((chunk * 4 + kqq) * 16 + n) * 8 + jj] = bh;
-                                L.Bs[(((NCHK + chunk) * 4 + kqq) * 16 + n) * 8 + jj] = bl;
-                            } else if (has) {
-                                const int t = tq;   // (c - 32 NCHK)
-                                L.Bs[(((2 * NCHK) * 4 + 0) * 16 + n) * 8 + t] = bh;
-                                L.Bs[(((2 * NCHK) * 4 + 1) * 16 + n) * 8 + t] = bh;
-                                L.Bs[(((2 * NCHK) * 4 + 2) * 16 + n) * 8 + t] = bl;
+                        for (int s = 0; s < NP; ++s) {
+                            float pr = 0.0f, pz = 0.0f;
+#pragma unroll
+                            for (int mm = 0; mm < MCH; ++mm) {
+                                const int c = tq + 16 * mm;
+                                const bool has = c < CPAD;   // (only the last round can fall beyond the padded channels)
+                                const float m2 = 2.0f * L.mus[min(c, dist::MAX_C + 7)];
+                                const float xm = has ? __builtin_fmaf(rv[s][mm], sm2, m2) : 0.0f;
+                                const float rs = has ? rv[s][mm] * sc : 0.0f;
+                                pr = __builtin_fmaf(xm, xm, pr);
+                                pz = __builtin_fmaf(rs, rs, pz);
+                                const float xc = __builtin_amdgcn_fmed3f(xm, -64000.0f, 64000.0f);
+                                const _Float16 bh = (_Float16)xc;
+                                const _Float16 bl = (_Float16)(xc - (float)bh);
+                                if (16 * mm < 32 * NCHK) {   // (compile time: the round lies in a chunk of 32)
+                                    const int chunk = (16 * mm) >> 5, kqq = 2 * (mm & 1) + (tq >> 3), jj = tq & 7;
+                                    L.Bs[s][((chunk * 4 + kqq) * 16 + n) * 8 + jj] = bh;
+                                    L.Bs[s][(((NCHK + chunk) * 4 + kqq) * 16 + n) * 8 + jj] = bl;
+                                } else if (has) {
+                                    const int t = tq;   // (c - 32 NCHK)
+                                    L.Bs[s][(((2 * NCHK) * 4 + 0) * 16 + n) * 8 + t] = bh;
+                                    L.Bs[s][(((2 * NCHK) * 4 + 1) * 16 + n) * 8 + t] = bh;
+                                    L.Bs[s][(((2 * NCHK) * 4 + 2) * 16 + n) * 8 + t] = bl;
+                                }
                             }
-                        }
-                        pr = 0.25f * pr;
-                        pr = pr + __shfl_xor(pr, 16); pr = pr + __shfl_xor(pr, 32);
-                        pz = pz + __shfl_xor(pz, 16); pz = pz + __shfl_xor(pz, 32);
-                        if (kq == 0) *reinterpret_cast<v2f*>(&L.rp[(wave * 16 + n) * 2]) = v2f{pr, pz};
-                    }
-                    DSTAMP(3)   // table atomics, (wait for the reference features) centring
-                    DIST_BARRIER();   // tables (and the operand image) complete
-                    DSTAMP(4)   // barrier
-                    if (!centred) {
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) {
-                            const v2f pp = *reinterpret_cast<const v2f*>(&L.rp[(w * 16 + n) * 2]);
-                            rr = rr + pp.x; zc = zc + pp.y;
-                        }
-                        centred = true;
-                    }
-                    // the pixel-side operands of lane (n, kq): high[NCHK], low[NCHK], tail -- from LDS every pass (they would
-                    // otherwise occupy registers through the vector phases of every further pass)
-                    h8 Bv[NAC];
-#pragma unroll
-                    for (int i = 0; i < NAC; ++i) Bv[i] = *reinterpret_cast<const h8*>(&L.Bs[((i * 4 + kq) * 16 + n) * 8]);
-                    {
-                        // the specials of the tail chunk (K slots 24..31 = lanes kq == 3): the constants that multiply the texel's
-                        // pieces of N, and |r'|^2 as three fp16 pieces against the texel's constants (dist_layout.hpp)
-                        const dist::Pieces pq = dist::split_pieces(fminf(rr, 2.0e9f));
-                        h8 sp;
-                        sp[0] = (_Float16)dist::PIECE_C1; sp[1] = (_Float16)dist::PIECE_C2; sp[2] = (_Float16)dist::PIECE_C3;
-                        sp[3] = pq.p1; sp[4] = pq.p2; sp[5] = pq.p3; sp[6] = (_Float16)0.f; sp[7] = (_Float16)0.f;
-                        if (kq == 3) Bv[NAC - 1] = sp;
-                    }
-                    // ---- the row table, cut into blocks of 16 texels: every wave for itself, lane = texel row yb + lane -------
-                    const int yb = __builtin_amdgcn_readfirstlane(L.ired[par][0]), yt = __builtin_amdgcn_readfirstlane(L.ired[par][1]);
-                    int nb = 0, lo = INT_MAX, hi = INT_MIN, nblk = 0, fb = 0;
-                    bool fits = true;
-                    if (yb <= yt) {
-                        const int ncell = yt - yb + 1;
-                        if (ncell + 1 > 64 || ncell + 1 > MAXB) {   // (every texel row takes a block; rows are kept modulo 64)
-                            fits = false;
-                        } else {
-                            // the cells of rows lane - 1 and lane touch texel row lane
-                            if (lane < ncell) { lo = L.cmin[par][(yb + lane) & 63]; hi = L.cmax[par][(yb + lane) & 63]; }
-                            if (lane >= 1 && lane <= ncell) {
-                                lo = min(lo, L.cmin[par][(yb + lane - 1) & 63]);
-                                hi = max(hi, L.cmax[par][(yb + lane - 1) & 63]);
-                            }
-#ifndef DIST_UNALIGNED_BLOCKS
-                            // (blocks start at a multiple of 4 texels of the padded row: 64-byte pieces for the loads of four lanes)
-                            if (lo <= hi) lo = ((lo + dist::RING) & ~3) - dist::RING;
-#endif
-                            nblk = lo <= hi ? (hi - lo + 2 + 15) >> 4 : 0;   // texels lo .. hi + 1
-                            const int incl = wave_scan_incl(nblk);
-                            nb = __builtin_amdgcn_readlane(incl, 63);
-                            fits = nb <= MAXB;
-                            fb = incl - nblk;
+                            pr = 0.25f * pr;
+                            pr = pr + __shfl_xor(pr, 16); pr = pr + __shfl_xor(pr, 32);
+                            pz = pz + __shfl_xor(pz, 16); pz = pz + __shfl_xor(pz, 32);
+                            if (kq == 0) *reinterpret_cast<v2f*>(&L.rp[s][(wave * 16 + n) * 2]) = v2f{pr, pz};
                         }
                     }
-                    if (L.iflag != 0) fits = false;   // (the item is evaluated directly)
-                    const int rowoff = 16 * fb - lo;    // slot of texel x of this lane's row = x + rowoff
-                    const bool go = fits && nb > 0;
-                    DSTAMP(5)   // operands from LDS, row table cut into blocks
-                    // ---- Y = |s' - r'|^2 for the blocks of the pass, on the matrix pipe --------------------------------------
-                    int sl[4];   // slots of the top (low 16 bits) / bottom row of this thread's cells; < 0: no cell
-                    {
-                        v4i rs4;   // the descriptor of rsrc, spelled out for the inline asm
+                    // ---- the pass on a set of pixel blocks: both (mask 3), or -- when their common window does not fit the Y
+                    //      buffer -- one after the other (masks 1, 2); NP == 1: mask 1
+                    int mask = (1 << NP) - 1;
+                    for (;;) {
+                        const int par = pt & 1;
+                        // ---- row table: contributions of this thread's planes ------------------------------------------------
                         {
-                            const unsigned long long pa = reinterpret_cast<unsigned long long>(srcv);
-                            rs4.x = (int)(unsigned)pa; rs4.y = (int)(unsigned)(pa >> 32) & 0xffff; rs4.z = (int)dist::view_bytes(C, H, W); rs4.w = 0x00020000;
-                        }
-                        const int voffA = opaque_v(n * 16 + kq * PB);
-                        // a block's texel operands in consumption order: (high c, low c) for c < NCHK, tail; ONE register set, every
-                        // chunk refilled with the next block's right behind its last multiplication (a block in flight per wave)
-                        h8 S[NAC];
-                        // Block j of the pass (lane j): the byte offset of its first texel in plane 0.  Its row = the lane rho with
-                        // fb <= j < fb + nblk: the row lanes scatter their index through LDS (every wave writes the same values and
-                        // reads back what it wrote), its first texel lo[rho] + 16 (j - fb[rho]).
-                        int boff = 0;
-                        if (go) {
+                            int lmin = INT_MAX, lmax = INT_MIN;
 #pragma unroll
-                            for (int i = 0; i < 2; ++i)   // (a row rarely needs more than two blocks: no loop for those)
-                                if (i < nblk) L.brow[fb + i] = lane;
-                            for (int i = 2; i < nblk; ++i) L.brow[fb + i] = lane;
-                            const int rho = L.brow[min(lane, MAXB - 1)];
-                            const int xs = __builtin_amdgcn_ds_bpermute(4 * rho, lo) + 16 * (lane - __builtin_amdgcn_ds_bpermute(4 * rho, fb));
-                            boff = lane < nb ? ((yb + rho + dist::RING) * Wp + xs + dist::RING) * 16 : OOB;
-                        }
-                        auto fetch = [&](int i, int soff) {   // chunk i: planes 4 i .. 4 i + 3 (the lane's: + kq, in voffA)
-#ifdef ABL_NO_ALOAD
-                            S[i] = __builtin_bit_cast(h8, v4i{soff, voffA, i, 1});
-#else
-                            S[i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffA, soff + i * 4 * PB, 0));
-#endif
-                        };
-                        // wave w: blocks w q .. w q + q - 1 (consecutive blocks: consecutive slots)
-                        const int q = (nb + 3) >> 2, b0 = wave * q, b1 = min(nb, b0 + q);
-                        if (DIST_XPRIO) __builtin_amdgcn_s_setprio(DIST_XPRIO);
-#ifdef ABL_NO_X
-                        if (false) {
-#else
-                        if (go) {
-#endif
-                            // the Q records of the pass's cells, from memory straight to LDS: blocks 4 g .. 4 g + 3 per instruction
-                            // (lane = (block, texel)); wave w moves groups w and w + 4
+                            for (int s = 0; s < NP; ++s) {
+                                if (!(mask >> s & 1)) continue;   // uniform
+                                int run = INT_MIN, rmin = 0, rmax = 0;   // consecutive planes of equal row are folded first
 #pragma unroll
-                            for (int gq = 0; gq < (MAXB + 15) / 16; ++gq) {
-                                const int g = wave + 4 * gq;
-                                if (4 * g < nb) {   // uniform
-                                    const int bo = __builtin_amdgcn_ds_bpermute(4 * (4 * g + kq), boff);
-                                    const int vq = 4 * g + kq < nb ? bo + n * 16 : OOB;
-                                    dma_b128(rs4, lds_addr_of(&L.Qs[g * 256]), vq, QPL * PB);
+                                for (int j = 0; j < 4; ++j) {
+                                    if (cell[s][j] != NO_CELL) {
+                                        const int cyy = cell_y(cell[s][j]), cxx = cell_x(cell[s][j]);
+                                        lmin = min(lmin, cyy); lmax = max(lmax, cyy);
+                                        if (cyy != run) {
+                                            if (run != INT_MIN) { atomicMin(&L.cmin[par][run & 63], rmin); atomicMax(&L.cmax[par][run & 63], rmax); }
+                                            run = cyy; rmin = cxx; rmax = cxx;
+                                        } else {
+                                            rmin = min(rmin, cxx); rmax = max(rmax, cxx);
+                                        }
+                                    }
+                                }
+                                if (run != INT_MIN) { atomicMin(&L.cmin[par][run & 63], rmin); atomicMax(&L.cmax[par][run & 63], rmax); }
+                            }
+                            const int wmin = wave_min_i(lmin), wmax = wave_max_i(lmax);
+                            if (lane == 0 && wmin <= wmax) { atomicMin(&L.ired[par][0], wmin); atomicMax(&L.ired[par][1], wmax); }
+                        }
+                        DSTAMP(3)   // table atomics, (wait for the reference features) centring
+                        PDEPTH_LDS_BARRIER();   // tables (and the operand images) complete
+                        DSTAMP(4)   // barrier
+                        if (!centred) {
+#pragma unroll
+                            for (int s = 0; s < NP; ++s)
+#pragma unroll
+                                for (int w = 0; w < 4; ++w) {
+                                    const v2f pp = *reinterpret_cast<const v2f*>(&L.rp[s][(w * 16 + n) * 2]);
+                                    rr[s] = rr[s] + pp.x; zc[s] = zc[s] + pp.y;
+                                }
+                            // the specials of the tail chunk (K slots 24..31 = lanes kq == 3): the constants that multiply the texel's
+                            // pieces of N, and |r'|^2 as three fp16 pieces against the texel's constants (dist_layout.hpp) -- into the
+                            // operand image (every wave writes the same values; a wave reads what it wrote itself)
+                            if (kq == 3) {
+#pragma unroll
+                                for (int s = 0; s < NP; ++s) {
+                                    const dist::Pieces pq = dist::split_pieces(fminf(rr[s], 2.0e9f));
+                                    h8 sp;
+                                    sp[0] = (_Float16)dist::PIECE_C1; sp[1] = (_Float16)dist::PIECE_C2; sp[2] = (_Float16)dist::PIECE_C3;
+                                    sp[3] = pq.p1; sp[4] = pq.p2; sp[5] = pq.p3; sp[6] = (_Float16)0.f; sp[7] = (_Float16)0.f;
+                                    *reinterpret_cast<h8*>(&L.Bs[s][(((NAC - 1) * 4 + 3) * 16 + n) * 8]) = sp;
                                 }
                             }
-#ifdef DIST_FAT
+                            centred = true;
                         }
-                        // (256-register build: every block of the wave in flight at once)
-                        h8 SF[BPW][NAC];
-                        if (go) {
+                        // the pixel-side operands of lane (n, kq): high[NCHK], low[NCHK], tail -- from LDS every pass (NP == 1) or
+                        // every texel block (NP == 2: 40 registers otherwise)
+                        h8 Bv[NP][NAC];
+                        if (NP == 1) {
 #pragma unroll
-                            for (int i = 0; i < BPW; ++i)
-                                if (b0 + i < b1) {
-                                    const int soff = __builtin_amdgcn_readlane(boff, b0 + i);
-#pragma unroll
-                                    for (int c = 0; c < NAC; ++c)
-                                        SF[i][c] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffA, soff + c * 4 * PB, 0));
+                            for (int i = 0; i < NAC; ++i) Bv[0][i] = *reinterpret_cast<const h8*>(&L.Bs[0][((i * 4 + kq) * 16 + n) * 8]);
+                        }
+                        // ---- the row table, cut into blocks of 16 texels: every wave for itself, lane = texel row yb + lane -----
+                        const int yb = __builtin_amdgcn_readfirstlane(L.ired[par][0]), yt = __builtin_amdgcn_readfirstlane(L.ired[par][1]);
+                        int nb = 0, lo = INT_MAX, hi = INT_MIN, nblk = 0, fb = 0;
+                        bool fits = true;
+                        if (yb <= yt) {
+                            const int ncell = yt - yb + 1;
+                            if (ncell + 1 > 64 || ncell + 1 > MAXB) {   // (every texel row takes a block; rows are kept modulo 64)
+                                fits = false;
+                            } else {
+                                // the cells of rows lane - 1 and lane touch texel row lane
+                                if (lane < ncell) { lo = L.cmin[par][(yb + lane) & 63]; hi = L.cmax[par][(yb + lane) & 63]; }
+                                if (lane >= 1 && lane <= ncell) {
+                                    lo = min(lo, L.cmin[par][(yb + lane - 1) & 63]);
+                                    hi = max(hi, L.cmax[par][(yb + lane - 1) & 63]);
                                 }
-                        }
-#else
-                            if (b0 < b1) {
-                                const int soff = __builtin_amdgcn_readlane(boff, b0);
-#pragma unroll
-                                for (int c = 0; c < NCHK; ++c) { fetch(c, soff); fetch(NCHK + c, soff); }
-                                fetch(NAC - 1, soff);
+                                // (blocks start at a multiple of 4 texels of the padded row: 64-byte pieces for the loads of four lanes)
+                                if (lo <= hi) lo = ((lo + dist::RING) & ~3) - dist::RING;
+                                nblk = lo <= hi ? (hi - lo + 2 + 15) >> 4 : 0;   // texels lo .. hi + 1
+                                const int incl = wave_scan_incl(nblk);
+                                nb = __builtin_amdgcn_readlane(incl, 63);
+                                fits = nb <= MAXB;
+                                fb = incl - nblk;
                             }
                         }
+                        if (L.iflag != 0) fits = false;   // (the item is evaluated directly)
+#ifdef DIST_FORCE_DIRECT   // test build: every pass takes the direct evaluation (DIST_FORCE_DIRECT_VIEW: those of that view)
+#ifdef DIST_FORCE_DIRECT_VIEW
+                        if (v == DIST_FORCE_DIRECT_VIEW)
 #endif
-                        // the slots of this thread's cells (under the first block's loads)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const bool has = fits && cell[j] != NO_CELL;
-                            const int r = has ? cell_y(cell[j]) - yb : 0;
-                            const int o0 = __builtin_amdgcn_ds_bpermute(4 * r, rowoff), o1 = __builtin_amdgcn_ds_bpermute(4 * r + 4, rowoff);
-                            const int cxx = cell_x(cell[j]);
-                            sl[j] = has ? (cxx + o0) | ((cxx + o1) << 16) : -1;
-                        }
-#ifdef ABL_NO_X
-                        if (false) {
-#else
-                        if (go) {
+                        fits = false;
 #endif
-#ifdef DIST_FAT
-#pragma unroll
-                            for (int i = 0; i < BPW; ++i) {
-                                const int bi = b0 + i;
-                                if (bi >= b1) break;
-                                v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                                for (int c = 0; c < NCHK; ++c) {
-                                    acc = DIST_MFMA(SF[i][c], Bv[c], acc);
-                                    acc = DIST_MFMA(SF[i][c], Bv[NCHK + c], acc);
-                                    acc = DIST_MFMA(SF[i][NCHK + c], Bv[c], acc);
-                                }
-                                acc = DIST_MFMA(SF[i][NAC - 1], Bv[NAC - 1], acc);
-                                *reinterpret_cast<v4f*>(&L.Ys[n * XSTRIDE + 16 * bi + 4 * kq]) = acc;
+                        ++pt;
+                        if (NP == 2 && !fits && mask == 3 && L.iflag == 0) {
+                            // the common window of the two blocks is too large: the blocks one after the other (every wave has read the
+                            // tables: behind the barrier wave 1 cleans them)
+                            PDEPTH_LDS_BARRIER();
+                            if (wave == 1) {
+                                L.cmin[par][lane] = INT_MAX; L.cmax[par][lane] = INT_MIN;
+                                if (lane == 0) { L.ired[par][0] = INT_MAX; L.ired[par][1] = INT_MIN; }
                             }
-#else
-#pragma unroll
-                            for (int i = 0; i < BPW; ++i) {
-                                const int bi = b0 + i;
-                                if (bi >= b1) break;
-                                const bool more = i + 1 < BPW && bi + 1 < b1;   // uniform
-                                const int soff = more ? __builtin_amdgcn_readlane(boff, bi + 1) : 0;
-                                v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                                for (int c = 0; c < NCHK; ++c) {
-                                    acc = DIST_MFMA(S[c], Bv[c], acc);
-                                    acc = DIST_MFMA(S[c], Bv[NCHK + c], acc);
-                                    if (more) fetch(c, soff);
-                                    acc = DIST_MFMA(S[NCHK + c], Bv[c], acc);
-                                    if (more) fetch(NCHK + c, soff);
-                                }
-                                acc = DIST_MFMA(S[NAC - 1], Bv[NAC - 1], acc);
-                                if (more) fetch(NAC - 1, soff);
-                                *reinterpret_cast<v4f*>(&L.Ys[n * XSTRIDE + 16 * bi + 4 * kq]) = acc;   // Y[texel 4 kq ..][pixel n] of the block
-                            }
-#endif
-                            DSTAMP(6)   // slots, loads + multiplications
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's Q records have landed in LDS
+                            mask = 1;
+                            continue;
                         }
-                        if (DIST_XPRIO) __builtin_amdgcn_s_setprio(0);
-                    }
-                    DSTAMP(7)   // wait for the Q records
-                    DIST_BARRIER();   // Y and the Q records of the pass are complete
-                    DSTAMP(8)   // barrier
-                    ++pt;
-                    // (every wave has read the tables of this pass: wave 1 cleans them for the pass after the next)
-                    if (wave == 1) {
-                        L.cmin[par][lane] = INT_MAX; L.cmax[par][lane] = INT_MIN;
-                        if (lane == 0) { L.ired[par][0] = INT_MAX; L.ired[par][1] = INT_MIN; }
-                    }
+                        const int rowoff = 16 * fb - lo;    // slot of texel x of this lane's row = x + rowoff
+                        const bool go = fits && nb > 0;
+                        DSTAMP(5)   // operands from LDS, row table cut into blocks
+                        // ---- Y = |s' - r'|^2 for the blocks of the pass, on the matrix pipe ------------------------------------
+                        int sl[NP][4];   // slots of the top (low 16 bits) / bottom row of this thread's cells; < 0: no cell
+                        {
+                            v4i rs4;   // the descriptor of rsrc, spelled out for the inline asm
+                            {
+                                const unsigned long long pa = reinterpret_cast<unsigned long long>(srcv);
+                                rs4.x = (int)(unsigned)pa; rs4.y = (int)(unsigned)(pa >> 32) & 0xffff; rs4.z = (int)dist::view_bytes(C, H, W); rs4.w = 0x00020000;
+                            }
+                            const int voffA = opaque_v(n * 16 + kq * PB);
+                            // a block's texel operands in consumption order: (high c, low c) for c < NCHK, tail; ONE register set, every
+                            // chunk refilled with the next block's right behind its last multiplication (a block in flight per wave)
+                            h8 S[NAC];
+                            // Block j of the pass (lane j): the byte offset of its first texel in plane 0.  Its row = the lane rho with
+                            // fb <= j < fb + nblk: the row lanes scatter their index through LDS (every wave writes the same values and
+                            // reads back what it wrote), its first texel lo[rho] + 16 (j - fb[rho]).
+                            int boff = 0;
+                            if (go) {
+#pragma unroll
+                                for (int i = 0; i < 2; ++i)   // (a row rarely needs more than two blocks: no loop for those)
+                                    if (i < nblk) L.brow[fb + i] = lane;
+                                for (int i = 2; i < nblk; ++i) L.brow[fb + i] = lane;
+                                const int rho = L.brow[min(lane, MAXB - 1)];
+                                const int xs = __builtin_amdgcn_ds_bpermute(4 * rho, lo) + 16 * (lane - __builtin_amdgcn_ds_bpermute(4 * rho, fb));
+                                boff = lane < nb ? ((yb + rho + dist::RING) * Wp + xs + dist::RING) * 16 : OOB;
+                            }
+                            auto fetch = [&](int i, int soff) {   // chunk i: planes 4 i .. 4 i + 3 (the lane's: + kq, in voffA)
+                                S[i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffA, soff + i * 4 * PB, 0));
+                            };
+                            // wave w: blocks w q .. w q + q - 1 (consecutive blocks: consecutive slots)
+                            const int q = (nb + 3) >> 2, b0 = wave * q, b1 = min(nb, b0 + q);
+                            if (DIST_XPRIO) __builtin_amdgcn_s_setprio(DIST_XPRIO);
+                            if (go) {
+                                // the Q records of the pass's cells, from memory straight to LDS: blocks 4 g .. 4 g + 3 per instruction
+                                // (lane = (block, texel)); wave w moves groups w and w + 4
+#pragma unroll
+                                for (int gq = 0; gq < (MAXB + 15) / 16; ++gq) {
+                                    const int g = wave + 4 * gq;
+                                    if (4 * g < nb) {   // uniform
+                                        const int bo = __builtin_amdgcn_ds_bpermute(4 * (4 * g + kq), boff);
+                                        const int vq = 4 * g + kq < nb ? bo + n * 16 : OOB;
+                                        dma_b128(rs4, lds_addr_of(&L.Qs[g * 256]), vq, QPL * PB);
+                                    }
+                                }
+                                if (b0 < b1) {
+                                    const int soff = __builtin_amdgcn_readlane(boff, b0);
+#pragma unroll
+                                    for (int c = 0; c < NCHK; ++c) { fetch(c, soff); fetch(NCHK + c, soff); }
+                                    fetch(NAC - 1, soff);
+                                }
+                            }
+                            // the slots of this thread's cells (under the first block's loads)
+#pragma unroll
+                            for (int s = 0; s < NP; ++s)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const bool has = fits && (mask >> s & 1) && cell[s][j] != NO_CELL;
+                                    const int r = has ? cell_y(cell[s][j]) - yb : 0;
+                                    const int o0 = __builtin_amdgcn_ds_bpermute(4 * r, rowoff), o1 = __builtin_amdgcn_ds_bpermute(4 * r + 4, rowoff);
+                                    const int cxx = cell_x(cell[s][j]);
+                                    sl[s][j] = has ? (cxx + o0) | ((cxx + o1) << 16) : -1;
+                                }
+                            if (go) {
+#pragma unroll 1
+                                for (int bi = b0; bi < b1; ++bi) {   // (rolled: unrolled, the compiler hoists the later blocks' work and spills)
+                                    const bool more = bi + 1 < b1;   // uniform
+                                    const int soff = more ? __builtin_amdgcn_readlane(boff, bi + 1) : 0;
+                                    // (a texel chunk against both pixel blocks, then its refill; a block outside the mask is multiplied all
+                                    //  the same: its Y is not read)
+                                    v4f acc[NP];
+#pragma unroll
+                                    for (int s = 0; s < NP; ++s) acc[s] = v4f{0.f, 0.f, 0.f, 0.f};
+                                    if (NP == 2) {
+                                        const int bo = opaque_v((kq * 16 + n) * 8);   // (opaque: read per block, not hoisted out of the loop)
+#pragma unroll
+                                        for (int s = 0; s < NP; ++s)
+#pragma unroll
+                                            for (int c = 0; c < NAC; ++c) Bv[s][c] = *reinterpret_cast<const h8*>(&L.Bs[s][c * 512 + bo]);
+                                    }
+#pragma unroll
+                                    for (int c = 0; c < NCHK; ++c) {
+#pragma unroll
+                                        for (int s = 0; s < NP; ++s) {
+                                            acc[s] = DIST_MFMA(S[c], Bv[s][c], acc[s]);
+                                            acc[s] = DIST_MFMA(S[c], Bv[s][NCHK + c], acc[s]);
+                                        }
+                                        if (more) fetch(c, soff);
+#pragma unroll
+                                        for (int s = 0; s < NP; ++s) acc[s] = DIST_MFMA(S[NCHK + c], Bv[s][c], acc[s]);
+                                        if (more) fetch(NCHK + c, soff);
+                                    }
+#pragma unroll
+                                    for (int s = 0; s < NP; ++s) acc[s] = DIST_MFMA(S[NAC - 1], Bv[s][NAC - 1], acc[s]);
+                                    if (more) fetch(NAC - 1, soff);
+#pragma unroll
+                                    for (int s = 0; s < NP; ++s)   // Y[texel 4 kq ..][pixel n] of the block
+                                        *reinterpret_cast<v4f*>(&L.Ys[s][n * XSTRIDE + 16 * bi + 4 * kq]) = acc[s];
+                                }
+                                DSTAMP(6)   // slots, loads + multiplications
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's Q records have landed in LDS
+                            }
+                            if (DIST_XPRIO) __builtin_amdgcn_s_setprio(0);
+                        }
+                        DSTAMP(7)   // wait for the Q records
+                        PDEPTH_LDS_BARRIER();   // Y and the Q records of the pass are complete
+                        DSTAMP(8)   // barrier
+                        // (every wave has read the tables of this pass: wave 1 cleans them for the pass after the next)
+                        if (wave == 1) {
+                            L.cmin[par][lane] = INT_MAX; L.cmax[par][lane] = INT_MIN;
+                            if (lane == 0) { L.ired[par][0] = INT_MAX; L.ired[par][1] = INT_MIN; }
+                        }
 
-                    // ---- combine: cost of this thread's planes of the pass ------------------------------------------------
-#ifdef ABL_NO_COMBINE
-                    if (true) { for (int j = 0; j < 4; ++j) cost[4 * h + j] += fw[j] + fn[j] + (float)sl[j]; } else
-#endif
-                    if (!fits) {
-                        failmask |= 1u << (v * NH + h);   // (evaluated directly behind the view loop)
-                    } else {
+                        // ---- combine: cost of this thread's planes of the pass ---------------------------------------------
                         const float cinv = L.cst[7];
-                        const float* yr = &L.Ys[n * XSTRIDE];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            // (no tap inside the image: the taps read zero, cost = |r|^2 -- and NaN where the position itself
-                            //  is not finite, as the reference's weights inf - floor(inf) make it)
-                            float q = zc + (fw[j] + fn[j]) * 0.0f;
-                            if (sl[j] >= 0) {
-                                const int s0 = sl[j] & 0xffff, s1 = sl[j] >> 16;
-                                const float Y00 = yr[s0], Y01 = yr[s0 + 1], Y10 = yr[s1], Y11 = yr[s1 + 1];
-                                const v4f qa = *reinterpret_cast<const v4f*>(&L.Qs[s0 * 4]);   // Dx0, Dy0, Dd, Dx1
-                                const float dy1 = L.Qs[s0 * 4 + 5];                            // Dy0 of the right neighbour
-                                const float ex = 1.0f - fw[j], ey = 1.0f - fn[j];
-                                const float w00 = ey * ex, w01 = ey * fw[j], w10 = fn[j] * ex, w11 = fn[j] * fw[j];
-                                const float ys = __builtin_fmaf(w11, Y11, __builtin_fmaf(w10, Y10, __builtin_fmaf(w01, Y01, w00 * Y00)));
-                                const float qi = __builtin_fmaf(w11, qa.z, __builtin_fmaf(w10, qa.y, w01 * qa.x));
-                                const float qo = __builtin_fmaf(w01, dy1, w10 * qa.w);
-                                q = ys - __builtin_fmaf(w11, qo, w00 * qi);
+                        for (int s = 0; s < NP; ++s) {
+                            if (!(mask >> s & 1)) continue;   // uniform
+                            if (!fits) {
+                                failmask[s] |= 1u << (v * NH + h);   // (evaluated directly behind the view loop)
+                                continue;
                             }
-                            cost[4 * h + j] = cost[4 * h + j] + q * cinv;
+                            const float* yr = &L.Ys[s][n * XSTRIDE];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                // (no tap inside the image: the taps read zero, cost = |r|^2 -- and NaN where the position itself
+                                //  is not finite, as the reference's weights inf - floor(inf) make it)
+                                float qv = zc[s] + (fw[s][j] + fn[s][j]) * 0.0f;
+                                if (sl[s][j] >= 0) {
+                                    const int s0 = sl[s][j] & 0xffff, s1 = sl[s][j] >> 16;
+                                    const float Y00 = yr[s0], Y01 = yr[s0 + 1], Y10 = yr[s1], Y11 = yr[s1 + 1];
+                                    const v4f qa = *reinterpret_cast<const v4f*>(&L.Qs[s0 * 4]);   // Dx0, Dy0, Dd, Dx1
+                                    const float dy1 = L.Qs[s0 * 4 + 5];                            // Dy0 of the right neighbour
+                                    const float ex = 1.0f - fw[s][j], ey = 1.0f - fn[s][j];
+                                    const float w00 = ey * ex, w01 = ey * fw[s][j], w10 = fn[s][j] * ex, w11 = fn[s][j] * fw[s][j];
+                                    const float ys = __builtin_fmaf(w11, Y11, __builtin_fmaf(w10, Y10, __builtin_fmaf(w01, Y01, w00 * Y00)));
+                                    const float qi = __builtin_fmaf(w11, qa.z, __builtin_fmaf(w10, qa.y, w01 * qa.x));
+                                    const float qo = __builtin_fmaf(w01, dy1, w10 * qa.w);
+                                    qv = ys - __builtin_fmaf(w11, qo, w00 * qi);
+                                }
+                                cost[s][4 * h + j] = cost[s][4 * h + j] + qv * cinv;
+                            }
                         }
+                        DSTAMP(9)   // combine
+                        if (NP == 2 && mask == 1) {   // (the second block of a pair that did not fit together)
+                            PDEPTH_LDS_BARRIER();     // every wave is done with the Y buffer of the first
+                            mask = 2;
+                            continue;
+                        }
+                        break;
                     }
                 }
             }
 
-            DSTAMP(9)   // combine
-            if (failmask != 0) {
+#pragma unroll
+            for (int s = 0; s < NP; ++s) {
+                if (failmask[s] == 0) continue;   // uniform
                 // Passes left to the direct evaluation: the reference's own form on the packed features -- per plane the four
                 // taps of every group of 8 channels by two 16-byte loads each (high + low parts), the pixel's centred reference
                 // features from the operand image in LDS.  An item whose features did not fit the fp16 range: NaN.
@@ -727,7 +724,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 const bool ovf = (L.iflag & 1) != 0;
 #pragma unroll 1
                 for (int vh = 0; vh < V * NH; ++vh) {
-                    if (!(failmask >> vh & 1u)) continue;
+                    if (!(failmask[s] >> vh & 1u)) continue;
                     if (tid == 0) ++n_direct;
                     const int v = vh / NH, h = vh - v * NH;
                     ViewXform xf;
@@ -737,7 +734,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                     for (int i = 0; i < 3; ++i) xf.kt[i] = L.xf[v * 12 + 9 + i];
                     xf.separate = da.a.blas_mode;
                     float t2a, t2b, t2c;
-                    ray_term2(xf, ray[0], ray[1], ray[2], t2a, t2b, t2c);
+                    ray_term2(xf, ray[s][0], ray[s][1], ray[s][2], t2a, t2b, t2c);
                     const char* srcv = da.packed + (size_t)((size_t)b * V + v) * dist::view_bytes(C, H, W);
 #pragma unroll 1
                     for (int j = 0; j < 4; ++j) {
@@ -745,8 +742,8 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                         float ix, iy, fwj, fnj;
                         plane_sample_pos_fast(xf, t2a, t2b, t2c, L.dcl[k], c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ix, iy);
                         int cellj = cell_of(ix, iy, W, H, fwj, fnj);
-                        if (k >= D || !xlive) cellj = NO_CELL;
-                        float q = zc + (fwj + fnj) * 0.0f;   // (no tap inside the image)
+                        if (k >= D || !xlive[s]) cellj = NO_CELL;
+                        float qv = zc[s] + (fwj + fnj) * 0.0f;   // (no tap inside the image)
                         if (cellj != NO_CELL) {
                             const int cxx = cell_x(cellj), cyy = cell_y(cellj);
                             const float ex = 1.0f - fwj, ey = 1.0f - fnj;
@@ -763,8 +760,8 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                                 const h8 a10 = *reinterpret_cast<const h8*>(ph + (size_t)Wp * 16), a11 = *reinterpret_cast<const h8*>(ph + (size_t)Wp * 16 + 16);
                                 const h8 l00 = *reinterpret_cast<const h8*>(pl), l01 = *reinterpret_cast<const h8*>(pl + 16);
                                 const h8 l10 = *reinterpret_cast<const h8*>(pl + (size_t)Wp * 16), l11 = *reinterpret_cast<const h8*>(pl + (size_t)Wp * 16 + 16);
-                                const h8 rh = *reinterpret_cast<const h8*>(&L.Bs[(((tail ? 2 * NCHK : (g >> 2)) * 4 + (tail ? 0 : (g & 3))) * 16 + n) * 8]);
-                                const h8 rl = *reinterpret_cast<const h8*>(&L.Bs[(((tail ? 2 * NCHK : NCHK + (g >> 2)) * 4 + (tail ? 2 : (g & 3))) * 16 + n) * 8]);
+                                const h8 rh = *reinterpret_cast<const h8*>(&L.Bs[s][(((tail ? 2 * NCHK : (g >> 2)) * 4 + (tail ? 0 : (g & 3))) * 16 + n) * 8]);
+                                const h8 rl = *reinterpret_cast<const h8*>(&L.Bs[s][(((tail ? 2 * NCHK : NCHK + (g >> 2)) * 4 + (tail ? 2 : (g & 3))) * 16 + n) * 8]);
 #pragma unroll
                                 for (int i = 0; i < 8; ++i) {
                                     float val = ((float)a00[i] + (float)l00[i]) * w00;
@@ -776,84 +773,81 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                                     part = __builtin_fmaf(diff, diff, part);
                                 }
                             }
-                            q = part + (fwj + fnj) * 0.0f;
+                            qv = part + (fwj + fnj) * 0.0f;
                         }
-                        if (ovf) q = __builtin_nanf("");
-                        const float cj = q * L.cst[7];
+                        if (ovf) qv = __builtin_nanf("");
+                        const float cj = qv * L.cst[7];
 #pragma unroll
-                        for (int jj = 0; jj < NC; ++jj) cost[jj] = cost[jj] + (jj == 4 * h + j ? cj : 0.0f);
+                        for (int jj = 0; jj < NC; ++jj) cost[s][jj] = cost[s][jj] + (jj == 4 * h + j ? cj : 0.0f);
                     }
                 }
             }
-#ifdef DIST_PREFETCH
-            // (the next block's pixel loads have long arrived: have them counted as arrived HERE, in front of this block's output
-            //  stores -- a wait placed behind the stores, at their first use in the next block, would wait for the stores as well)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(rayN[i]));
-#pragma unroll
-            for (int mm = 0; mm < MCH; ++mm) asm volatile("" : "+v"(rvN[mm]));
-#endif
             // ---- epilogue: cost store, log-softmax over D, expectation ----------------------------------------------------
             // (buffer stores: one 32-bit lane offset, the plane as the scalar offset: plane 64 h + 16 wave + 4 kq + j)
-            const int ovoff = xlive ? (4 * kq * HW + p) * 4 : OOB;
             float* const cost_out = da.a.cost_out;
             float* const logp_out = da.a.logp_out;
             float* const depth_out = da.a.depth_out;
             if (cost_out) {
                 const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(cost_out + (size_t)b * D * HW), 0, D * HW * 4, 0x00020000);
 #pragma unroll
-                for (int j = 0; j < NC; ++j)   // (planes beyond D lie beyond the descriptor: dropped)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cost[j]), rc, ovoff, (64 * (j >> 2) + 16 * wave + (j & 3)) * HW * 4, DIST_STORE_AUX);
+                for (int s = 0; s < NP; ++s) {
+                    const int ovoff = xlive[s] ? (4 * kq * HW + p[s]) * 4 : OOB;
+#pragma unroll
+                    for (int j = 0; j < NC; ++j)   // (planes beyond D lie beyond the descriptor: dropped)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cost[s][j]), rc, ovoff, (64 * (j >> 2) + 16 * wave + (j & 3)) * HW * 4, DIST_STORE_AUX);
+                }
             }
-#ifdef ABL_NO_EPILOGUE
-            { float t_ = 0.f; for (int j = 0; j < NC; ++j) t_ += cost[j]; if (t_ == 12345.678f && depth_out) depth_out[0] = t_; DIST_BARRIER(); }
-            if (false) {
-#else
             if (logp_out || depth_out) {
-#endif
                 // per wave: max, sum exp, sum d exp over its planes of pixel n; merged over the four waves through LDS
-                float mx = -INFINITY;
 #pragma unroll
-                for (int j = 0; j < NC; ++j)
-                    if (64 * (j >> 2) + 4 * tq + (j & 3) < D) mx = fmaxf(mx, cost[j]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16));
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                float ssum = 0.0f, esum = 0.0f;
-#pragma unroll
-                for (int j = 0; j < NC; ++j) {
-                    const int k = 64 * (j >> 2) + 4 * tq + (j & 3);
-                    const float ek = k < D ? dist_exp(cost[j] - mx) : 0.0f;
-                    ssum = ssum + ek;
-                    esum = __builtin_fmaf(L.dcl[k], ek, esum);
-                }
-                ssum = ssum + __shfl_xor(ssum, 16); ssum = ssum + __shfl_xor(ssum, 32);
-                esum = esum + __shfl_xor(esum, 16); esum = esum + __shfl_xor(esum, 32);
-                if (kq == 0) *reinterpret_cast<v4f*>(&L.red[(wave * 16 + n) * 4]) = v4f{mx, ssum, esum, 0.0f};
-                DSTAMP(10)   // cost stores, partial softmax
-                DIST_BARRIER();
-                float M = -INFINITY;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) M = fmaxf(M, L.red[(w * 16 + n) * 4]);
-                float S = 0.0f, E = 0.0f;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const v4f part = *reinterpret_cast<const v4f*>(&L.red[(w * 16 + n) * 4]);
-                    // (a wave whose planes all lie beyond D: max -inf, sums 0)
-                    const float scw = part.x == -INFINITY ? 0.0f : dist_exp(part.x - M);
-                    S = __builtin_fmaf(part.y, scw, S);
-                    E = __builtin_fmaf(part.z, scw, E);
-                }
-                const float ls = logf(S);
-                if (logp_out) {
-                    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(logp_out + (size_t)b * D * HW), 0, D * HW * 4, 0x00020000);
+                for (int s = 0; s < NP; ++s) {
+                    float mx = -INFINITY;
 #pragma unroll
                     for (int j = 0; j < NC; ++j)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (cost[j] - M) - ls), rl, ovoff,
-                                                              (64 * (j >> 2) + 16 * wave + (j & 3)) * HW * 4, DIST_STORE_AUX);
+                        if (64 * (j >> 2) + 4 * tq + (j & 3) < D) mx = fmaxf(mx, cost[s][j]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    float ssum = 0.0f, esum = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) {
+                        const int k = 64 * (j >> 2) + 4 * tq + (j & 3);
+                        const float ek = k < D ? dist_exp(cost[s][j] - mx) : 0.0f;
+                        ssum = ssum + ek;
+                        esum = __builtin_fmaf(L.dcl[k], ek, esum);
+                    }
+                    ssum = ssum + __shfl_xor(ssum, 16); ssum = ssum + __shfl_xor(ssum, 32);
+                    esum = esum + __shfl_xor(esum, 16); esum = esum + __shfl_xor(esum, 32);
+                    if (kq == 0) *reinterpret_cast<v4f*>(&L.red[s][(wave * 16 + n) * 4]) = v4f{mx, ssum, esum, 0.0f};
                 }
-                if (depth_out && xlive && tq == 0) depth_out[(size_t)b * HW + p] = E / S;
+                DSTAMP(10)   // cost stores, partial softmax
+                PDEPTH_LDS_BARRIER();
+#pragma unroll
+                for (int s = 0; s < NP; ++s) {
+                    float M = -INFINITY;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) M = fmaxf(M, L.red[s][(w * 16 + n) * 4]);
+                    float S_ = 0.0f, E = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const v4f part = *reinterpret_cast<const v4f*>(&L.red[s][(w * 16 + n) * 4]);
+                        // (a wave whose planes all lie beyond D: max -inf, sums 0)
+                        const float scw = part.x == -INFINITY ? 0.0f : dist_exp(part.x - M);
+                        S_ = __builtin_fmaf(part.y, scw, S_);
+                        E = __builtin_fmaf(part.z, scw, E);
+                    }
+                    const float ls = logf(S_);
+                    const int ovoff = xlive[s] ? (4 * kq * HW + p[s]) * 4 : OOB;
+                    if (logp_out) {
+                        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(logp_out + (size_t)b * D * HW), 0, D * HW * 4, 0x00020000);
+#pragma unroll
+                        for (int j = 0; j < NC; ++j)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (cost[s][j] - M) - ls), rl, ovoff,
+                                                                  (64 * (j >> 2) + 16 * wave + (j & 3)) * HW * 4, DIST_STORE_AUX);
+                    }
+                    if (depth_out && xlive[s] && tq == 0) depth_out[(size_t)b * HW + p[s]] = E / S_;
+                }
             } else {
-                DIST_BARRIER();   // (every wave is done with the block's operand image before the next block's centring)
+                PDEPTH_LDS_BARRIER();   // (every wave is done with the blocks' operand images before the next trip's centring)
             }
             DSTAMP(11)   // barrier + merge + stores
         }   // pixel blocks of the item
@@ -878,9 +872,10 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     }
 }
 
-template <int NCHK, int NH>
-hipError_t launch_inst(const SweepArgs& a, const char* packed, const float* stats, int* queue, int tiles_x, int tiles, hipStream_t stream) {
-    auto kern = sweep_dist_kernel<NCHK, NH>;
+template <int NCHK, int NH, int NP>
+hipError_t launch_np(const SweepArgs& a, const char* packed, const float* stats, int* queue, int tiles_x, int tiles, int spi, long long nblk_cap,
+                     hipStream_t stream) {
+    auto kern = sweep_dist_kernel<NCHK, NH, NP>;
     // persistent grid: as many workgroups as the chip holds at once (registers and LDS decide: asked once per
     // instantiation and device), a multiple of 8; fewer when there is less work
     static int per_cu[64] = {0};
@@ -894,12 +889,23 @@ hipError_t launch_inst(const SweepArgs& a, const char* packed, const float* stat
     long long nblk = ((long long)sweep_device_cus() * per_cu[dev] + 7) & ~7ll;
     DistArgs da;
     da.a = a; da.packed = packed; da.stats = stats; da.queue = queue; da.tiles_x = tiles_x; da.ntile = tiles;
-    // small problems: one pixel block per item, so that every CU gets work
-    da.spi = (long long)tiles * a.B < DIST_SPI1_BELOW * nblk ? 1 : 4;
+    da.spi = spi;
     const long long need = 8ll * ((tiles + 7) / 8) * (4 / da.spi) * a.B;   // a workgroup per item of the largest XCD band, times 8
     if (need <= DIST_ONE_EACH_X * nblk) nblk = need;
+    (void)nblk_cap;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, stream, da);
     return hipGetLastError();
+}
+
+template <int NCHK, int NH>
+hipError_t launch_inst(const SweepArgs& a, const char* packed, const float* stats, int* queue, int tiles_x, int tiles, hipStream_t stream) {
+    // small problems: one pixel block per item, so that every CU gets work; else whole tiles, two pixel blocks per pass (D <= 64)
+    const long long resident = 3ll * sweep_device_cus();
+    const int spi = (long long)tiles * a.B < DIST_SPI1_BELOW * resident ? 1 : 4;
+    if constexpr (NH == 1 && DIST_NP2 != 0) {
+        if (spi == 4) return launch_np<NCHK, NH, 2>(a, packed, stats, queue, tiles_x, tiles, spi, resident, stream);
+    }
+    return launch_np<NCHK, NH, 1>(a, packed, stats, queue, tiles_x, tiles, spi, resident, stream);
 }
 
 }  // namespace
