@@ -39,55 +39,7 @@
 #include "pick.hpp"
 #include "wave_util.hpp"
 
-#ifndef DIST_MAXB1
-#define DIST_MAXB1 22      // blocks of 16 texels a pass can take, D <= 64
-#endif
-#ifndef DIST_MAXB2
-#define DIST_MAXB2 32      // ... D > 64
-#endif
-#ifndef DIST_MAXB_NP2
-#define DIST_MAXB_NP2 26   // ... of a pass over two pixel blocks (D <= 64): 75 KB of LDS per workgroup, two per CU
-#endif
-#ifndef DIST_NP2
-#define DIST_NP2 0         // 1: whole tiles at D <= 64 run two pixel blocks per pass (built, parity-green, measured 25 % SLOWER: it
-#endif                     //    saves 4 % of the vector instructions and leaves two workgroups per CU instead of three)
-#ifndef DIST_OCC1
-#define DIST_OCC1 2        // workgroups per CU at D <= 64: 256 registers per lane, nothing spilled (4: 128 registers, 23 spilled: slower)
-#endif
-#ifndef DIST_OCC2
-#define DIST_OCC2 2
-#endif
-#ifndef DIST_XPRIO
-#define DIST_XPRIO 1
-#endif
-#ifndef DIST_STORE_AUX
-#define DIST_STORE_AUX 2   // nt: the outputs are written once and not read by this kernel
-#endif
-#ifndef DIST_SPI1_BELOW
-#define DIST_SPI1_BELOW 2  // single pixel blocks as queue items below this many tiles per workgroup
-#endif
-#ifndef DIST_ONE_EACH_X
-#define DIST_ONE_EACH_X 2  // no queue up to this many items per resident workgroup
-#endif
-#ifndef DIST_GUARD_RATIO
-#define DIST_GUARD_RATIO 6.0f   // spread energy / lagged spread beyond which an item is evaluated directly (guard below)
-#endif
-
-#ifdef ABL_NO_MFMA
-#define DIST_MFMA(a, b, c) ((c) + __builtin_bit_cast(wv::v4f, a) * 1e-30f + __builtin_bit_cast(wv::v4f, b) * 1e-30f)
-#elif defined(DIST_MFMA16)
-// two K = 16 instructions per K = 32 operand pair (the sum over the K slots is the same)
-typedef _Float16 pdepth_h4 __attribute__((ext_vector_type(4)));
-#define DIST_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_shufflevector(a, a, 4, 5, 6, 7), __builtin_shufflevector(b, b, 4, 5, 6, 7), \
-                               __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_shufflevector(a, a, 0, 1, 2, 3), __builtin_shufflevector(b, b, 0, 1, 2, 3), c, 0, 0, 0), 0, 0, 0)
-#else
-#define DIST_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
-#endif
-#ifdef ABL_NO_BARRIER
-#define DIST_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#else
-#define DIST_BARRIER() PDEPTH_LDS_BARRIER()
-#endif
+#include "sweep_dist_knobs.hpp"
 
 namespace pdepth {
 
@@ -107,23 +59,14 @@ struct DistArgs {
 };
 #define KARG(type, field) kernarg_at<type>(offsetof(DistArgs, field))
 
-// phase stamps (-DDIST_STAMPS): shader-clock cycles per phase, summed per wave, added into the queue ints 8..31 on the way out
-#ifdef DIST_STAMPS
-#define DSTAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += t_ - stamp_t; stamp_t = t_; }
-#else
-#define DSTAMP(i)
-#endif
 
 // exp(x) for x <= 0 (softmax terms): the hardware 2^t on the rounded product t = x log2(e).  The product's rounding error
 // (2^-24 |t|) is a relative error |t| ln2 2^-24 of the result: 4e-7 for the terms within a factor 1000 of the largest one,
 // which are the ones that carry a depth map or a normaliser; geometry.hpp's exp_nonpos (12 instructions) keeps 1.5 ulp
 // for every term (DIST_EXACT_EXP restores it).
 __device__ __forceinline__ float dist_exp(float x) {
-#ifdef DIST_EXACT_EXP
-    return exp_nonpos(x);
-#else
+    if (DIST_EXACT_EXP) return exp_nonpos(x);
     return __builtin_amdgcn_exp2f(fmaxf(x, -1000.0f) * 1.44269502162933349609375f);
-#endif
 }
 
 template <int MAXB, int NAC, int NP>
@@ -290,10 +233,15 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 }
                 const int e = dist::scale_exponent(am);
                 const float sc = ldexpf(1.0f, e);
-                // Guard.  The rounding error of Y = N - 2X + |r'|^2 grows with the energy of the centred features, the cost with
-                // their spread at the distance of a sweep: where the first exceeds the second by more than DIST_GUARD_RATIO
-                // (strong trends across the image that a constant per channel cannot remove) the item is evaluated directly.
-                const bool outside = sv > DIST_GUARD_RATIO * sl_ && sl_ >= 0.0f;
+                // Guard.  The rounding error of Y = N - 2 X + |r'|^2 is 2^-23 of the ENERGY of the centred features (sum_c var_c,
+                // trends across the image included: a constant per channel does not remove them), that of the reference's own
+                // form 2^-23 of the cost, i.e. of their spread at the distance of a sweep (sum_c lag_c).  Measured on features
+                // with trends (tools/dbg/dist_guard.py, depth against the CPU oracle): ratio 1.34 -> 3.6e-5 m, ratio 2.1 ..
+                // 2.4 -> 1.0e-4 .. 1.4e-4 m, where the reference's form keeps 3e-5.  An item is evaluated directly where the
+                // ratio exceeds DIST_GUARD_RATIO AND the energy is large enough against sigma for the difference to show
+                // (unit-variance features: 67; features whose energy is all spread gain nothing from the direct form).
+                const float sg_ = KARG(float, a.sigma);
+                const bool outside = sv > DIST_GUARD_RATIO * sl_ && sv * 10.0f > DIST_GUARD_ENERGY * fabsf(sg_);
                 if (lane == 0) {
                     const float sg = KARG(float, a.sigma);
                     L.cst[6] = sc; L.cst[7] = ldexpf(refined_rcp(sg), -2 * e);
@@ -541,12 +489,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                             }
                         }
                         if (L.iflag != 0) fits = false;   // (the item is evaluated directly)
-#ifdef DIST_FORCE_DIRECT   // test build: every pass takes the direct evaluation (DIST_FORCE_DIRECT_VIEW: those of that view)
-#ifdef DIST_FORCE_DIRECT_VIEW
-                        if (v == DIST_FORCE_DIRECT_VIEW)
-#endif
-                        fits = false;
-#endif
+                        if (DIST_FORCE_DIRECT == -1 || DIST_FORCE_DIRECT == v) fits = false;   // (test builds)
                         ++pt;
                         if (NP == 2 && !fits && mask == 3 && L.iflag == 0) {
                             // the common window of the two blocks is too large: the blocks one after the other (every wave has read the

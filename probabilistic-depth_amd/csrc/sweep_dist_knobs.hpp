@@ -1,0 +1,62 @@
+// Build-time knobs of sweep_dist.hip (tools/variants_dist.sh sets them with -D for A/B builds; the defaults are the product).
+#pragma once
+
+#ifndef DIST_MAXB1
+#define DIST_MAXB1 22      // blocks of 16 texels a pass can take, D <= 64
+#endif
+#ifndef DIST_MAXB2
+#define DIST_MAXB2 32      // ... D > 64
+#endif
+#ifndef DIST_MAXB_NP2
+#define DIST_MAXB_NP2 26   // ... of a pass over two pixel blocks (D <= 64): 75 KB of LDS per workgroup, two per CU
+#endif
+#ifndef DIST_NP2
+#define DIST_NP2 0         // 1: whole tiles at D <= 64 run two pixel blocks per pass (built, parity-green, measured 25 % SLOWER: it
+#endif                     //    saves 4 % of the vector instructions and leaves two workgroups per CU instead of three)
+#ifndef DIST_OCC1
+#define DIST_OCC1 2        // minimum waves per SIMD asked of the compiler at D <= 64: 164 registers, nothing spilled, three
+#endif                     //    workgroups per CU (4: 128 registers, 23 of them spilled: slower)
+#ifndef DIST_OCC2
+#define DIST_OCC2 2
+#endif
+#ifndef DIST_XPRIO
+#define DIST_XPRIO 1       // wave priority in the matrix phase
+#endif
+#ifndef DIST_STORE_AUX
+#define DIST_STORE_AUX 2   // nt: the outputs are written once and not read by this kernel (0, 1, 3: no difference measured)
+#endif
+#ifndef DIST_SPI1_BELOW
+#define DIST_SPI1_BELOW 2  // single pixel blocks as queue items below this many tiles per workgroup
+#endif
+#ifndef DIST_ONE_EACH_X
+#define DIST_ONE_EACH_X 2  // no queue up to this many items per resident workgroup
+#endif
+#ifndef DIST_GUARD_RATIO
+#define DIST_GUARD_RATIO 1.7f   // the guard: energy of the centred features / their spread at a lag of 16 texels, and ...
+#endif
+#ifndef DIST_GUARD_ENERGY
+#define DIST_GUARD_ENERGY 110.0f   // ... energy x 10 / sigma beyond which an item is evaluated directly (sweep_dist.hip)
+#endif
+#ifndef DIST_EXACT_EXP
+#define DIST_EXACT_EXP 0   // 1: geometry.hpp's exp_nonpos (1.5 ulp, 12 instructions) instead of the hardware 2^x on the rounded product
+#endif
+#ifndef DIST_FORCE_DIRECT
+#define DIST_FORCE_DIRECT -2   // test builds: -1 = every pass takes the direct evaluation, v >= 0 = the passes of view v
+#endif
+
+// The matrix instruction.  DIST_MFMA16: two K = 16 instructions (v_mfma_f32_16x16x16_f16) per K = 32 operand pair -- the probe
+// that showed the packed-fp32 erratum (wave_util.hpp) to need v_mfma_f32_16x16x32_f16 in the other waves.
+#ifdef DIST_MFMA16
+#define DIST_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_shufflevector(a, a, 4, 5, 6, 7), __builtin_shufflevector(b, b, 4, 5, 6, 7), \
+                               __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_shufflevector(a, a, 0, 1, 2, 3), __builtin_shufflevector(b, b, 0, 1, 2, 3), c, 0, 0, 0), 0, 0, 0)
+#else
+#define DIST_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#endif
+
+// phase stamps (-DDIST_STAMPS): shader-clock cycles per phase, summed per wave, added into the queue ints 8..31 on the way out
+// (every stamp is a scalar memory read and a wait for it: the phases stretch, their proportions are indicative only)
+#ifdef DIST_STAMPS
+#define DSTAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += t_ - stamp_t; stamp_t = t_; }
+#else
+#define DSTAMP(i)
+#endif

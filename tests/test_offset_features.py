@@ -1,4 +1,4 @@
-"""GPU suite: features that are NOT zero-mean.
+"""GPU suite: features that are NOT zero-mean, and features with trends.
 
 The L2 cost sum_c (sum_t w_t s_t - r)^2 (warping/homography.py:80-82,129) does not change when the same constant is added
 to every reference and source value of a channel -- wherever the four taps lie inside the image.  The correlation form
@@ -40,9 +40,9 @@ def _offset_batch(kind, pose, B=2, C=67, D=64, H=64, W=128, V=1, seed=9):
     elif kind == "relu":
         b["ref"] = torch.clamp(b["ref"] + 1.5, min=0.0)
         b["src"] = torch.clamp(b["src"] + 1.5, min=0.0)
-    elif kind == "ramp":
+    elif kind.startswith("ramp"):   # 'ramp' = +-1 sigma, 'ramp2' / 'ramp4' = +-2 / +-4 sigma
         mu = (torch.rand(C, generator=g) * 2 - 1) * 4.0
-        ramp = torch.linspace(-1.0, 1.0, H)[None, None, :, None]
+        ramp = torch.linspace(-1.0, 1.0, H)[None, None, :, None] * float(kind[4:] or 1)
         b["ref"] = b["ref"] + mu[None, :, None, None] + ramp
         b["src"] = b["src"] + mu[None, None, :, None, None] + ramp[:, None]
     else:
@@ -67,11 +67,34 @@ def test_offset_features_against_the_oracle(dev, kind, pose):
     """64x128, C=67, D=64: every implementation ALGO_AUTO can run, on features with per-channel means of up to 8 standard
     deviations."""
     b = _offset_batch(kind, pose)
-    for algo in ("auto", "corr", "tiled1", "tiled2", "direct"):
+    for algo in ("auto", "dist", "corr", "tiled1", "tiled2", "direct"):
         _check(b, dev, algo)
         # the tiled kernel only gets there because the pre-pass switches its correlation-form plane group off
         if kind == "uniform8" and algo.startswith("tiled"):
             assert _native.noncentred_guard(2, 64, 128) is True
+
+
+@pytest.mark.parametrize("pose", ["mono", "stereo"])
+@pytest.mark.parametrize("kind", ["ramp2", "ramp4"])
+def test_trends_are_evaluated_in_the_reference_form(dev, kind, pose):
+    """A vertical ramp of +-2 and +-4 standard deviations under the offsets: what a constant per channel cannot remove.  The
+    rounding error of every fast form grows with the energy that is left (round 4's default lost the 1e-4 m at +-2); the
+    reference's own form (warping/homography.py:80-82,129) does not.  ALGO_AUTO decides per batch item ON THE DEVICE from the
+    statistics of the pre-pass (csrc/sweep_dist.hip, the guard): such items take the direct evaluation inside the same launch --
+    the diagnostics counter says so -- and meet the north-star bound like `direct` itself; an item of plain N(0,1) features in
+    the same batch keeps the fast path."""
+    b = _offset_batch(kind, pose)
+    for algo in ("auto", "dist", "direct"):
+        _check(b, dev, algo)
+        if algo != "direct":
+            assert _native.fallback_tiles(2, 64, 128) >= 2 * 64 * 128 // 16, "every pixel block of both items was meant to go direct"
+    # a batch of one item with the trend and one without: the decision is per item
+    plain = synth.make_batch(9, 2, C=67, D=64, H=64, W=128, V=1, pose=pose)
+    mixed = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    for k in ("ref", "src"):
+        mixed[k][1] = plain[k][1]
+    _check(mixed, dev, "auto")
+    assert 64 * 128 // 16 <= _native.fallback_tiles(2, 64, 128) < 2 * 64 * 128 // 16
 
 
 def test_offset_features_border_cells_and_views(dev):
@@ -109,17 +132,17 @@ def test_packed_source_is_tied_to_the_kernel_family(dev):
     b = _offset_batch("uniform8", "mono", B=1)
     d = to_dev(b, dev)
     args = (d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0)
-    centred = ops.pack_source(d["src"], 64)                      # auto, L2
+    centred = ops.pack_source(d["src"], 64)                      # auto, L2: the distance-form kernel's fp16 planes
     plain = ops.pack_source(d["src"], 64, algo="tiled1")
-    assert centred.centred and not plain.centred
-    with pytest.raises(RuntimeError, match="another kernel family"):
-        ops.sweep_dpv(d["ref"], centred, *args, algo="tiled1")
-    with pytest.raises(RuntimeError, match="another kernel family"):
-        ops.sweep_dpv(d["ref"], plain, *args, algo="auto")
-    with pytest.raises(RuntimeError, match="another kernel family"):
-        ops.sweep_dpv(d["ref"], centred, *args, feat_dist="L1")
+    corr = ops.pack_source(d["src"], 64, algo="corr")            # centred float4 planes
+    assert centred.centred and corr.centred and not plain.centred
+    assert (centred.layout, corr.layout, plain.layout) == (_native.LAYOUT_DIST16, _native.LAYOUT_C4_CENTRED, _native.LAYOUT_C4)
+    for ps, kw in ((centred, dict(algo="tiled1")), (plain, dict(algo="auto")), (centred, dict(feat_dist="L1")), (corr, dict(algo="auto")),
+                   (centred, dict(algo="corr"))):
+        with pytest.raises(RuntimeError, match="another kernel family"):
+            ops.sweep_dpv(d["ref"], ps, *args, **kw)
     first = {}
-    for ps, algo in ((centred, "auto"), (plain, "tiled1")):
+    for ps, algo in ((centred, "auto"), (plain, "tiled1"), (corr, "corr")):
         cp, lp, dp = ops.sweep_dpv(d["ref"], ps, *args, algo=algo, want_cost=True)
         ca, la, da = ops.sweep_dpv(d["ref"], d["src"], *args, algo=algo, want_cost=True)
         assert torch.equal(cp, ca) and torch.equal(lp, la) and torch.equal(dp, da), algo
@@ -134,7 +157,7 @@ def test_passes_that_do_not_fit_are_evaluated_directly(dev):
     """A wide-baseline pose: epipolar segments of hundreds of texels, more blocks of X than the kernel's LDS holds -- those
     passes take the direct evaluation inside the same launch (no tile flags, no second kernel) and meet the same bounds;
     the diagnostics counter says that it happened."""
-    total = 0
+    total = {"auto": 0, "corr": 0}
     for seed, (H, W, D, V) in enumerate(((96, 200, 64, 1), (120, 260, 128, 2))):
         b = synth.make_batch(900 + seed, 1, C=35, D=D, H=H, W=W, V=V, pose="wide")
         g = torch.Generator().manual_seed(seed)
@@ -143,41 +166,23 @@ def test_passes_that_do_not_fit_are_evaluated_directly(dev):
         b["src"] = b["src"] + mu[None, None, :, None, None]
         ocost, ologp, odepth = oracle_batch(b)
         d = to_dev(b, dev)
-        cost, logp, depth = ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0,
-                                          algo="corr", want_cost=True)
-        total += _native.fallback_tiles(1, H, W)
-        fin = torch.isfinite(ocost)
-        assert torch.equal(torch.isfinite(cost.cpu()), fin)
-        np.testing.assert_allclose(cost.cpu()[fin].numpy(), ocost[fin].numpy(), rtol=COST_RTOL, atol=COST_ATOL)
-        dfin = torch.isfinite(odepth)
-        assert (depth.cpu()[dfin] - odepth[dfin]).abs().max().item() <= DEPTH_ATOL
-        # cost only (no softmax epilogue between consecutive pixel blocks)
-        c2 = ops.sweep_cost(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0, algo="corr")
-        assert torch.equal(c2.nan_to_num(nan=-7.0), cost.nan_to_num(nan=-7.0))
-    assert total > 0, "these poses are meant to exceed the row tables"
-
-
-def test_pack_inside_the_sweep_kernel_gives_the_same_bits(dev, monkeypatch):
-    """PDEPTH_CORR_FUSE_PACK=1: the NCHW entry runs the channel statistics and ONE sweep kernel that packs batch item b + 1
-    while it sweeps item b (csrc/sweep_corr.hip; off by default: measured slower).  Same arithmetic
-    (csrc/pack_body.hpp), so the same bits as the pack kernel in front -- call after call on one workspace with new data
-    (a stale line of the previous call's packed source in some XCD's L2 would show), several views, ragged sizes."""
-    for seed, (B, H, W, V, D) in enumerate(((3, 64, 128, 2, 64), (2, 37, 83, 1, 48), (4, 64, 128, 1, 100))):
-        for rep in range(3):
-            b = _offset_batch("uniform8", "mono", B=B, H=H, W=W, V=V, D=D, seed=40 + 7 * seed + rep)
-            d = to_dev(b, dev)
-            args = (d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0)
-            monkeypatch.delenv("PDEPTH_CORR_FUSE_PACK", raising=False)
-            want = ops.sweep_dpv(*args, algo="corr", want_cost=True)
-            monkeypatch.setenv("PDEPTH_CORR_FUSE_PACK", "1")
-            got = ops.sweep_dpv(*args, algo="corr", want_cost=True)
-            for g, w_ in zip(got, want):
-                assert torch.equal(g.nan_to_num(nan=-7.0), w_.nan_to_num(nan=-7.0)), (B, H, W, V, rep)
-    monkeypatch.delenv("PDEPTH_CORR_FUSE_PACK", raising=False)
+        for algo in ("auto", "corr"):
+            cost, logp, depth = ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0,
+                                              algo=algo, want_cost=True)
+            total[algo] += _native.fallback_tiles(1, H, W)
+            fin = torch.isfinite(ocost)
+            assert torch.equal(torch.isfinite(cost.cpu()), fin)
+            np.testing.assert_allclose(cost.cpu()[fin].numpy(), ocost[fin].numpy(), rtol=COST_RTOL, atol=COST_ATOL)
+            dfin = torch.isfinite(odepth)
+            assert (depth.cpu()[dfin] - odepth[dfin]).abs().max().item() <= DEPTH_ATOL
+            # cost only (no softmax epilogue between consecutive pixel blocks)
+            c2 = ops.sweep_cost(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0, algo=algo)
+            assert torch.equal(c2.nan_to_num(nan=-7.0), cost.nan_to_num(nan=-7.0))
+    assert min(total.values()) > 0, f"these poses are meant to exceed the row tables: {total}"
 
 
 def test_extremes_of_the_default_kernel(dev):
-    """The corners of the shape range sweep_corr_supports() admits -- one channel, one plane, images smaller than a tile, the
+    """The corners of the shape range sweep_dist_supports() / sweep_corr_supports() admit -- one channel, one plane, images smaller than a tile, the
     widest features (C = 72: 18 packed planes), D = 65 (a second plane group with one plane in it), 8 source views, more than
     64 batch items (the per-item block-shape table holds 64) -- against the oracle, with offset features; and just beyond
     them (9 views, C = 73, D = 129) `auto` still answers (the LDS-tiled kernel) while the forced selector says no."""
@@ -191,15 +196,16 @@ def test_extremes_of_the_default_kernel(dev):
         b["src"] = b["src"] + mu[None, None, :, None, None]
         ocost, ologp, odepth = oracle_batch(b)
         d = to_dev(b, dev)
-        for algo in ("corr", "auto"):
+        for algo in ("auto", "dist", "corr"):
             cost, logp, depth = ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0,
                                               algo=algo, want_cost=True)
             fin = torch.isfinite(ocost)
             assert torch.equal(torch.isfinite(cost.cpu()), fin), (algo, c)
-            np.testing.assert_allclose(cost.cpu()[fin].numpy(), ocost[fin].numpy(), rtol=COST_RTOL, atol=COST_ATOL * c["V"], err_msg=f"{algo} {c}")
+            # (the north-star bounds as they stand, whatever the number of views: no scaling with V)
+            np.testing.assert_allclose(cost.cpu()[fin].numpy(), ocost[fin].numpy(), rtol=COST_RTOL, atol=COST_ATOL, err_msg=f"{algo} {c}")
             dfin = torch.isfinite(odepth)
             if bool(dfin.any()):
-                assert (depth.cpu()[dfin] - odepth[dfin]).abs().max().item() <= DEPTH_ATOL * max(1.0, c["V"] / 2), (algo, c)
+                assert (depth.cpu()[dfin] - odepth[dfin]).abs().max().item() <= DEPTH_ATOL, (algo, c)
     for c in (dict(C=8, D=16, V=9), dict(C=73, D=16, V=1), dict(C=8, D=129, V=1)):
         b = synth.make_batch(400, 1, C=c["C"], D=c["D"], H=12, W=20, V=c["V"], pose="mono")
         ocost, ologp, odepth = oracle_batch(b)
@@ -207,6 +213,7 @@ def test_extremes_of_the_default_kernel(dev):
         args = (d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0)
         cost = ops.sweep_dpv(*args, algo="auto", want_cost=True)[0]
         fin = torch.isfinite(ocost)
-        np.testing.assert_allclose(cost.cpu()[fin].numpy(), ocost[fin].numpy(), rtol=COST_RTOL, atol=COST_ATOL * c["V"], err_msg=str(c))
-        with pytest.raises(RuntimeError):
-            ops.sweep_dpv(*args, algo="corr")
+        np.testing.assert_allclose(cost.cpu()[fin].numpy(), ocost[fin].numpy(), rtol=COST_RTOL, atol=COST_ATOL, err_msg=str(c))
+        for algo in ("corr", "dist"):
+            with pytest.raises(RuntimeError):
+                ops.sweep_dpv(*args, algo=algo)
