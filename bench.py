@@ -9,7 +9,9 @@ over one batch of synthetic inputs already resident in HBM.  Workload = BASELINE
 volumes per GPU, V=1, C=67, D=64, sweep resolution 256x512.  With N GPUs every rank owns its own B=4 batch (weak
 scaling, no data-path collective); per-rank metrics are all-gathered once at the end (RCCL).  Prints ONE JSON line on
 rank 0.  Next to the headline it reports the same step through the packed-source entry
-(pdepth_sweep_dpv_packed_f32: features already in the kernels' staging layout) as `packed_entry`.
+(pdepth_sweep_dpv_packed_f32: features already in the kernels' staging layout) as `packed_entry`, and SURVEY 8(d)'s
+secondary figures: `model_real` (the shape the reference's model sweeps a 256x512 frame at, 64x128, B = 1 and 4, both entries)
+and `peaked` (the headline workload on the correlated feature variant).
 """
 import argparse
 import json
@@ -90,11 +92,12 @@ def main():
     ap.add_argument("--planes", type=int, default=64)
     ap.add_argument("--views", type=int, default=1)
     ap.add_argument("--pose", default="mono", choices=["mono", "stereo"])
-    ap.add_argument("--algo", default="auto", choices=["auto", "direct", "corr", "tiled1", "tiled2", "cells", "mfma"],
+    ap.add_argument("--algo", default="auto", choices=["auto", "direct", "dist", "corr", "tiled1", "tiled2", "cells", "mfma"],
                     help="cells / mfma: lab builds of the library only (make LAB=1)")
     ap.add_argument("--peaked", action="store_true", help="SURVEY 8(d)'s correlated feature variant (src = 0.7 shift(ref) + 0.3 noise: a peaked DPV)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-start measurement in front of the headline")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the model_real / peaked measurements in front of the headline")
     ap.add_argument("--config", default=None, help="an experiment file in the reference's JSON schema (configs/*.json): "
                     "planes, depth range, sigma, channels and the pose family come from it; the sweep resolution stays "
                     "--height x --width (BASELINE quotes the metric at 256x512)")
@@ -172,8 +175,56 @@ def main():
                                      algo="direct", want_cost=False, want_logp=False, want_depth=True)[2]
     except RuntimeError:
         pass
+    # SURVEY 8(d), "Ambiguity resolved": the 64x128 model-real number is always reported next to the 256x512 one, and both the
+    # N(0,1) and the peaked feature variants.  GPU time per call from HIP events over 50 back-to-back calls (the launch gaps of
+    # the call are inside); launches per call: NCHW entry = statistics + pack + sweep, packed entry = the sweep.
+    secondary = {}
+    if not a.no_secondary and a.algo in ("auto", "dist", "corr") and rank == 0 and not a.config:
+        def small(Bs, entry):
+            bs = synth.make_batch(2, Bs, C=cfg["C"], D=cfg["D"], H=64, W=128, V=cfg["V"], pose=a.pose)
+            ds = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in bs.items()}
+            src = ops.pack_source(ds["src"], cfg["D"], a.algo) if entry == "packed" else ds["src"]
+            f = lambda: ops.sweep_dpv(ds["ref"], src, ds["K"], ds["R"], ds["t"], ds["rays"], ds["cxcy"], dc, sigma, algo=a.algo)
+            for _ in range(10):
+                f()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(50):
+                f()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            us = e0.elapsed_time(e1) / 50 * 1e3
+            by = algorithmic_bytes_per_volume(cfg["C"], cfg["V"], cfg["D"], 64, 128) * Bs
+            return {"us_per_call": us, "wall_us_per_call": (time.perf_counter() - t0) / 50 * 1e6, "launches": 1 if entry == "packed" else 3,
+                    "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "volumes_per_s": Bs / (us * 1e-6)}
+        try:
+            secondary["model_real"] = {"shape": "C=%d D=%d 64x128 V=%d pose=%s (the reference sweeps a 256x512 frame at 1/4 resolution: "
+                                                "models/models.py:518)" % (cfg["C"], cfg["D"], cfg["V"], a.pose),
+                                       "B1_nchw": small(1, "nchw"), "B1_packed": small(1, "packed"),
+                                       "B4_nchw": small(4, "nchw"), "B4_packed": small(4, "packed")}
+            if not a.peaked:
+                bp = synth.make_batch(2, hi - lo, first_item=lo, **dict(cfg, peaked=True))
+                dp = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in bp.items()}
+                fp = lambda: ops.sweep_dpv(dp["ref"], dp["src"], dp["K"], dp["R"], dp["t"], dp["rays"], dp["cxcy"], dc, sigma, algo=a.algo)
+                for _ in range(a.warmup):
+                    fp()
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.steps):
+                    fp()
+                e1.record()
+                torch.cuda.synchronize(dev)
+                ms = e0.elapsed_time(e1) / a.steps
+                secondary["peaked"] = {"ms_per_step": ms, "value": (hi - lo) / (ms * 1e-3),
+                                       "what": "the headline call on SURVEY 8(d)'s correlated features (src = 0.7 shift(ref) + 0.3 noise)"}
+                del bp, dp
+        except RuntimeError as e:
+            secondary["error"] = str(e)
     packed_entry, out_p, kern_p = None, None, None
-    if a.algo in ("auto", "corr"):   # secondary: the same step on features already in the kernels' staging layout
+    if a.algo in ("auto", "dist", "corr"):   # secondary: the same step on features already in the kernels' staging layout
         try:
             ps = ops.pack_source(d["src"], cfg["D"], a.algo)
             out_p, _, kern_p = timed(ps)
@@ -189,11 +240,8 @@ def main():
                            dtype=torch.float32, device=dev)
     allm = pdist.gather_metrics(metrics).cpu()
     fallback = pdepth_amd._native.fallback_tiles(hi - lo, cfg["H"], cfg["W"], gather_flag=2 if a.algo == "cells" else 1)
-    # which sweep kernel ran: the selector, or -- ALGO_AUTO on this shape class -- the device-side choice of the pre-pass
-    tiled_class = cfg["V"] == 1 and cfg["D"] <= 64 and cfg["H"] * cfg["W"] >= 96 * 1024
-    impl = a.algo if a.algo != "auto" else ("corr" if cfg["C"] <= 72 and cfg["D"] <= 128 else "tiled")
-    if os.environ.get("PDEPTH_SWEEP_IMPL") and a.algo == "auto":
-        impl = os.environ["PDEPTH_SWEEP_IMPL"]
+    # which sweep kernel ran: the selector, or -- ALGO_AUTO -- the family the library picks for this descriptor
+    impl = a.algo if a.algo != "auto" else pdepth_amd._native.selected_kernel(hi - lo, cfg["V"], cfg["C"], cfg["D"], cfg["H"], cfg["W"])
 
     if out_p is not None:
         packed_entry = {"kernel_ms": kern_p, "max_abs_depth_diff_vs_headline": float((out_p[2] - depth).abs().max())}
@@ -216,7 +264,8 @@ def main():
                         prof = rec
             except Exception:
                 prof = {}
-        kname = {"corr": "sweep_corr_kernel (correlation form on mean-centred features, matrix pipe)",
+        kname = {"dist": "sweep_dist_kernel (distance form sum w |s - r|^2 - Q, fp16 high / low parts on the matrix pipe)",
+                 "corr": "sweep_corr_kernel (correlation form on mean-centred features, matrix pipe)",
                  "mfma": "sweep_mfma_kernel (matrix-pipe kernel)", "tiled": "sweep_tiled_kernel (LDS-tiled band kernel)",
                  "tiled1": "sweep_tiled_kernel, one tile per block", "tiled2": "sweep_tiled_kernel, two tiles per block",
                  "cells": "sweep_cells_fast_kernel + sweep_cells_kernel", "direct": "sweep_direct_kernel (gather)"}.get(impl, str(impl))
@@ -225,7 +274,9 @@ def main():
                 #  with the commit and box it was collected on)
                 "traffic_source": prof.get("source"),
                 "traffic_collected": prof.get("collected"),
-                "kernel": ("fused sweep+DPV call = feature_stats_kernel + pack_c4_kernel (pre-pass: channel means, centred re-layout) + " + kname
+                "kernel": ("fused sweep+DPV call = feature_stats_kernel + pack_dist_kernel (pre-pass: channel statistics, centred fp16 re-layout "
+                           "+ neighbour differences) + " + kname if impl == "dist" else
+                           "fused sweep+DPV call = feature_stats_kernel + pack_c4_kernel (pre-pass: channel means, centred re-layout) + " + kname
                            if impl == "corr" else
                            "fused sweep+DPV call = feature_stats_kernel + pack_c4_kernel (source re-layout pre-pass) + " + kname +
                            " + the gather kernel on flagged tiles"),
@@ -240,7 +291,12 @@ def main():
             roof["valu_frac"] = prof["valu_wave_instr_per_launch"] / (kern_ms * 1e-3) / VALU_ISSUE_PEAK
             roof["valu_wave_instr_per_launch"] = prof["valu_wave_instr_per_launch"]
         extras = {"roofline": roof, "gather_fallback_tiles": fallback,
-                  "preheat_ms": preheat_ms, "preheat": "cold_start + preflight + packed_entry (see those objects) ran before the headline's warm-up"}
+                  "preheat_ms": preheat_ms, "preheat": "cold_start + preflight + model_real + peaked + packed_entry (see those objects) ran before the headline's warm-up"}
+        for k in ("model_real", "peaked"):
+            if k in secondary:
+                extras[k] = secondary[k]
+        if "error" in secondary:
+            extras["secondary_error"] = secondary["error"]
         if cold is not None:
             cold["value"] = (hi - lo) * world / (cold["ms_per_step"] * 1e-3)
             extras["cold_start"] = cold

@@ -208,6 +208,13 @@ def _blas(blas_mode):
     return host_blas_mode() if blas_mode is None else int(blas_mode)
 
 
+def selected_kernel(B, V, C, D, H, W, metric=METRIC_L2, algo=ALGO_AUTO):
+    """Name of the sweep kernel family a descriptor selects ('dist' | 'corr' | 'tiled' | 'direct'): pdepth_sweep_source_layout."""
+    lib = load()
+    desc = SweepDesc(B, V, C, D, H, W, int(metric), int(algo), BLAS_FMA, 1.0, C * H * W, V * C * H * W, C * H * W)
+    return {LAYOUT_DIST16: "dist", LAYOUT_C4_CENTRED: "corr", LAYOUT_C4: "tiled"}.get(lib.pdepth_sweep_source_layout(ctypes.byref(desc)), "direct")
+
+
 class PackedSource:
     """Source views [B,V,C,H,W] in the sweep kernels' staging layout (pdepth_pack_source_f32): a workspace to hand to
     sweep() in place of src, for callers that sweep the same source features more than once or write them once per

@@ -54,6 +54,24 @@ constexpr int LAYOUT_SLOT = 56;
 constexpr int LAYOUT_C4 = 1, LAYOUT_C4_CENTRED = 2, LAYOUT_DIST16 = 3;   // (0: nothing packed yet)
 constexpr int DIST_DONE_SLOT = 57, DIST_DIRECT_SLOT = 58, DIST_DIRECT_LAST_SLOT = 59;   // sweep_dist.hip: as the CORR_ slots
 constexpr int PICK_SKIP_IF_SET = 1, PICK_RUN_IF_SET = 2;
+
+// First statement of a sweep kernel on a packed source: does the workspace hold the layout this kernel reads?  If not (a C
+// caller swept a workspace packed for another kernel family: include/pdepth.h, pdepth_sweep_source_layout) every output of
+// the call is filled with NaN by the whole grid and the kernel leaves: loud numbers instead of costs computed from the
+// wrong bytes.  (The packing entry points write the tag; the Python binding refuses the mismatch before it gets here.)
+__device__ __forceinline__ bool poison_on_foreign_layout(const SweepArgs& a, const int* __restrict__ queue, int expected) {
+    if (queue[LAYOUT_SLOT] == expected) return false;
+    const float nan = __builtin_nanf("");
+    const size_t hw = (size_t)a.H * a.W, nvol = (size_t)a.B * a.D * hw, nmap = (size_t)a.B * hw;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = i0; i < nvol; i += step) {
+        if (a.cost_out) a.cost_out[i] = nan;
+        if (a.logp_out) a.logp_out[i] = nan;
+    }
+    if (a.depth_out)
+        for (size_t i = i0; i < nmap; i += step) a.depth_out[i] = nan;
+    return true;
+}
 constexpr int PH_PRE = 1, PH_KERNEL = 2, PH_GATHER = 4, PH_ALL = 7;   // phases of a sweep launcher: pre-pass / flag clear, kernel, gather
 
 // sweep_direct.hip

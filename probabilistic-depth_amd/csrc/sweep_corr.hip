@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256, NH == 1 ? CORR_OCC1 : CORR_OCC2) void sweep_co
     constexpr int XSTRIDE = Lds::XSTRIDE;
     static_assert(MAXB * 16 + 16 <= (1 << SL_BITS), "slot bits");
     __shared__ Lds L;
+    if (poison_on_foreign_layout(ca.a, ca.queue, LAYOUT_C4_CENTRED)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = KARG(int, a.D), H = KARG(int, a.H), W = KARG(int, a.W), V = KARG(int, a.V), C = KARG(int, a.C);
@@ -992,7 +993,11 @@ hipError_t launch_sweep_corr(const SweepArgs& a, void* workspace, hipStream_t st
         const long long items = (long long)a.V * ((a.H * a.W + 255) / 256);
         // (measured slower than the pack kernel in front -- profiles/r04_ab/fuse_pack_*.txt, DESIGN.md section 3 -- and so
         //  only on request: PDEPTH_CORR_FUSE_PACK=1)
+#ifdef PDEPTH_LAB
         const char* fuse = getenv("PDEPTH_CORR_FUSE_PACK");
+#else
+        const char* fuse = nullptr;   // (the product library has no environment switches)
+#endif
         if (fuse && fuse[0] == '1' && sweep_ws_holds_pack_counters(a.B, a.H, a.W) && items < (1ll << 30)) {
             hipError_t e = launch_stats_only(a, workspace, stream);
             if (e != hipSuccess) return e;

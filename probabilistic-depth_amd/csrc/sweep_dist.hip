@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     typedef DistLds<MAXB, NAC, NP> Lds;
     constexpr int XSTRIDE = Lds::XSTRIDE;
     __shared__ Lds L;
+    if (poison_on_foreign_layout(da.a, da.queue, LAYOUT_DIST16)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = KARG(int, a.D), H = KARG(int, a.H), W = KARG(int, a.W), V = KARG(int, a.V), C = KARG(int, a.C);

@@ -184,6 +184,7 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
                                                               int* __restrict__ tile_flags, int* __restrict__ queue,
                                                               int tiles_x, int ntile) {
     if (PDEPTH_COLD_ARG(int, pick) == PICK_SKIP_IF_SET && queue[PICK_SLOT] != 0) return;   // (the pre-pass chose the other kernel: pick.hpp)
+    if (poison_on_foreign_layout(a, queue, LAYOUT_C4)) return;
     const int aD = SPEC ? 64 : a.D, aC = SPEC ? 67 : a.C, aV = SPEC ? 1 : a.V;
     extern __shared__ __attribute__((aligned(16))) float4 lds4[];
     float4* win = lds4;                                   // [NBUF][NTEX_MAX]
