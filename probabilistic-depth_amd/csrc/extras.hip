@@ -363,7 +363,11 @@ static bool correlation_forward_mfma_ok(int C, int H, int W, int radius, int str
 
 hipError_t launch_correlation_forward(const float* x1, const float* x2, int B, int C, int H, int W, int radius,
                                       int stride2, float* out, hipStream_t stream) {
+#ifdef PDEPTH_LAB
     static const bool no_mfma = [] { const char* e = getenv("PDEPTH_CORR_NO_MFMA"); return e && e[0] == '1'; }();   // A/B timing
+#else
+    constexpr bool no_mfma = false;   // (the product library reads no environment)
+#endif
     if (!no_mfma && radius >= 1 && radius <= RMAX && correlation_forward_mfma_ok(C, H, W, radius, stride2)) {
         const long long nwg = (long long)B * H * ((W + 63) / 64);
         if (nwg < (1ll << 31)) {

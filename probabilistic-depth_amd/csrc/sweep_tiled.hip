@@ -929,10 +929,14 @@ hipError_t launch_sweep_tiled(const SweepArgs& a, void* workspace, hipStream_t s
 #endif
 
 // Launches the pre-pass, this variant's tiled kernel, then the gather kernel on the tiles it flagged.
-// PDEPTH_NO_SPEC=1 (read once): always the general instantiation (A/B timing of the compile-time specialisation)
+// lab builds, PDEPTH_NO_SPEC=1 (read once): always the general instantiation (A/B timing of the compile-time specialisation)
 static bool getenv_once_no_spec() {
+#ifdef PDEPTH_LAB
     static const bool v = [] { const char* e = getenv("PDEPTH_NO_SPEC"); return e && e[0] == '1'; }();
     return v;
+#else
+    return false;
+#endif
 }
 
 hipError_t PDEPTH_CAT(launch_sweep_tiled_n, PDEPTH_NSUB)(const SweepArgs& a, void* workspace, hipStream_t stream, bool packed_ready, int phases) {

@@ -135,7 +135,25 @@ def test_product_library_carries_no_lab_bench():
             n = len(re.findall(r"^\s*#\s*if", open(os.path.join(csrc, f)).read(), re.M))
             assert n <= 5, f"{f}: {n} preprocessor conditionals"
     lib = _native.load()
-    names = {"pdepth_sweep_centres_source", "pdepth_sweep_dpv_packed_f32"}
+    names = {"pdepth_sweep_centres_source", "pdepth_sweep_dpv_packed_f32", "pdepth_sweep_source_layout"}
     for n in names:
         assert hasattr(lib, n)
-    assert _native.ALGO_CORR == 6
+    assert (_native.ALGO_CORR, _native.ALGO_DIST) == (6, 7)
+    # the lab selectors (the cell-list and fp32-matrix kernels of rounds 2 / 3) are refused by the product library, by name
+    cam = _native.Camera(1, 1, 1, 1, 1)
+    for algo in (_native.ALGO_CELLS, _native.ALGO_MFMA):
+        desc = _native.SweepDesc(1, 1, 4, 8, 8, 16, 0, algo, 0, 1.0, 512, 512, 512)
+        rc = lib.pdepth_sweep_dpv_f32(ctypes.byref(desc), ctypes.byref(cam), 1, 1, 1, None, 1, 1, 256, 1 << 20, None)
+        assert rc == 1 and b"lab builds only" in lib.pdepth_last_error()
+    # ... and it reads no environment: every experiment switch of the sources (PDEPTH_SWEEP_IMPL, PDEPTH_CORR_FUSE_PACK,
+    # PDEPTH_NO_SPEC, PDEPTH_CORR_NO_MFMA) sits behind #ifdef PDEPTH_LAB, so their names are not in the binary
+    blob = open(_native.LIB_PATH, "rb").read()
+    for name in (b"PDEPTH_SWEEP_IMPL", b"PDEPTH_CORR_FUSE_PACK", b"PDEPTH_NO_SPEC", b"PDEPTH_CORR_NO_MFMA"):
+        assert name not in blob, name
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".hpp")):
+            body = open(os.path.join(csrc, f)).read()
+            for m in re.finditer(r"getenv\(", body):
+                head = body[:m.start()]
+                opened = len(re.findall(r"^\s*#\s*ifdef PDEPTH_LAB", head, re.M)) + len(re.findall(r"^\s*#\s*if defined\(PDEPTH_LAB\)", head, re.M))
+                assert opened > 0 and head.rfind("PDEPTH_LAB") > head.rfind("#endif"), f"{f}: getenv outside a lab-only block"

@@ -153,6 +153,30 @@ def test_packed_source_is_tied_to_the_kernel_family(dev):
         assert torch.equal(c2, first["auto"])
 
 
+def test_a_foreign_packed_layout_is_detected_on_the_device(dev):
+    """A caller of the C ABI (no binding in between) that hands pdepth_sweep_dpv_packed_f32 a workspace packed for another
+    kernel family: pdepth_pack_* writes the layout's tag into the workspace, every packed sweep kernel compares it with the
+    layout it reads and, on a mismatch, fills its outputs with NaN instead of interpreting foreign bytes.
+    The binding's host-side check is bypassed here by forging the tag it keeps."""
+    b = synth.make_batch(5, 1, C=67, D=64, H=64, W=128, V=1, pose="mono")
+    d = to_dev(b, dev)
+    args = (d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0)
+    for pack_algo, sweep_algo in (("corr", "auto"), ("tiled1", "auto"), ("auto", "corr"), ("auto", "tiled1"), ("corr", "tiled1"),
+                                  ("tiled1", "corr")):
+        ps = ops.pack_source(d["src"], 64, algo=pack_algo)
+        honest = ps.layout
+        ps.layout = ops.pack_source(d["src"], 64, algo=sweep_algo).layout      # what the sweep's descriptor expects
+        assert ps.layout != honest
+        cost, logp, depth = ops.sweep_dpv(d["ref"], ps, *args, algo=sweep_algo, want_cost=True)
+        for name, out in (("cost", cost), ("logp", logp), ("depth", depth)):
+            assert bool(torch.isnan(out).all()), f"packed for {pack_algo}, swept as {sweep_algo}: {name} is not all NaN"
+        # the workspace is still what it was: the honest sweep gives the NCHW entry's answer
+        ps.layout = honest
+        cp, _, dp = ops.sweep_dpv(d["ref"], ps, *args, algo=pack_algo, want_cost=True)
+        ca, _, da = ops.sweep_dpv(d["ref"], d["src"], *args, algo=pack_algo, want_cost=True)
+        assert torch.equal(cp, ca) and torch.equal(dp, da), pack_algo
+
+
 def test_passes_that_do_not_fit_are_evaluated_directly(dev):
     """A wide-baseline pose: epipolar segments of hundreds of texels, more blocks of X than the kernel's LDS holds -- those
     passes take the direct evaluation inside the same launch (no tile flags, no second kernel) and meet the same bounds;

@@ -117,6 +117,14 @@ def test_rccl_path_initialises_on_the_hardware():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = json.loads([l for l in p.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["value"] > 0 and line["scaling"] == "weak"
+    # SURVEY section 8(d) "Ambiguity resolved": the 64x128 model-real figure and the peaked variant ride in the driver's line
+    # (VERDICT r4, item 4): B = 1 and B = 4, both entries, with us per call, launches per call and the roofline fraction
+    assert line["roofline"]["sweep_kernel"] == "dist" and line["packed_entry"]["max_abs_depth_diff_vs_headline"] == 0.0
+    for key in ("B1_nchw", "B1_packed", "B4_nchw", "B4_packed"):
+        row = line["model_real"][key]
+        assert row["us_per_call"] > 0 and row["launches"] >= 1 and 0 < row["frac"] < 1 and row["volumes_per_s"] > 0, key
+    assert line["model_real"]["B1_packed"]["launches"] == 1 and "64x128" in line["model_real"]["shape"]
+    assert line["peaked"]["ms_per_step"] > 0 and line["peaked"]["value"] > 0
 
 
 @pytest.mark.gpu

@@ -95,6 +95,21 @@ def draw_case(rng, case, build):
     return shape, b
 
 
+def replay_case(seed, case, spec=False, offset=True):
+    """Case `case` of `seed` as a soak run with SOAK_SPEC=spec, SOAK_OFFSET=offset drew it (the generator is advanced
+    through the earlier cases): tests/test_soak_regressions.py pins the worst cases of earlier rounds' soaks with this."""
+    global SPEC, OFFSET
+    keep = SPEC, OFFSET
+    SPEC, OFFSET = spec, offset
+    try:
+        rng = np.random.default_rng(seed)
+        for c in range(case):
+            draw_case(rng, c, build=False)
+        return draw_case(rng, case, build=True)
+    finally:
+        SPEC, OFFSET = keep
+
+
 def describe(case, algo, s, metric):
     return f"case {case} {algo} {s['pose']} {s['H']}x{s['W']} C={s['C']} D={s['D']} V={s['V']} B={s['B']} k={s['k']} {metric}"
 
