@@ -26,7 +26,7 @@ import torch.nn.functional as F
 __all__ = [
     "powerf", "unit_rays", "intrinsics_from_fov", "plane_coords", "sweep_cost",
     "warp_feature", "log_dpv", "dpv_to_depthmap", "sweep_dpv", "sample_coords", "gen_dpv_withmask", "dpv_fuse",
-    "correlation", "correlation_general", "inverse_warp", "dpv_variance", "gen_ufield",
+    "correlation", "correlation_general", "inverse_warp", "dpv_variance", "gen_ufield", "sweep_dpv_exact64",
 ]
 
 
@@ -337,6 +337,52 @@ def sweep_dpv(feat_ref, feat_src, d_candi, R, t, K, rays, cx, cy, sigma, metric=
     cost = sweep_cost(feat_ref, feat_src, d_candi, R, t, K, rays, cx, cy, sigma, metric)
     logp = log_dpv(cost)
     return cost, logp, dpv_to_depthmap(logp, d_candi, BV_log=True)
+
+
+def sweep_dpv_exact64(feat_ref, feat_src, d_candi, R, t, K, rays, cx, cy, sigma, plane_chunk=8):
+    """The chain of sweep_dpv() evaluated in float64 AT THE float32 SAMPLE POSITIONS of the reference (sample_coords(): the
+    positions are data here, every implementation has them bit for bit): bilinear taps with zeros outside the image
+    (warping/homography.py:197), squared differences summed over the channels (:80-82), / sigma summed over the views (:129),
+    log_softmax over the planes (models/packnet.py:394), expectation (utils/img_utils.py:52-61).
+
+    NOT the reference's numerics -- the yardstick for them: the distance of the float32 oracle from this volume is the
+    rounding noise of the reference itself, which an implementation can only reproduce by copying its summation order
+    (csrc/sweep_direct.hip does; the fast kernels are held to "no noisier than the reference", tests/util.py).
+    Returns (cost [1,D,h,w], depth [1,h,w], kappa [1,h,w]) float64; kappa = sum_k p_k |d_k - E|: the change of the expected
+    depth per unit of (worst-sign) error of the costs of a pixel, to first order."""
+    ref = feat_ref[0].double()
+    C, h, w = ref.shape
+    V = feat_src.shape[1]
+    d32 = np.asarray(d_candi).astype(np.float32)
+    D = len(d32)
+    refv = ref.reshape(1, C, h * w)
+    cost = torch.zeros(D, h * w, dtype=torch.float64)
+    for v in range(V):
+        ixa, iya = sample_coords(K, R[v], t[v], rays, d32, cx, cy, h, w)   # [D, hw] float32
+        sv = feat_src[0, v].double().reshape(C, h * w)
+        for k0 in range(0, D, plane_chunk):
+            ix, iy = ixa[k0:k0 + plane_chunk].double(), iya[k0:k0 + plane_chunk].double()
+            n = ix.shape[0]
+            valid = torch.isfinite(ix) & torch.isfinite(iy)
+            ix, iy = torch.where(valid, ix, torch.zeros_like(ix)), torch.where(valid, iy, torch.zeros_like(iy))
+            x0, y0 = torch.floor(ix), torch.floor(iy)
+            fx, fy = ix - x0, iy - y0
+            val = torch.zeros(n, C, h * w, dtype=torch.float64)
+            for dy, dx, wt in ((0, 0, (1 - fx) * (1 - fy)), (0, 1, fx * (1 - fy)), (1, 0, (1 - fx) * fy), (1, 1, fx * fy)):
+                xx, yy = x0 + dx, y0 + dy
+                ok = (xx >= 0) & (xx <= w - 1) & (yy >= 0) & (yy <= h - 1)
+                idx = torch.where(ok, yy * w + xx, torch.zeros_like(xx)).long()
+                tap = sv[:, idx.reshape(-1)].reshape(C, n, h * w).permute(1, 0, 2)
+                val += tap * (wt * ok)[:, None, :]
+            dist = ((val - refv) ** 2).sum(1)
+            dist[~valid] = float("nan")
+            cost[k0:k0 + n] += dist / float(sigma)
+    logp = torch.log_softmax(cost, 0)
+    p = logp.exp()
+    dk = torch.from_numpy(d32.astype(np.float64))[:, None]
+    depth = (dk * p).sum(0)
+    kappa = (p * (dk - depth[None]).abs()).sum(0)
+    return cost.reshape(1, D, h, w), depth.reshape(1, h, w), kappa.reshape(1, h, w)
 
 
 # --------------------------------------------------------------------------------------

@@ -4,10 +4,12 @@
 // pdepth_pack_source_f32) or straight from the encoder output (pdepth_pack_views_f32: the reference's
 // cat(feat, avg_pool2d(rgb)) of models/models.py:518-534 is never materialised).
 //
-// One thread per texel of the (H + 2) x (W + 2) image (ring of zero-feature texels = padding_mode 'zeros'), channels in
-// groups of eight (= one 16-byte store of high parts and one of low parts), the next group's 32 loads in flight while a
-// group is converted.  The kernel is a stream: 4 C bytes in, 16 * nplanes bytes out per texel.
+// One lane per column of a strip of four rows of the (H + 2) x (W + 2) image (ring of zero-feature texels = padding_mode
+// 'zeros'), channels in groups of eight (= one 16-byte store of high parts and one of low parts per row), the next group's
+// 41 loads in flight while a group is converted.  The kernel is a stream: 4 C bytes in, 16 * nplanes bytes out per texel.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 
 #include "dist_layout.hpp"
 #include "kernels.hpp"
@@ -49,64 +51,117 @@ struct ViewSource {
     }
 };
 
-// mus[c] = mu[c] * 2^e (LDS, zeros beyond C), sc = 2^e.  out = the view's planes.  (xp, yp) = texel of the padded image.
-template <int NCHK, typename Source>
-__device__ __forceinline__ void pack_dist_texel(const Source& src, int C, int H, int W, int xp, int yp, const float* mus, float sc,
+// mus[c] = mu[c] * 2^e (LDS, zeros beyond C), sc = 2^e.  out = the view's planes.
+//
+// One wave = 64 consecutive texels of a strip of ROWS rows of the padded image (the strips of a view laid end to end:
+// element e = strip * Wp + xp), every lane its column: the lane loads its ROWS + 1 texels of a channel once, the right-hand
+// neighbours come from the next lane (DPP wave_shl:1) and, for lane 63, from one extra load per group of eight channels in
+// which lane r * 8 + j fetches the neighbour of row r, channel j.  A vector-memory instruction occupies the CU's address
+// pipe for ~17 cycles whatever it loads (tools/mb_ta.hip): the first version of this kernel (one thread per texel, its four
+// cell corners loaded separately) issued 4 loads per channel and texel, this one (ROWS + 1) / ROWS.  Where a row of the padded image ends inside a wave, the "neighbour" a lane gets belongs to the
+// next row's first texel: both lie in the ring (x = W + 1 or beyond, x = -1), both hold the zero feature vector.
+
+__device__ __forceinline__ float wave_shl1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+template <int NCHK, int ROWS, typename Source>
+__device__ __forceinline__ void pack_dist_strip(const Source& src, int C, int H, int W, long long e0, const float* mus, float sc,
                                                 char* __restrict__ out, int* __restrict__ item_flags) {
-    const int x = xp - dist::RING, y = yp - dist::RING;
+    const int lane = threadIdx.x & 63;
+    const int Wp = dist::wp(W), Hp = dist::hp(H);
     const long long PB = dist::plane_bytes(H, W);
-    const size_t toff = ((size_t)yp * dist::wp(W) + xp) * 16;
-    // the texel and its right / lower / diagonal neighbours: inside the image?  (outside: the zero feature vector)
-    const bool yin0 = (unsigned)y < (unsigned)H, yin1 = (unsigned)(y + 1) < (unsigned)H;
-    const bool xin0 = (unsigned)x < (unsigned)W, xin1 = (unsigned)(x + 1) < (unsigned)W;
-    const bool in[4] = {xin0 && yin0, xin1 && yin0, xin0 && yin1, xin1 && yin1};
-    const int ya = min(max(y, 0), H - 1), yb = min(max(y + 1, 0), H - 1), xa = min(max(x, 0), W - 1), xb = min(max(x + 1, 0), W - 1);
+    const long long nelem = (long long)((Hp + ROWS - 1) / ROWS) * Wp;
+    // this lane's column, and the column whose texels lane 63 needs as right-hand neighbours (the "halo": element e0 + 64)
+    const long long e = e0 + lane;
+    const int strip = (int)(e / Wp), xp = (int)(e - (long long)strip * Wp), yp0 = strip * ROWS;
+    const long long eh = e0 + 64;
+    const int strip_h = (int)(eh / Wp), xh = (int)(eh - (long long)strip_h * Wp) - dist::RING, yh0 = strip_h * ROWS;
+    const int x = xp - dist::RING;
+    const bool xin = (unsigned)x < (unsigned)W;
+    const int xa = min(max(x, 0), W - 1);
+    bool in[ROWS + 1];
+    int ya[ROWS + 1];
+#pragma unroll
+    for (int r = 0; r <= ROWS; ++r) {
+        const int y = yp0 + r - dist::RING;
+        in[r] = xin && (unsigned)y < (unsigned)H;
+        ya[r] = min(max(y, 0), H - 1);
+    }
+    // halo lane r * 8 + j: row r of the halo column, channel j of the group
+    const int hr = min(lane >> 3, ROWS), hj = lane & 7;
+    const int yh = yh0 + hr - dist::RING;
+    const bool hin = (unsigned)xh < (unsigned)W && (unsigned)yh < (unsigned)H && lane < 8 * (ROWS + 1);
+    const int xha = min(max(xh, 0), W - 1), yha = min(max(yh, 0), H - 1);
+
     constexpr int NG = 4 * NCHK + 1;   // groups of 8 channels; the last one is the tail
-    float n = 0.f, dx0 = 0.f, dy0 = 0.f, dd = 0.f, dx1 = 0.f;
+    float n[ROWS], dx[ROWS + 1], dy0[ROWS], dd[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) n[r] = dy0[r] = dd[r] = 0.f;
+#pragma unroll
+    for (int r = 0; r <= ROWS; ++r) dx[r] = 0.f;
     bool ovf = false;
-    auto issue = [&](int g, float(&v)[32]) {
+    constexpr int NV = 8 * (ROWS + 1) + 1;
+    auto issue = [&](int g, float(&v)[NV]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = min(8 * g + j, C - 1);   // (channels beyond C: loaded from the last one, dropped below)
-            v[4 * j + 0] = src.at(c, ya, xa); v[4 * j + 1] = src.at(c, ya, xb);
-            v[4 * j + 2] = src.at(c, yb, xa); v[4 * j + 3] = src.at(c, yb, xb);
+            const int c = min(8 * g + j, C - 1);   // (channels beyond C: loaded from the last one, their mean is zero and so are they)
+#pragma unroll
+            for (int r = 0; r <= ROWS; ++r) v[r * 8 + j] = src.at(c, ya[r], xa);
         }
+        v[NV - 1] = src.at(min(8 * g + hj, C - 1), yha, xha);
     };
-    auto finish = [&](int g, const float(&v)[32]) {
-        h8 hh, ll;
+    auto finish = [&](int g, const float(&v)[NV]) {
+        h8 hh[ROWS], ll[ROWS];
+        // x' = (x - mu) 2^e in one rounding (the scaling is exact); outside the image, and beyond C: x = 0
+        const bool hhas = 8 * g + hj < C;
+        const float hc = __builtin_fmaf(hhas && hin ? v[NV - 1] : 0.f, sc, -mus[min(8 * g + hj, dist::MAX_C + 7)]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = 8 * g + j;
             const bool has = c < C;   // uniform
             const float m = mus[min(c, dist::MAX_C + 7)];
-            // x' = (x - mu) 2^e in one rounding (the scaling is exact); outside the image: x = 0
-            const float s00 = __builtin_fmaf(has && in[0] ? v[4 * j + 0] : 0.f, sc, -m);
-            const float s01 = __builtin_fmaf(has && in[1] ? v[4 * j + 1] : 0.f, sc, -m);
-            const float s10 = __builtin_fmaf(has && in[2] ? v[4 * j + 2] : 0.f, sc, -m);
-            const float s11 = __builtin_fmaf(has && in[3] ? v[4 * j + 3] : 0.f, sc, -m);
-            ovf = ovf || !(fabsf(s00) <= 65000.0f);
-            const float sx = fminf(fmaxf(s00, -65000.0f), 65000.0f);
-            const _Float16 h = (_Float16)sx;
-            hh[j] = h;
-            ll[j] = (_Float16)(sx - (float)h);
-            n = __builtin_fmaf(s00, s00, n);
-            const float a = s00 - s01, b = s00 - s10, d1 = s00 - s11, d2 = s01 - s10, e = s10 - s11;
-            dx0 = __builtin_fmaf(a, a, dx0);
-            dy0 = __builtin_fmaf(b, b, dy0);
-            dd = __builtin_fmaf(d1, d1, dd);
-            dd = __builtin_fmaf(d2, d2, dd);
-            dx1 = __builtin_fmaf(e, e, dx1);
+            float s[ROWS + 1], sr[ROWS + 1];
+#pragma unroll
+            for (int r = 0; r <= ROWS; ++r) {
+                s[r] = __builtin_fmaf(has && in[r] ? v[r * 8 + j] : 0.f, sc, -m);
+                sr[r] = wave_shl1(s[r]);
+                const float h63 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hc), r * 8 + j));
+                sr[r] = lane == 63 ? h63 : sr[r];
+                const float a = s[r] - sr[r];
+                dx[r] = __builtin_fmaf(a, a, dx[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                ovf = ovf || !(fabsf(s[r]) <= 65000.0f);
+                const float sx = fminf(fmaxf(s[r], -65000.0f), 65000.0f);
+                const _Float16 h = (_Float16)sx;
+                hh[r][j] = h;
+                ll[r][j] = (_Float16)(sx - (float)h);
+                n[r] = __builtin_fmaf(s[r], s[r], n[r]);
+                const float b = s[r] - s[r + 1], d1 = s[r] - sr[r + 1], d2 = sr[r] - s[r + 1];
+                dy0[r] = __builtin_fmaf(b, b, dy0[r]);
+                dd[r] = __builtin_fmaf(d1, d1, dd[r]);
+                dd[r] = __builtin_fmaf(d2, d2, dd[r]);
+            }
         }
-        if (g < 4 * NCHK) {
-            *reinterpret_cast<h8*>(out + (size_t)g * PB + toff) = hh;
-            *reinterpret_cast<h8*>(out + (size_t)(4 * NCHK + g) * PB + toff) = ll;
-        } else {
-            *reinterpret_cast<h8*>(out + (size_t)(8 * NCHK + 0) * PB + toff) = hh;
-            *reinterpret_cast<h8*>(out + (size_t)(8 * NCHK + 1) * PB + toff) = ll;
-            *reinterpret_cast<h8*>(out + (size_t)(8 * NCHK + 2) * PB + toff) = hh;
+        if (e < nelem) {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                if (yp0 + r >= Hp) break;
+                const size_t toff = ((size_t)(yp0 + r) * Wp + xp) * 16;
+                if (g < 4 * NCHK) {
+                    *reinterpret_cast<h8*>(out + (size_t)g * PB + toff) = hh[r];
+                    *reinterpret_cast<h8*>(out + (size_t)(4 * NCHK + g) * PB + toff) = ll[r];
+                } else {
+                    *reinterpret_cast<h8*>(out + (size_t)(8 * NCHK + 0) * PB + toff) = hh[r];
+                    *reinterpret_cast<h8*>(out + (size_t)(8 * NCHK + 1) * PB + toff) = ll[r];
+                    *reinterpret_cast<h8*>(out + (size_t)(8 * NCHK + 2) * PB + toff) = hh[r];
+                }
+            }
         }
     };
-    float va[32], vb[32];
+    float va[NV], vb[NV];
     issue(0, va);
 #pragma unroll 1
     for (int g = 0; g < NG; g += 2) {
@@ -119,16 +174,34 @@ __device__ __forceinline__ void pack_dist_texel(const Source& src, int C, int H,
             finish(g + 1, vb);
         }
     }
-    // specials: N as three fp16 pieces, and the constants that multiply the pixel's pieces of |r'|^2
-    ovf = ovf || !(n < 2.0e9f);
-    const dist::Pieces pn = dist::split_pieces(fminf(n, 2.0e9f));
-    h8 sp;
-    sp[0] = pn.p1; sp[1] = pn.p2; sp[2] = pn.p3;
-    sp[3] = (_Float16)dist::PIECE_C1; sp[4] = (_Float16)dist::PIECE_C2; sp[5] = (_Float16)dist::PIECE_C3;
-    sp[6] = (_Float16)0.f; sp[7] = (_Float16)0.f;
-    *reinterpret_cast<h8*>(out + (size_t)(8 * NCHK + 3) * PB + toff) = sp;
-    *reinterpret_cast<v4f*>(out + (size_t)(8 * NCHK + 4) * PB + toff) = v4f{dx0, dy0, dd, dx1};
+    if (e >= nelem) return;
+    // specials: N as three fp16 pieces, and the constants that multiply the pixel's pieces of |r'|^2;
+    // Q record: (Dx0, Dy0, Dd, Dx1) -- Dx1 of a texel is Dx0 of the texel below
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        if (yp0 + r >= Hp) break;
+        const size_t toff = ((size_t)(yp0 + r) * Wp + xp) * 16;
+        ovf = ovf || !(n[r] < 2.0e9f);
+        const dist::Pieces pn = dist::split_pieces(fminf(n[r], 2.0e9f));
+        h8 sp;
+        sp[0] = pn.p1; sp[1] = pn.p2; sp[2] = pn.p3;
+        sp[3] = (_Float16)dist::PIECE_C1; sp[4] = (_Float16)dist::PIECE_C2; sp[5] = (_Float16)dist::PIECE_C3;
+        sp[6] = (_Float16)0.f; sp[7] = (_Float16)0.f;
+        *reinterpret_cast<h8*>(out + (size_t)(8 * NCHK + 3) * PB + toff) = sp;
+        *reinterpret_cast<v4f*>(out + (size_t)(8 * NCHK + 4) * PB + toff) = v4f{dx[r], dy0[r], dd[r], dx[r + 1]};
+    }
     if (ovf) atomicOr(item_flags, 1);
+}
+
+// Rows per strip.  Measured on the headline shape (4 views of 256 x 512, C = 67; gpurun_out/pack_time2.txt -> profiles/r05_ab/):
+// 1 row: 74 us, 2 rows: 78 us, 4 rows (258 registers, one wave per SIMD): 91 us; the one-thread-per-texel first version
+// (4 loads per channel): 70 us.  The kernel moves 140 MB in and 179 MB out: 4.3 TB/s, what a read-and-write stream reaches
+// on this memory system -- the address pipe was not the limit after all.  One row keeps the most waves in flight, which is
+// what the small shapes want (64 x 128: 17 us against 21 / 31 us).
+constexpr int PACK_ROWS = 1;
+
+__host__ __device__ inline int pack_dist_waves(int H, int W, int ROWS) {
+    return (int)(((long long)((dist::hp(H) + ROWS - 1) / ROWS) * dist::wp(W) + 63) / 64);
 }
 
 // the scaled channel means of batch item b into LDS (mus: MAX_C + 8 floats), returns 2^e
@@ -159,7 +232,7 @@ __device__ __forceinline__ void reset_queue(int* __restrict__ queue) {
     if (threadIdx.x < 64) queue[threadIdx.x] = threadIdx.x == LAYOUT_SLOT ? LAYOUT_DIST16 : 0;
 }
 
-template <int NCHK>
+template <int NCHK, int ROWS>
 __global__ __launch_bounds__(256) void pack_dist_kernel(const float* __restrict__ src, long long bstride, long long vstride, int V, int C,
                                                         int H, int W, char* __restrict__ out, int* __restrict__ flags, int nflags,
                                                         int* queue, float* __restrict__ stats) {
@@ -169,18 +242,16 @@ __global__ __launch_bounds__(256) void pack_dist_kernel(const float* __restrict_
     __shared__ float mus[dist::MAX_C + 8];
     __shared__ float scratch[4];
     const float sc = load_item_scale(stats, b, mus, scratch);
-    const int Wp = dist::wp(W), Hp = dist::hp(H);
-    const int pix = xcd_block_order(gridDim.x, blockIdx.x) * 256 + threadIdx.x;
-    if (pix >= Hp * Wp) return;
-    const int yp = pix / Wp, xp = pix - yp * Wp;
+    const int wave = xcd_block_order(gridDim.x, blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (wave >= pack_dist_waves(H, W, ROWS)) return;
     NchwSource s{src + (size_t)b * bstride + (size_t)(bv % V) * vstride, H * W, W};
-    pack_dist_texel<NCHK>(s, C, H, W, xp, yp, mus, sc, out + (size_t)bv * dist::view_bytes(C, H, W),
+    pack_dist_strip<NCHK, ROWS>(s, C, H, W, (long long)wave * 64, mus, sc, out + (size_t)bv * dist::view_bytes(C, H, W),
                           reinterpret_cast<int*>(stats + (size_t)b * STATS_STRIDE + STATS_FLAGS));
 }
 
 // the encoder epilogue (sweep_pack.hip: pack_views_kernel says what it replaces): views 0..V-1 of an item into the packed
 // layout, view V (the reference view) as NCHW [B, Cf + 3, H, W]
-template <int NCHK>
+template <int NCHK, int ROWS>
 __global__ __launch_bounds__(256) void pack_views_dist_kernel(const float* __restrict__ feat, const float* __restrict__ rgb, int V, int Cf,
                                                               int H, int W, int rate, int IH, int IW, char* __restrict__ out,
                                                               float* __restrict__ ref_out, int* __restrict__ flags, int nflags, int* queue,
@@ -201,10 +272,9 @@ __global__ __launch_bounds__(256) void pack_views_dist_kernel(const float* __res
         for (int c = 0; c < C; ++c) o[(size_t)c * HW] = s.at(c, y, x);
         return;
     }
-    const int Wp = dist::wp(W), Hp = dist::hp(H);
-    if (pix >= Hp * Wp) return;
-    const int yp = pix / Wp, xp = pix - yp * Wp;
-    pack_dist_texel<NCHK>(s, C, H, W, xp, yp, mus, sc, out + (size_t)(b * V + v) * dist::view_bytes(C, H, W),
+    const int wave = xcd_block_order(gridDim.x, blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (wave >= pack_dist_waves(H, W, ROWS)) return;
+    pack_dist_strip<NCHK, ROWS>(s, C, H, W, (long long)wave * 64, mus, sc, out + (size_t)(b * V + v) * dist::view_bytes(C, H, W),
                           reinterpret_cast<int*>(stats + (size_t)b * STATS_STRIDE + STATS_FLAGS));
 }
 
@@ -218,15 +288,17 @@ hipError_t launch_pack_dist(const SweepArgs& a, void* workspace, hipStream_t str
     int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + sweep_ws_flag_only_bytes(a.B, a.H, a.W));
     hipError_t e = launch_feature_stats(a, stats, stream);
     if (e != hipSuccess) return e;
-    const int npix = dist::hp(a.H) * dist::wp(a.W), nflags = (int)(sweep_ws_flag_only_bytes(a.B, a.H, a.W) / sizeof(int));
-    dim3 grid((npix + 255) / 256, a.B * a.V);
-#define PDEPTH_PACK_DIST(N) hipLaunchKernelGGL(pack_dist_kernel<N>, grid, dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V, a.C, a.H, \
-                                               a.W, packed, flags, nflags, queue, stats)
+    const int nflags = (int)(sweep_ws_flag_only_bytes(a.B, a.H, a.W) / sizeof(int));
+    dim3 grid((pack_dist_waves(a.H, a.W, PACK_ROWS) + 3) / 4, a.B * a.V);
+#define PDEPTH_PACK_DIST(N, R) hipLaunchKernelGGL((pack_dist_kernel<N, R>), grid, dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V, a.C, \
+                                                  a.H, a.W, packed, flags, nflags, queue, stats)
+#define PDEPTH_PACK_DIST_R(N) PDEPTH_PACK_DIST(N, PACK_ROWS)
     switch (dist::nchk(a.C)) {
-        case 0: PDEPTH_PACK_DIST(0); break;
-        case 1: PDEPTH_PACK_DIST(1); break;
-        default: PDEPTH_PACK_DIST(2); break;
+        case 0: PDEPTH_PACK_DIST_R(0); break;
+        case 1: PDEPTH_PACK_DIST_R(1); break;
+        default: PDEPTH_PACK_DIST_R(2); break;
     }
+#undef PDEPTH_PACK_DIST_R
 #undef PDEPTH_PACK_DIST
     return hipGetLastError();
 }
@@ -239,15 +311,18 @@ hipError_t launch_pack_views_dist(const SweepArgs& a, const float* feat, const f
     int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + sweep_ws_flag_only_bytes(a.B, a.H, a.W));
     hipError_t e = launch_view_stats(a, feat, rgb, rate, img_h, img_w, stats, stream);
     if (e != hipSuccess) return e;
-    const int npix = dist::hp(a.H) * dist::wp(a.W), nflags = (int)(sweep_ws_flag_only_bytes(a.B, a.H, a.W) / sizeof(int));
-    dim3 grid((npix + 255) / 256, a.B * (a.V + 1));
-#define PDEPTH_PACK_VIEWS_DIST(N) hipLaunchKernelGGL(pack_views_dist_kernel<N>, grid, dim3(256), 0, stream, feat, rgb, a.V, a.C - 3, a.H, a.W, rate, \
-                                                     img_h, img_w, packed, ref_out, flags, nflags, queue, stats)
+    const int nflags = (int)(sweep_ws_flag_only_bytes(a.B, a.H, a.W) / sizeof(int));
+    // (source views: 4 waves of 64 x ROWS texels per block; the reference view: 256 pixels per block)
+    dim3 grid(std::max((pack_dist_waves(a.H, a.W, PACK_ROWS) + 3) / 4, (a.H * a.W + 255) / 256), a.B * (a.V + 1));
+#define PDEPTH_PACK_VIEWS_DIST(N, R) hipLaunchKernelGGL((pack_views_dist_kernel<N, R>), grid, dim3(256), 0, stream, feat, rgb, a.V, a.C - 3, a.H, a.W, \
+                                                        rate, img_h, img_w, packed, ref_out, flags, nflags, queue, stats)
+#define PDEPTH_PACK_VIEWS_DIST_R(N) PDEPTH_PACK_VIEWS_DIST(N, PACK_ROWS)
     switch (dist::nchk(a.C)) {
-        case 0: PDEPTH_PACK_VIEWS_DIST(0); break;
-        case 1: PDEPTH_PACK_VIEWS_DIST(1); break;
-        default: PDEPTH_PACK_VIEWS_DIST(2); break;
+        case 0: PDEPTH_PACK_VIEWS_DIST_R(0); break;
+        case 1: PDEPTH_PACK_VIEWS_DIST_R(1); break;
+        default: PDEPTH_PACK_VIEWS_DIST_R(2); break;
     }
+#undef PDEPTH_PACK_VIEWS_DIST_R
 #undef PDEPTH_PACK_VIEWS_DIST
     return hipGetLastError();
 }

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int
     const int p = live ? pix : HW - 1;  // dead lanes shadow the last pixel, never store
 
     float* cost = lds;                                  // [D][64]
-    float* acc = MULTI_CHUNK ? lds + a.D * 64 : nullptr;  // [D][64], raw per-view sums
+    float* acc = MULTI_CHUNK ? lds + a.D * 64 : nullptr;   // [D][64], raw per-view sums: level 1 of the cascade, then the total
+    float* acc2 = MULTI_CHUNK && a.C >= 256 ? lds + a.D * 128 : nullptr;  // [D][64], level 2 (256 channels and more)
     for (int k = 0; k < a.D; ++k) cost[k * 64 + tid] = 0.0f;
 
     const float cx = a.cxcy[b * 2 + 0];
@@ -72,7 +73,10 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int
                                    : a.src + (size_t)b * a.src_bstride + (size_t)v * a.src_vstride;
 
         if (MULTI_CHUNK)
-            for (int k = 0; k < a.D; ++k) acc[k * 64 + tid] = 0.0f;
+            for (int k = 0; k < a.D; ++k) {
+                acc[k * 64 + tid] = 0.0f;
+                if (acc2) acc2[k * 64 + tid] = 0.0f;
+            }
 
         for (int c0 = 0; c0 < a.C; c0 += CCH) {
             float rf[CCH];
@@ -86,7 +90,12 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int
                 const Footprint f = make_footprint(ix, iy, a.W, a.H);
                 const float* s00 = PACKED ? srcv + (size_t)(f.y0 * a.W + f.x0) * 4 : srcv + (size_t)c0 * HW + (f.y0 * a.W + f.x0);
                 constexpr int TS = PACKED ? 4 : 1;   // floats between horizontally adjacent texels
-                float part = 0.0f;
+                // Sum over the channels in the order of ATen's sum(dim=1) on [D, C, h, w] (SumKernel.cpp: cascade_sum ->
+                // vectorized_outer_sum -> multi_row_sum, level_step = 16 up to 2^19 elements): runs of 16 channels are summed
+                // from zero (s0), a finished run is added to the level above (s1), 16 runs of that to the next (s2); the
+                // left-over channels stay in s0 and the result is (s0 + s1) + s2.  MULTI_CHUNK: s1 (and s2) live in LDS
+                // between the chunks (CCH is a multiple of 16: a chunk starts at a run boundary).
+                float s0 = 0.0f, s1 = MULTI_CHUNK ? acc[k * 64 + tid] : 0.0f;
 #pragma unroll
                 for (int cc = 0; cc < CCH; ++cc) {
                     if (c0 + cc < a.C) {  // wave-uniform
@@ -101,13 +110,23 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int
                         val = __builtin_fmaf(vsw, f.sw, val);
                         val = __builtin_fmaf(vse, f.se, val);
                         const float diff = val - rf[cc];
-                        part = part + (METRIC == 0 ? diff * diff : fabsf(diff));
+                        s0 = s0 + (METRIC == 0 ? diff * diff : fabsf(diff));
+                        if ((cc & 15) == 15) {
+                            s1 = s1 + s0;
+                            s0 = 0.0f;
+                            if (MULTI_CHUNK && (c & 255) == 255) {   // (acc2 != nullptr: C >= 256)
+                                acc2[k * 64 + tid] = acc2[k * 64 + tid] + s1;
+                                s1 = 0.0f;
+                            }
+                        }
                     }
                 }
-                if (MULTI_CHUNK)
-                    acc[k * 64 + tid] = acc[k * 64 + tid] + part;
-                else
-                    cost[k * 64 + tid] = cost[k * 64 + tid] + part / a.sigma;
+                if (MULTI_CHUNK) {
+                    if (c0 + CCH < a.C) acc[k * 64 + tid] = s1;                      // (s0 == 0: whole runs only)
+                    else acc[k * 64 + tid] = acc2 ? (s0 + s1) + acc2[k * 64 + tid] : s0 + s1;
+                } else {
+                    cost[k * 64 + tid] = cost[k * 64 + tid] + (s0 + s1) / a.sigma;
+                }
             }
         }
         if (MULTI_CHUNK)
@@ -126,14 +145,23 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int
         float s = 0.0f;
         for (int k = 0; k < a.D; ++k) s = s + expf(cost[k * 64 + tid] - m);
         const float ls = logf(s);
-        float e = 0.0f;
+        // expectation: torch.sum(d * exp(logp), dim=0) (utils/img_utils.py:59), in the order of ATen's cascade (see above)
+        float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
         float* o = a.logp_out ? a.logp_out + (size_t)b * a.D * HW + pix : nullptr;
         for (int k = 0; k < a.D; ++k) {
             const float lp = (cost[k * 64 + tid] - m) - ls;
             if (o && live) o[(size_t)k * HW] = lp;
-            e = e + a.d_candi[k] * expf(lp);
+            e0 = e0 + a.d_candi[k] * expf(lp);
+            if ((k & 15) == 15) {
+                e1 = e1 + e0;
+                e0 = 0.0f;
+                if ((k & 255) == 255) {
+                    e2 = e2 + e1;
+                    e1 = 0.0f;
+                }
+            }
         }
-        if (a.depth_out && live) a.depth_out[(size_t)b * HW + pix] = e;
+        if (a.depth_out && live) a.depth_out[(size_t)b * HW + pix] = (e0 + e1) + e2;
     }
     __syncthreads();   // (one wave per block: orders this tile's LDS reads before the next tile's writes)
     }  // tiles
@@ -159,7 +187,7 @@ static hipError_t launch_metric(const SweepArgs& a, const int* tile_flags, const
         const size_t lds = (size_t)a.D * 64 * sizeof(float);
         return packed ? go(sweep_direct_kernel<METRIC, 68, false, true>, lds) : go(sweep_direct_kernel<METRIC, 68, false, false>, lds);
     }
-    const size_t lds = (size_t)a.D * 64 * sizeof(float) * 2;
+    const size_t lds = (size_t)a.D * 64 * sizeof(float) * (a.C >= 256 ? 3 : 2);
     return packed ? go(sweep_direct_kernel<METRIC, 32, true, true>, lds) : go(sweep_direct_kernel<METRIC, 32, true, false>, lds);
 }
 
@@ -174,7 +202,7 @@ hipError_t launch_sweep_direct_flagged(const SweepArgs& a, const int* tile_flags
                          : launch_metric<1>(a, tile_flags, gather_count, tiles_x, tiles, stream, flag_value);
 }
 
-// Largest D the direct kernel can hold in LDS (two arrays in the chunked variant).
-int sweep_direct_max_planes(int C) { return C <= 68 ? 512 : 256; }  // 128 KB of LDS
+// Largest D the direct kernel can hold in LDS (two arrays in the chunked variant, three from 256 channels on).
+int sweep_direct_max_planes(int C) { return C <= 68 ? 512 : (C < 256 ? 256 : 170); }  // 128 KB of LDS
 
 }  // namespace pdepth
