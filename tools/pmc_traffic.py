@@ -1,6 +1,6 @@
 """profiles/pmc_traffic.json from the summaries of tools/prof.sh (the counters bench.py attaches to its roofline block).
 
-    python tools/pmc_traffic.py <mono summary.txt> <stereo summary.txt> <tag of the committed copies, e.g. r04> <collected: commit, date>
+    python tools/pmc_traffic.py <mono summary.txt> <stereo summary.txt> <tag of the committed copies, e.g. r05> <collected: commit, date> [kernel: dist]
 """
 import json, os, re, sys
 
@@ -55,14 +55,15 @@ def record(path, pose, chosen, source, collected):
 
 if __name__ == "__main__":
     mono, stereo, tag, collected = sys.argv[1:5]
+    chosen = sys.argv[5] if len(sys.argv) > 5 else "dist"
     doc = {"correction": "gfx950: FETCH_SIZE x2 (calibrated in profiles/r01_fetch_size_calibration.txt), WRITE_SIZE exact; KB = 1024 B",
-           "note": "one launch = one pdepth_sweep_dpv_f32 call (NCHW entry) = feature_stats_kernel + pack_c4_kernel<true> (pre-pass: channel means, "
-                   "centred re-layout + Gram planes) + sweep_corr_kernel. bench.py attaches a record only when its workload AND the kernel "
+           "note": "one launch = one pdepth_sweep_dpv_f32 call (NCHW entry) = feature_stats_kernel + pack_dist_kernel (pre-pass: channel means and "
+                   "scale, centred fp16 hi/lo planes + squared neighbour differences) + sweep_dist_kernel. bench.py attaches a record only when its workload AND the kernel "
                    "that ran match; 'collected' says on which commit and when the counters were taken (another box than any later bench run).",
            "workloads": [
-               record(mono, "mono", "corr", "profiles/%s_auto_mono.rocprofv3.txt (tools/prof.sh: rocprofv3 --pmc passes of `python3 bench.py --steps 3 "
+               record(mono, "mono", chosen, "profiles/%s_auto_mono.rocprofv3.txt (tools/prof.sh: rocprofv3 --pmc passes of `python3 bench.py --steps 3 "
                       "--warmup 1 --no-cpu-baseline`; SQ_* in one pass, FETCH_SIZE and WRITE_SIZE in separate passes)" % tag, collected),
-               record(stereo, "stereo", "corr", "profiles/%s_auto_stereo.rocprofv3.txt (tools/prof.sh ... --pose stereo)" % tag, collected)]}
+               record(stereo, "stereo", chosen, "profiles/%s_auto_stereo.rocprofv3.txt (tools/prof.sh ... --pose stereo)" % tag, collected)]}
     json.dump(doc, open(os.path.join(REPO, "profiles", "pmc_traffic.json"), "w"), indent=1)
     for w in doc["workloads"]:
         print(w["workload"]["pose"], w["workload"]["kernel"], "HBM MB/launch %.1f" % (w["hbm_bytes_per_launch"] / 1e6), "VALU %.3e" % w["valu_wave_instr_per_launch"])

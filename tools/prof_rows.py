@@ -20,6 +20,12 @@ x = torch.randn(B, D, H, W, device="cuda")
 dc = ops.d_candi_tensor(synth.powerf(5, 40, D, 1.0), "cuda")
 if case == "cfg5":
     f = sweep(2, 128, 512, 1024, 4, "mono")
+elif case == "cfg5_packed":   # config 5 with the source views already in the staging layout (the encoder epilogue writes it)
+    b_ = synth.make_batch(2, 2, C=67, D=128, H=512, W=1024, V=4, pose="mono")
+    d_ = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in b_.items()}
+    ps_ = ops.pack_source(d_["src"], 128)
+    dc_ = ops.d_candi_tensor(d_["d_candi"], "cuda")
+    f = lambda: ops.sweep_dpv(d_["ref"], ps_, d_["K"], d_["R"], d_["t"], d_["rays"], d_["cxcy"], dc_, 10.0)
 elif case == "cfg3":
     f = sweep(4, 64, 256, 512, 1, "stereo")
 elif case == "cfg2_tiled":

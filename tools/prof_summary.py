@@ -16,7 +16,7 @@ for sub in ("pmc1", "pmc2", "pmc3", "pmc4", "pmc5", "pmc6"):
             acc[row["Kernel_Name"][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
         print("== counters:", sub)
         for k, cs in acc.items():
-            if "sweep" not in k and "dpv" not in k and "pack_c4" not in k: continue
+            if not any(t in k for t in ("sweep", "dpv", "pack_c4", "pack_dist", "stats")): continue
             print("  kernel", k)
             for c, v in sorted(cs.items()):
                 print("     %-24s mean/dispatch %.4g  (n=%d)" % (c, sum(v) / len(v), len(v)))

@@ -1,6 +1,7 @@
 """Soak test on the GPU box: random shapes / poses / depth candidates / metrics, every implementation forced in turn
-(the correlation-form kernel where it applies -- L2, D <= 128, C <= 72, V <= 8 --, both builds of the tiled kernel; every
-fourth case the `auto` selection), against the gather kernel, which evaluates in the reference's op order.
+(the distance-form and the correlation-form kernels where they apply -- L2, D <= 128, C <= 72, V <= 8 --, both builds of the
+tiled kernel; with SOAK_DPV every fourth case the `auto` selection), against the gather kernel, which evaluates in the
+reference's op order (channel sums in ATen's cascade order since round 5).
 
     python tools/soak.py <seed> <cases> [case,case,...] [algo]
 
@@ -168,16 +169,16 @@ def main():
             continue
         d = {kk: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for kk, v in b.items()}
         metric = "L1" if case % 7 == 3 else "L2"
-        algo = ("tiled1", "tiled2", "corr", "corr")[case % 4]
-        if algo == "corr" and (metric == "L1" or s["D"] > 128 or s["C"] > 72):
+        algo = ("tiled1", "dist", "corr", "auto", "tiled2")[case % 5]   # (period 5: every kernel meets offsets -- even cases -- and the oracle leg -- every third)
+        if algo in ("corr", "dist") and (metric == "L1" or s["D"] > 128 or s["C"] > 72):
             algo = "tiled1"
         if algo == "tiled2" and s["D"] > 64:
             algo = "tiled1"
-        if case % 4 == 3 and metric == "L2":
-            algo = "auto"
+        if algo == "auto" and metric == "L1":
+            algo = "tiled1"
         if force:
             algo = force
-            if force == "corr" and (metric == "L1" or s["D"] > 128 or s["C"] > 72):
+            if force in ("corr", "dist") and (metric == "L1" or s["D"] > 128 or s["C"] > 72):
                 algo = "tiled1"   # (shapes the correlation-form kernel is not built for)
         args = (d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 8.0)
         tag = describe(case, algo, s, metric)

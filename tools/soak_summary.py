@@ -1,0 +1,51 @@
+"""profiles/r05_soak_summary.txt from gpurun_out/soak_regressions.json (written by tests/test_soak_regressions.py on the GPU box)
+and the soak logs of the round: python tools/soak_summary.py > profiles/r05_soak_summary.txt"""
+import glob
+import json
+import os
+import re
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+d = json.load(open(os.path.join(REPO, "gpurun_out", "soak_regressions.json")))
+print("""Soak evidence, round 5  (VERDICT r4 item 3; tests/test_soak_regressions.py, tools/soak.py, tools/dbg/soak_exact.py)
+=====================================================================================================================
+The six worst cases of the round-4 soaks (seeds 5150 / 5151 / 777 / 778, SOAK_OFFSET=1: per-channel means of up to 8 sigma,
+costs of 200 .. 760), evaluated over the WHOLE image: CPU oracle (float32, reference op order), the float64 evaluation of the
+same formula at the same float32 sample positions ("exact"), `direct` (gather kernel) and `auto` (distance-form kernel).
+Depth differences in metres, maximum over all pixels of all batch items; "> 1e-4": number of pixels.
+
+case            shape                                   | oracle vs exact   | direct vs oracle            | auto vs oracle                          | auto: cost noise / oracle's   unexplained
+""" .rstrip())
+for k in sorted(d):
+    r = d[k]
+    s = r["shape"]
+    sh = "%s %dx%d C=%d D=%d V=%d B=%d k=%d" % (s["pose"], s["H"], s["W"], s["C"], s["D"], s["V"], s["B"], s["k"])
+    o, di, a = r["oracle_vs_exact"], r["direct"], r["auto"]
+    print("%-15s %-39s | %.2e (%4d px) | %.2e p99.9 %.1e (%d px) | %.2e p99.9 %.1e (%3d px of %6d) | max x%.2f rms x%.2f       %.0e m" % (
+        k, sh, o["max_m"], o["over_1e4"], di["max_m"], di["p999_m"], di["over_1e4"], a["max_m"], a["p999_m"], a["over_1e4"], r["pixels"],
+        a["noise_max_ratio"], a["noise_rms_ratio"], a["unexplained_m"]))
+print("""
+Reading.
+ * Round 4's `direct` was 2.9e-4 m from the oracle at single pixels (soak62:98) although its sample positions are the
+   reference's bit for bit: it added the channels one after the other, ATen's sum(dim=1) adds runs of 16 and then the runs
+   (SumKernel.cpp cascade_sum / multi_row_sum).  With that order for the channels and for the expectation over the planes
+   (csrc/sweep_direct.hip) its cost IS the oracle's (noise ratio 1.00 in every case) and the depth is within 3.5e-5 m on
+   all six cases, candidates up to 60 m included: asserted at 1e-4 m, unscaled.
+ * The float32 reference itself is up to 3.2e-4 m from the exact value of its own formula on these inputs (soak51:12:
+   153 pixels beyond 1e-4 m).  Costs of several hundred carry 1e-4 of float32 rounding noise and the softmax turns a unit of
+   cost into up to kappa = 17 .. 28 m of expected depth.  "Within 1e-4 m of the reference" is then a statement about
+   rounding LIKE the reference, which only a kernel that copies its summation order can make (`direct` does).
+ * `auto` (distance form, fp16-split matrix products) is as accurate as the reference: its cost is 0.9 .. 2.2 times as far
+   from the exact volume as the oracle's at the worst element, 0.9 .. 1.5 times in rms -- and its depth differs from the
+   oracle's by no more than 1e-4 m plus kappa x (the two measured cost errors at that pixel): the last column is what is
+   left over, zero everywhere.  That is what the test asserts for `auto` (tests/util.py: NOISE_MAX = 3, NOISE_RMS = 2,
+   noise_and_explained()); on the BASELINE workloads (N(0,1) / peaked features, costs ~17) the plain 1e-4 m holds
+   unscaled for every kernel (tests/test_bench_sizes.py, test_hip_parity.py, test_offset_features.py).
+ * A caller who needs the reference's rounding on such inputs selects PDEPTH_ALGO_DIRECT (INTEGRATION.md).
+""")
+logs = sorted(glob.glob(os.path.join(REPO, "gpurun_out", "soak*.log")))
+print("Soak runs whose logs are in gpurun_out/ (git-ignored; last line of each):")
+for f in logs:
+    lines = [l for l in open(f).read().splitlines() if l.startswith("cases ")]
+    if lines:
+        print("  %-16s %s" % (os.path.basename(f), re.sub(r"\s+", " ", lines[-1])))
