@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--peaked", action="store_true", help="SURVEY 8(d)'s correlated feature variant (src = 0.7 shift(ref) + 0.3 noise: a peaked DPV)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-start measurement in front of the headline")
+    ap.add_argument("--preheat-ms", type=float, default=60.0, help="untimed headline steps in front of the W warm-up steps (clock ramp), ms of wall time")
     ap.add_argument("--no-secondary", action="store_true", help="skip the model_real / peaked measurements in front of the headline")
     ap.add_argument("--config", default=None, help="an experiment file in the reference's JSON schema (configs/*.json): "
                     "planes, depth range, sigma, channels and the pose family come from it; the sweep resolution stays "
@@ -141,18 +142,26 @@ def main():
             step(src)
         torch.cuda.synchronize(dev)
         pdist.barrier()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+        # HIP events on the launch stream (torch's current stream IS the stream the C ABI launches on) around the K steps.
+        # One pair for the whole region: an event between two steps is a packet of its own on the queue, and with one after
+        # every step the K steps ran 2 % (NCHW entry) to 10 % (packed entry: one kernel per step) slower than the same K
+        # calls back to back (profiles/r05_ab/bench_events_per_step.txt); PDEPTH_BENCH_TRACE=1 brings the per-step events
+        # back (diagnostics: clock ramp, stragglers).
+        trace = bool(os.environ.get("PDEPTH_BENCH_TRACE"))
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1 if trace else 2)]
         t0 = time.perf_counter()
         ev[0].record()
         for i in range(a.steps):
             out = step(src)
-            ev[i + 1].record()
+            if trace:
+                ev[i + 1].record()
+        if not trace:
+            ev[1].record()
         torch.cuda.synchronize(dev)
         pdist.barrier()
         wall = pdist.max_over_ranks(time.perf_counter() - t0, dev)
-        # HIP events on the launch stream (torch's current stream IS the stream the C ABI launches on)
-        kern_ms = sum(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps)) / a.steps
-        if os.environ.get("PDEPTH_BENCH_TRACE"):   # per-step GPU times (diagnostics: clock ramp, stragglers)
+        kern_ms = ev[0].elapsed_time(ev[-1]) / a.steps
+        if trace:
             print("per-step ms: " + " ".join("%.4f" % ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps)), file=sys.stderr)
         return out, wall, kern_ms
 
@@ -162,8 +171,10 @@ def main():
     #      (PDEPTH_BENCH_TRACE=1 prints them: 0.59 ms falling to 0.47 in round 3).
     #   2. `preflight`: the gather kernel -- the reference's op order, pinned to the oracle by the tests -- on the very batch that is
     #      timed, as a cross-check of the headline output.
-    #   3. `packed_entry`: the same step on features already in the kernels' staging layout (W + K steps).
-    #   4. the headline: W warm-up steps, K timed steps, now at sustained clocks.  `preheat_ms` = the GPU time of 1-3 in front of it.
+    #   3. `model_real`, `peaked`: SURVEY 8(d)'s secondary figures.
+    #   4. --preheat-ms of the headline step, untimed; then the headline: W warm-up steps, K timed steps, at sustained clocks.
+    #      `preheat_ms` = the wall time of 1-4 in front of it.
+    #   5. `packed_entry`: the same step on features already in the kernels' staging layout (W + K steps), right behind.
     t_pre0 = time.perf_counter()
     cold = None
     if not a.no_cold:
@@ -223,18 +234,25 @@ def main():
                 del bp, dp
         except RuntimeError as e:
             secondary["error"] = str(e)
+    # sustained clocks: from idle (and after the small / host-bound calls above) the GPU's clocks take ~50 steps of this size to
+    # settle (PDEPTH_BENCH_TRACE=1 shows the steps falling by 10 %; profiles/r05_ab/bench_clock_ramp.txt); the headline's own W warm-up
+    # steps are 2.5 ms.  60 ms of the headline step, untimed, declared in the line (`preheat`); `cold_start` is the number without it.
+    t_h0 = time.perf_counter()
+    while (time.perf_counter() - t_h0) * 1e3 < a.preheat_ms:
+        for _ in range(8):
+            step(d["src"])
+        torch.cuda.synchronize(dev)
+    preheat_ms = (time.perf_counter() - t_pre0) * 1e3
+
+    out, wall, kern_ms = timed(d["src"])
     packed_entry, out_p, kern_p = None, None, None
-    if a.algo in ("auto", "dist", "corr"):   # secondary: the same step on features already in the kernels' staging layout
+    if a.algo in ("auto", "dist", "corr"):   # secondary: the same step on features already in the kernels' staging layout, right behind
         try:
             ps = ops.pack_source(d["src"], cfg["D"], a.algo)
             out_p, _, kern_p = timed(ps)
             del ps
         except RuntimeError as e:
             packed_entry = {"error": str(e)}
-    torch.cuda.synchronize(dev)
-    preheat_ms = (time.perf_counter() - t_pre0) * 1e3
-
-    out, wall, kern_ms = timed(d["src"])
     depth = out[2]
     metrics = torch.tensor([hi - lo, kern_ms, float(depth.mean()), float(torch.isfinite(depth).all())],
                            dtype=torch.float32, device=dev)
@@ -291,7 +309,7 @@ def main():
             roof["valu_frac"] = prof["valu_wave_instr_per_launch"] / (kern_ms * 1e-3) / VALU_ISSUE_PEAK
             roof["valu_wave_instr_per_launch"] = prof["valu_wave_instr_per_launch"]
         extras = {"roofline": roof, "gather_fallback_tiles": fallback,
-                  "preheat_ms": preheat_ms, "preheat": "cold_start + preflight + model_real + peaked + packed_entry (see those objects) ran before the headline's warm-up"}
+                  "preheat_ms": preheat_ms, "preheat": "cold_start + preflight + model_real + peaked (see those objects) and %.0f ms of the headline step, untimed, ran before the headline's W warm-up steps; packed_entry right behind the headline" % a.preheat_ms}
         for k in ("model_real", "peaked"):
             if k in secondary:
                 extras[k] = secondary[k]
