@@ -170,7 +170,14 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         const int rem = iq - b_ * per_b, ti = rem >> msh;
         sub0_ = (rem & (m - 1)) * spi;
         int tile = band_first_of(q_) + ti;
-        if (rr8 == 0 && tiles_y_ % 16 == 0 && tiles_y_ * tiles_x == ntile) {
+        if (DIST_BANDS == 8 && rr8 == 0 && tiles_y_ % 8 == 0 && tiles_y_ * tiles_x == ntile) {
+            // XCD q owns band q of the image's 8 (twice the rows of the half-bands below: the source rows a band reaches
+            // beyond itself are fetched by 8 L2s per item, not 16)
+            const int hb_rows = tiles_y_ / 8;
+            const int cc = small_idx ? fdiv(ti, hb_rows) : ti / hb_rows, r_ = ti - cc * hb_rows;
+            const int col = DIST_COL_ALT ? ((cc & 1) ? tiles_x - 1 - (cc >> 1) : (cc >> 1)) : cc;
+            tile = (q_ * hb_rows + r_) * tiles_x + col;
+        } else if (rr8 == 0 && tiles_y_ % 16 == 0 && tiles_y_ * tiles_x == ntile) {
             // XCD q owns half-bands q and 8 + q of the image's 16: on a forward motion the cost of a tile grows with its
             // distance from the image centre, and this way every XCD gets the same mix; the heavier half first and, inside
             // a half, columns from both image borders inwards.  (Any static partition is valid: dry queues steal.)
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
             const int second = ti >= half_tiles ? 1 : 0, tih = ti - second * half_tiles;
             const int hbi = (q_ < 4) == (second == 0) ? q_ : 8 + q_;
             const int cc = small_idx ? fdiv(tih, hb_rows) : tih / hb_rows, r_ = tih - cc * hb_rows;
-            const int col = (cc & 1) ? tiles_x - 1 - (cc >> 1) : (cc >> 1);
+            const int col = DIST_COL_ALT ? ((cc & 1) ? tiles_x - 1 - (cc >> 1) : (cc >> 1)) : cc;
             tile = (hbi * hb_rows + r_) * tiles_x + col;
         } else if (rr8 == 0 && qq % tiles_x == 0) {   // the band is a whole number of tile rows: column by column
             const int band_rows = qq / tiles_x, tc = small_idx ? fdiv(ti, band_rows) : ti / band_rows;

@@ -25,6 +25,12 @@
 #ifndef DIST_STORE_AUX
 #define DIST_STORE_AUX 2   // nt: the outputs are written once and not read by this kernel (0, 1, 3: no difference measured)
 #endif
+#ifndef DIST_BANDS
+#define DIST_BANDS 16      // bands of tile rows per image in the XCD partition: 16 (XCD q: half-bands q and 8 + q) | 8 (band q: 7 % fewer L2 misses, 5 % slower -- the XCDs' loads differ; profiles/r05_ab/xcd_bands_8_vs_16.txt)
+#endif
+#ifndef DIST_COL_ALT
+#define DIST_COL_ALT 0     // columns of a band from both image borders inwards (1) | left to right (0: 1.2 % faster on the forward motion, 5 % fewer L2 misses)
+#endif
 #ifndef DIST_SPI1_BELOW
 #define DIST_SPI1_BELOW 2  // single pixel blocks as queue items below this many tiles per workgroup
 #endif
