@@ -14,6 +14,13 @@
 #include "dist_layout.hpp"
 #include "kernels.hpp"
 
+#ifndef PDEPTH_PACK_NT_LOAD
+#define PDEPTH_PACK_NT_LOAD 0
+#endif
+#ifndef PDEPTH_PACK_NT_STORE
+#define PDEPTH_PACK_NT_STORE 0
+#endif
+
 namespace pdepth {
 
 namespace {
@@ -25,7 +32,13 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 struct NchwSource {
     const float* base;   // view (b, v)
     int HW, W;
-    __device__ __forceinline__ float at(int c, int y, int x) const { return base[(size_t)c * HW + y * W + x]; }
+    __device__ __forceinline__ float at(int c, int y, int x) const {
+#if PDEPTH_PACK_NT_LOAD
+        return __builtin_nontemporal_load(base + (size_t)c * HW + y * W + x);
+#else
+        return base[(size_t)c * HW + y * W + x];
+#endif
+    }
 };
 // the encoder epilogue: channels < Cf from the encoder's feature maps, the rest = avg_pool2d(rgb, rate) as ATen computes it
 // (window sum in row-major order, divided by rate^2)
@@ -60,6 +73,12 @@ struct ViewSource {
 // pipe for ~17 cycles whatever it loads (tools/mb_ta.hip): the first version of this kernel (one thread per texel, its four
 // cell corners loaded separately) issued 4 loads per channel and texel, this one (ROWS + 1) / ROWS.  Where a row of the padded image ends inside a wave, the "neighbour" a lane gets belongs to the
 // next row's first texel: both lie in the ring (x = W + 1 or beyond, x = -1), both hold the zero feature vector.
+
+#if PDEPTH_PACK_NT_STORE
+#define PACK_ST(T, p, v) __builtin_nontemporal_store((v), reinterpret_cast<T*>(p))
+#else
+#define PACK_ST(T, p, v) (*reinterpret_cast<T*>(p) = (v))
+#endif
 
 __device__ __forceinline__ float wave_shl1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
@@ -151,12 +170,12 @@ __device__ __forceinline__ void pack_dist_strip(const Source& src, int C, int H,
                 if (yp0 + r >= Hp) break;
                 const size_t toff = ((size_t)(yp0 + r) * Wp + xp) * 16;
                 if (g < 4 * NCHK) {
-                    *reinterpret_cast<h8*>(out + (size_t)g * PB + toff) = hh[r];
-                    *reinterpret_cast<h8*>(out + (size_t)(4 * NCHK + g) * PB + toff) = ll[r];
+                    PACK_ST(h8, out + (size_t)g * PB + toff, hh[r]);
+                    PACK_ST(h8, out + (size_t)(4 * NCHK + g) * PB + toff, ll[r]);
                 } else {
-                    *reinterpret_cast<h8*>(out + (size_t)(8 * NCHK + 0) * PB + toff) = hh[r];
-                    *reinterpret_cast<h8*>(out + (size_t)(8 * NCHK + 1) * PB + toff) = ll[r];
-                    *reinterpret_cast<h8*>(out + (size_t)(8 * NCHK + 2) * PB + toff) = hh[r];
+                    PACK_ST(h8, out + (size_t)(8 * NCHK + 0) * PB + toff, hh[r]);
+                    PACK_ST(h8, out + (size_t)(8 * NCHK + 1) * PB + toff, ll[r]);
+                    PACK_ST(h8, out + (size_t)(8 * NCHK + 2) * PB + toff, hh[r]);
                 }
             }
         }
@@ -187,8 +206,8 @@ __device__ __forceinline__ void pack_dist_strip(const Source& src, int C, int H,
         sp[0] = pn.p1; sp[1] = pn.p2; sp[2] = pn.p3;
         sp[3] = (_Float16)dist::PIECE_C1; sp[4] = (_Float16)dist::PIECE_C2; sp[5] = (_Float16)dist::PIECE_C3;
         sp[6] = (_Float16)0.f; sp[7] = (_Float16)0.f;
-        *reinterpret_cast<h8*>(out + (size_t)(8 * NCHK + 3) * PB + toff) = sp;
-        *reinterpret_cast<v4f*>(out + (size_t)(8 * NCHK + 4) * PB + toff) = v4f{dx[r], dy0[r], dd[r], dx[r + 1]};
+        PACK_ST(h8, out + (size_t)(8 * NCHK + 3) * PB + toff, sp);
+        PACK_ST(v4f, out + (size_t)(8 * NCHK + 4) * PB + toff, (v4f{dx[r], dy0[r], dd[r], dx[r + 1]}));
     }
     if (ovf) atomicOr(item_flags, 1);
 }

@@ -412,14 +412,19 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                     // ---- the pass on a set of pixel blocks: both (mask 3), or -- when their common window does not fit the Y
                     //      buffer -- one after the other (masks 1, 2); NP == 1: mask 1
                     int mask = (1 << NP) - 1;
+                    // NP == 1: a pass whose window does not fit the Y buffer is retried as two passes of 32 planes each (psel 1:
+                    // the planes of waves 0 and 1, psel 2: those of waves 2 and 3 -- half the epipolar segment each); a half that
+                    // still does not fit is left to the direct evaluation
+                    int psel = 0;
                     for (;;) {
                         const int par = pt & 1;
+                        const bool mine = psel == 0 || (wave >> 1) == psel - 1;   // this wave's planes take part in the trip
                         // ---- row table: contributions of this thread's planes ------------------------------------------------
                         {
                             int lmin = INT_MAX, lmax = INT_MIN;
 #pragma unroll
                             for (int s = 0; s < NP; ++s) {
-                                if (!(mask >> s & 1)) continue;   // uniform
+                                if (!(mask >> s & 1) || !mine) continue;   // uniform
                                 int run = INT_MIN, rmin = 0, rmax = 0;   // consecutive planes of equal row are folded first
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
@@ -510,6 +515,15 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                             mask = 1;
                             continue;
                         }
+                        if (NP == 1 && !fits && psel == 0 && L.iflag == 0 && DIST_SPLIT_PLANES && DIST_FORCE_DIRECT == -2) {
+                            PDEPTH_LDS_BARRIER();   // (every wave has read the tables: behind the barrier wave 1 cleans them)
+                            if (wave == 1) {
+                                L.cmin[par][lane] = INT_MAX; L.cmax[par][lane] = INT_MIN;
+                                if (lane == 0) { L.ired[par][0] = INT_MAX; L.ired[par][1] = INT_MIN; }
+                            }
+                            psel = 1;
+                            continue;
+                        }
                         const int rowoff = 16 * fb - lo;    // slot of texel x of this lane's row = x + rowoff
                         const bool go = fits && nb > 0;
                         DSTAMP(5)   // operands from LDS, row table cut into blocks
@@ -568,7 +582,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                             for (int s = 0; s < NP; ++s)
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
-                                    const bool has = fits && (mask >> s & 1) && cell[s][j] != NO_CELL;
+                                    const bool has = fits && mine && (mask >> s & 1) && cell[s][j] != NO_CELL;
                                     const int r = has ? cell_y(cell[s][j]) - yb : 0;
                                     const int o0 = __builtin_amdgcn_ds_bpermute(4 * r, rowoff), o1 = __builtin_amdgcn_ds_bpermute(4 * r + 4, rowoff);
                                     const int cxx = cell_x(cell[s][j]);
@@ -629,10 +643,11 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
 #pragma unroll
                         for (int s = 0; s < NP; ++s) {
                             if (!(mask >> s & 1)) continue;   // uniform
-                            if (!fits) {
-                                failmask[s] |= 1u << (v * NH + h);   // (evaluated directly behind the view loop)
+                            if (!fits) {   // (evaluated directly behind the view loop: bits 2 (v NH + h), + 1 = the lower / upper 32 planes)
+                                failmask[s] |= (psel == 0 ? 3u : 1u << (psel - 1)) << (2 * (v * NH + h));
                                 continue;
                             }
+                            if (!mine) continue;
                             const float* yr = &L.Ys[s][n * XSTRIDE];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
@@ -655,6 +670,10 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                             }
                         }
                         DSTAMP(9)   // combine
+                        if (NP == 1 && psel == 1) {   // (the upper planes of a pass that did not fit whole; the next trip's barrier in
+                            psel = 2;                 //  front of its matrix phase keeps its Y writes behind this trip's reads)
+                            continue;
+                        }
                         if (NP == 2 && mask == 1) {   // (the second block of a pair that did not fit together)
                             PDEPTH_LDS_BARRIER();     // every wave is done with the Y buffer of the first
                             mask = 2;
@@ -675,8 +694,9 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 const bool ovf = (L.iflag & 1) != 0;
 #pragma unroll 1
                 for (int vh = 0; vh < V * NH; ++vh) {
-                    if (!(failmask[s] >> vh & 1u)) continue;
+                    if (!(failmask[s] >> (2 * vh) & 3u)) continue;
                     if (tid == 0) ++n_direct;
+                    if (!(failmask[s] >> (2 * vh + (wave >> 1)) & 1u)) continue;   // (this wave's half of the planes went through)
                     const int v = vh / NH, h = vh - v * NH;
                     ViewXform xf;
 #pragma unroll
@@ -771,7 +791,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                     if (kq == 0) *reinterpret_cast<v4f*>(&L.red[s][(wave * 16 + n) * 4]) = v4f{mx, ssum, esum, 0.0f};
                 }
                 DSTAMP(10)   // cost stores, partial softmax
-                PDEPTH_LDS_BARRIER();
+                if (!DIST_ABL_NOB3) PDEPTH_LDS_BARRIER();
 #pragma unroll
                 for (int s = 0; s < NP; ++s) {
                     float M = -INFINITY;

@@ -31,6 +31,15 @@
 #ifndef DIST_COL_ALT
 #define DIST_COL_ALT 0     // columns of a band from both image borders inwards (1) | left to right (0: 1.2 % faster on the forward motion, 5 % fewer L2 misses)
 #endif
+// 1: a pass whose texel blocks do not fit LDS is retried as two passes of 32 planes before the direct evaluation.  Built,
+// parity-green, off: config 5 (6 809 of 524 288 passes direct) 5.23 -> 5.13 ms per call with 10 registers spilled, 5.92 ms
+// without spills (193 registers: two workgroups per CU); the headline 2-3 % slower (profiles/r05_ab/split_planes.txt)
+#ifndef DIST_ABL_NOB3
+#define DIST_ABL_NOB3 0    // timing only (wrong results): no barrier in front of the merge of the waves' softmax parts
+#endif
+#ifndef DIST_SPLIT_PLANES
+#define DIST_SPLIT_PLANES 0
+#endif
 #ifndef DIST_SPI1_BELOW
 #define DIST_SPI1_BELOW 2  // single pixel blocks as queue items below this many tiles per workgroup
 #endif
