@@ -213,6 +213,9 @@ def main():
         try:
             secondary["model_real"] = {"shape": "C=%d D=%d 64x128 V=%d pose=%s (the reference sweeps a 256x512 frame at 1/4 resolution: "
                                                 "models/models.py:518)" % (cfg["C"], cfg["D"], cfg["V"], a.pose),
+                                       "what": "us_per_call = HIP events around 50 back-to-back calls of the Python binding (at B=1 the host's call, ~26 us, is "
+                                               "longer than the kernel: profiles/r05_small_sweeps.rocprofv3.txt has the kernels' own durations); "
+                                               "frac = algorithmic bytes / us_per_call / 8 TB/s",
                                        "B1_nchw": small(1, "nchw"), "B1_packed": small(1, "packed"),
                                        "B4_nchw": small(4, "nchw"), "B4_packed": small(4, "packed")}
             if not a.peaked:

@@ -13,12 +13,13 @@
 //
 //   how.  The 64 (128) planes of the 16 pixels are spread over the 256 threads of a workgroup -- thread (pixel n, tq) owns
 //       planes 4 tq .. 4 tq + 3 of each group of 64 (a PASS = one source view x one group of 64 planes):
-//         positions   bit-faithful sample positions (geometry.hpp), two planes per packed instruction;
+//         positions   bit-faithful sample positions (geometry.hpp; scalar fp32 instructions: wave_util.hpp says why not packed);
 //         row table   per source row the run of texels any sample touches: LDS min / max, rows indexed modulo 64; barrier;
 //                     EVERY wave cuts the runs into blocks of 16 texels for itself (a prefix sum over the rows in registers:
 //                     no serial phase, no block list in LDS; a sample finds its slot with two ds_bpermute);
 //         Y           wave w multiplies blocks w, w + 4, ...: a block's texel operands are 2 NCHK + 1 16-byte loads per lane
-//                     whose only per-block address part is a scalar offset; two blocks in flight; Y[pixel][slot] to LDS; the
+//                     whose only per-block address part is a scalar offset; one register set, every chunk refilled with the
+//                     next block's right behind its last multiplication; Y[pixel][slot] to LDS; the
 //                     Q records of the block's 16 cells straight from memory to LDS (buffer_load ... lds); barrier;
 //         combine     per (pixel, plane): 4 Y values, 5 Q values, the bilinear weights;
 //         epilogue    cost store; log-softmax over D and E[d]: per wave partial (max, sum, sum d) of each pixel, merged

@@ -53,9 +53,22 @@ class PacknetModel(nn.Module):
                 f"packnet: the PackNet network is not part of this package (SURVEY.md section 2); pass {what} to PacknetModel / "
                 "attach_networks -- the sweep + DPV head runs without it: models.packnet_head.PacknetHead")
 
-    @torch.no_grad()
+    def _inference_only(self):
+        """The sweep kernels have no backward: this host object is the reference's model for `--eval`.  The reference class is
+        trainable; a caller who runs this one with autograd on and trainable networks attached is told so, once."""
+        if torch.is_grad_enabled() and not getattr(self, "_warned_no_grad", False) and any(p.requires_grad for p in self.parameters()):
+            import warnings
+            warnings.warn("pdepth_amd PacknetModel runs under torch.no_grad(): the fused sweep + DPV head has no backward; the attached "
+                          "networks receive no gradients (inference / --eval only)", RuntimeWarning, stacklevel=3)
+            self._warned_no_grad = True
+
     def forward_encoder(self, model_input):
         """-> (BV = log_softmax(cost volumes) [B,D,h,w], feature_set[view] = list of raw feature maps [B,c_i,h_i,w_i])"""
+        self._inference_only()
+        with torch.no_grad():
+            return self._forward_encoder(model_input)
+
+    def _forward_encoder(self, model_input):
         self._need("base_encoder")
         rgb = model_input["rgb"]
         BV, _depth = self.head(model_input)
@@ -67,9 +80,10 @@ class PacknetModel(nn.Module):
         self.head.encoder.feats_raw = None
         return BV, feature_set
 
-    @torch.no_grad()
     def forward(self, input):
-        BV_cur, feature_set = self.forward_encoder(input)
-        self._need("base_decoder")
-        BV_cur_refined = self.base_decoder(torch.exp(BV_cur), feature_set[-1])
+        self._inference_only()
+        with torch.no_grad():
+            BV_cur, feature_set = self._forward_encoder(input)
+            self._need("base_decoder")
+            BV_cur_refined = self.base_decoder(torch.exp(BV_cur), feature_set[-1])
         return {"output": [BV_cur], "output_refined": [BV_cur_refined], "flow": None, "flow_refined": None}

@@ -50,6 +50,10 @@ class PacknetHead(nn.Module):
                 src, ref = ops.pack_views(enc, flat.float(), V1, len(model_input["d_candi"]))
             except ops.UnsupportedShape:   # a shape the packed sweep does not take; other native failures propagate
                 src = ref = None
+                # the encoder's output is reused (the fallback used to run the encoder a second time)
+                rate = int(flat.shape[3] / enc.shape[3])
+                both = torch.cat((enc, F.avg_pool2d(flat.float(), rate)), dim=1)
+                feat_imgs_all = both.view(B, V1, both.shape[1], both.shape[2], both.shape[3])
         if src is None:
             if feat_imgs_all is None:
                 feat_imgs_all = self.features(model_input["rgb"])

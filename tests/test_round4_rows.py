@@ -233,10 +233,16 @@ def test_image_sizes_that_are_not_a_multiple_of_the_map(monkeypatch):
     with pytest.raises(ops.UnsupportedShape):
         ops.pack_views(feat, torch.randn(4, 3, 64, 99, device=DEV), 2, 32)      # 99 = 4 * 24 + 3 columns
     inp = harness.move_input(synth.make_model_input(21, B=2, V=1, H=64, W=96, D=32, pose="mono"), DEV)
-    head = PacknetHead(synth.default_cfg("default"), encoder=lambda x: enc(x)[:, :, :16, :24])
+    calls = [0]
+
+    def counted(x):
+        calls[0] += 1
+        return enc(x)[:, :, :16, :24]
+    head = PacknetHead(synth.default_cfg("default"), encoder=counted)
     BV0, depth0 = head(inp)                                                                          # exact multiple: the epilogue kernel
     rgb = torch.nn.functional.pad(inp["rgb"], (0, 3, 0, 2))                                         # 66 x 99: the same pooled image
     BV1, depth1 = head(dict(inp, rgb=rgb))
+    assert calls[0] == 2, "the fallback must reuse the encoder's output (ADVICE r4), not run the encoder again"
     # (the encoder sees the padded frame: compare against the chain the reference runs on that frame)
     with torch.no_grad():
         flat = rgb.reshape(-1, 3, 66, 99)
