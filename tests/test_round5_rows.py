@@ -51,9 +51,7 @@ def test_float64_yardstick_agrees_with_the_oracle():
 
 def test_packnet_host_object_says_that_it_is_inference_only():
     from pdepth_amd.models import get_model
-    m = get_model(synth.default_cfg("packnet"), 0) if hasattr(synth, "default_cfg") else None
-    if m is None:
-        pytest.skip("no packnet configuration")
+    m = get_model(synth.default_cfg(model_name="packnet"), 0)
     m.attach_networks(torch.nn.Conv2d(3, 4, 1), torch.nn.Conv2d(4, 4, 1))
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
