@@ -207,8 +207,13 @@ def main():
                         raise
         if ORACLE and metric == "L2" and case % 3 == 0:
             worst_o = max(worst_o, oracle_leg(b, d, args, algo, tag, np.random.default_rng(77 + case)))
-        ca = ops.sweep_cost(*args, feat_dist=metric, algo=algo).cpu().numpy()
+        ca_dev = ops.sweep_cost(*args, feat_dist=metric, algo=algo)
         fb += _native.fallback_tiles(s["B"], s["H"], s["W"])
+        if case % 4 == 1:   # repeatability: the same call again, bit for bit (LDS min / max tables, queues, stealing: no order dependence)
+            cb_dev = ops.sweep_cost(*args, feat_dist=metric, algo=algo)
+            if not torch.equal(ca_dev.nan_to_num(), cb_dev.nan_to_num()):
+                print(tag, "a second call gives different bits")
+        ca = ca_dev.cpu().numpy()
         cd = ops.sweep_cost(*args, feat_dist=metric, algo="direct").cpu().numpy()
         n += 1
         if not np.array_equal(np.isnan(ca), np.isnan(cd)):
