@@ -103,7 +103,6 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     constexpr int CPAD = 32 * NCHK + 8;            // channels, padded
     constexpr int MCH = (CPAD + 15) / 16;          // channels per thread of the cooperative reference load
     constexpr int MAXB = NP == 2 ? DIST_MAXB_NP2 : (NH == 1 ? DIST_MAXB1 : DIST_MAXB2);
-    constexpr int BPW = (MAXB + 3) / 4;            // blocks per wave and pass
     constexpr int NC = 4 * NH;                     // planes (costs) per thread and pixel block
     constexpr int QPL = 8 * NCHK + 4;              // the Q plane
     typedef DistLds<MAXB, NAC, NP> Lds;
