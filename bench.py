@@ -171,10 +171,11 @@ def main():
     #      (PDEPTH_BENCH_TRACE=1 prints them: 0.59 ms falling to 0.47 in round 3).
     #   2. `preflight`: the gather kernel -- the reference's op order, pinned to the oracle by the tests -- on the very batch that is
     #      timed, as a cross-check of the headline output.
-    #   3. `model_real`, `peaked`: SURVEY 8(d)'s secondary figures.
+    #   3. `model_real`: SURVEY 8(d)'s 64x128 figures.
     #   4. --preheat-ms of the headline step, untimed; then the headline: W warm-up steps, K timed steps, at sustained clocks.
     #      `preheat_ms` = the wall time of 1-4 in front of it.
-    #   5. `packed_entry`: the same step on features already in the kernels' staging layout (W + K steps), right behind.
+    #   5. `packed_entry`: the same step on features already in the kernels' staging layout (W + K steps), right behind; then
+    #      `peaked`: the headline call on SURVEY 8(d)'s correlated features (W + K steps).
     t_pre0 = time.perf_counter()
     cold = None
     if not a.no_cold:
@@ -218,23 +219,6 @@ def main():
                                                "frac = algorithmic bytes / us_per_call / 8 TB/s",
                                        "B1_nchw": small(1, "nchw"), "B1_packed": small(1, "packed"),
                                        "B4_nchw": small(4, "nchw"), "B4_packed": small(4, "packed")}
-            if not a.peaked:
-                bp = synth.make_batch(2, hi - lo, first_item=lo, **dict(cfg, peaked=True))
-                dp = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in bp.items()}
-                fp = lambda: ops.sweep_dpv(dp["ref"], dp["src"], dp["K"], dp["R"], dp["t"], dp["rays"], dp["cxcy"], dc, sigma, algo=a.algo)
-                for _ in range(a.warmup):
-                    fp()
-                torch.cuda.synchronize(dev)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(a.steps):
-                    fp()
-                e1.record()
-                torch.cuda.synchronize(dev)
-                ms = e0.elapsed_time(e1) / a.steps
-                secondary["peaked"] = {"ms_per_step": ms, "value": (hi - lo) / (ms * 1e-3),
-                                       "what": "the headline call on SURVEY 8(d)'s correlated features (src = 0.7 shift(ref) + 0.3 noise)"}
-                del bp, dp
         except RuntimeError as e:
             secondary["error"] = str(e)
     # sustained clocks: from idle (and after the small / host-bound calls above) the GPU's clocks take ~50 steps of this size to
@@ -256,6 +240,27 @@ def main():
             del ps
         except RuntimeError as e:
             packed_entry = {"error": str(e)}
+    if "model_real" in secondary and not a.peaked:   # the peaked variant of the headline call, at sustained clocks like the headline
+        try:
+            if not a.peaked:
+                bp = synth.make_batch(2, hi - lo, first_item=lo, **dict(cfg, peaked=True))
+                dp = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in bp.items()}
+                fp = lambda: ops.sweep_dpv(dp["ref"], dp["src"], dp["K"], dp["R"], dp["t"], dp["rays"], dp["cxcy"], dc, sigma, algo=a.algo)
+                for _ in range(a.warmup):
+                    fp()
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.steps):
+                    fp()
+                e1.record()
+                torch.cuda.synchronize(dev)
+                ms = e0.elapsed_time(e1) / a.steps
+                secondary["peaked"] = {"ms_per_step": ms, "value": (hi - lo) / (ms * 1e-3),
+                                       "what": "the headline call on SURVEY 8(d)'s correlated features (src = 0.7 shift(ref) + 0.3 noise)"}
+                del bp, dp
+        except RuntimeError as e:
+            secondary["error"] = str(e)
     depth = out[2]
     metrics = torch.tensor([hi - lo, kern_ms, float(depth.mean()), float(torch.isfinite(depth).all())],
                            dtype=torch.float32, device=dev)
@@ -312,7 +317,7 @@ def main():
             roof["valu_frac"] = prof["valu_wave_instr_per_launch"] / (kern_ms * 1e-3) / VALU_ISSUE_PEAK
             roof["valu_wave_instr_per_launch"] = prof["valu_wave_instr_per_launch"]
         extras = {"roofline": roof, "gather_fallback_tiles": fallback,
-                  "preheat_ms": preheat_ms, "preheat": "cold_start + preflight + model_real + peaked (see those objects) and %.0f ms of the headline step, untimed, ran before the headline's W warm-up steps; packed_entry right behind the headline" % a.preheat_ms}
+                  "preheat_ms": preheat_ms, "preheat": "cold_start + preflight + model_real (see those objects) and %.0f ms of the headline step, untimed, ran before the headline's W warm-up steps; packed_entry and peaked right behind the headline" % a.preheat_ms}
         for k in ("model_real", "peaked"):
             if k in secondary:
                 extras[k] = secondary[k]
