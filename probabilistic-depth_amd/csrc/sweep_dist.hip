@@ -57,6 +57,7 @@ struct DistArgs {
     const float* stats;
     int* queue;
     int tiles_x, ntile, spi;
+    int tail;   // (spi == 4) tiles at the end of every XCD queue that are handed out as four single pixel blocks
 };
 #define KARG(type, field) kernarg_at<type>(offsetof(DistArgs, field))
 
@@ -140,12 +141,20 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         const int nt = KARG(int, ntile), qq = nt >> 3, rr8 = nt & 7;
         return q < rr8 ? q * (qq + 1) : rr8 * (qq + 1) + (q - rr8) * qq;
     };
+    // items of queue q: whole tiles (spi == 4), the last `tail` of them as four single pixel blocks each -- the end of a launch
+    // is then a pass long, not a tile long (a workgroup that finds the queues dry has at most one pass's neighbours to wait
+    // for); or single pixel blocks throughout (spi == 1: small problems)
+    auto items_of = [&](int q) {
+        const int ntq = band_tiles_of(q) * KARG(int, a.B);
+        if (da.spi != 4) return 4 * ntq;
+        const int tl = min(ntq, da.tail);
+        return ntq + 3 * tl;
+    };
     bool own_done = false;
     auto steal = [&]() -> int {   // (queue << 28) | index in the queue, or -1: every queue is exhausted
         int* queue = KARG(int*, queue);
-        const int mB = (4 / da.spi) * KARG(int, a.B);
         for (int j = 1; j < 8; ++j) {
-            const int q = (xcd + j) & 7, nq = band_tiles_of(q) * mB;
+            const int q = (xcd + j) & 7, nq = items_of(q);
             if (*(volatile int*)&queue[q] >= nq) continue;
             const int got = atomicAdd(&queue[q], 1);
             if (got < nq) return (q << 28) | got;
@@ -153,22 +162,29 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         return -1;
     };
     auto resolve = [&](int got) -> int {
-        const int n_own = band_tiles_of(xcd) * (4 / da.spi) * KARG(int, a.B);
+        const int n_own = items_of(xcd);
         if (!own_done && got < n_own) return (xcd << 28) | got;
         own_done = true;
         return steal();
     };
     // floor(nn / dd) for 0 <= nn < 2^22, 0 < dd (an integer divide costs ~40 dependent instructions)
     auto fdiv = [](int nn, int dd) { return (int)(((float)nn + 0.5f) * __builtin_amdgcn_rcpf((float)dd)); };
-    auto decode = [&](int item, int& b_, int& tx_, int& ty_, int& sub0_) {
-        const int ntile = KARG(int, ntile), tiles_x = KARG(int, tiles_x), spi = da.spi;
-        const int m = 4 / spi, msh = spi == 1 ? 2 : 0, qq = ntile >> 3, rr8 = ntile & 7;
-        const bool small_idx = (long long)ntile * m * KARG(int, a.B) < (1ll << 22);
+    auto decode = [&](int item, int& b_, int& tx_, int& ty_, int& sub0_, int& spi_) {
+        const int ntile = KARG(int, ntile), tiles_x = KARG(int, tiles_x);
+        const int qq = ntile >> 3, rr8 = ntile & 7;
+        const bool small_idx = (long long)ntile * 4 * KARG(int, a.B) < (1ll << 22);
         const int tiles_y_ = (H + 3) / 4;
-        const int q_ = item >> 28, iq = item & 0x0fffffff, band_tiles = band_tiles_of(q_), per_b = band_tiles * m;
-        b_ = small_idx ? fdiv(iq, per_b) : iq / per_b;
-        const int rem = iq - b_ * per_b, ti = rem >> msh;
-        sub0_ = (rem & (m - 1)) * spi;
+        const int q_ = item >> 28, iq = item & 0x0fffffff, band_tiles = band_tiles_of(q_);
+        // index of the tile in the queue's order (batch item by batch item), first pixel block and number of blocks of the item
+        int tidx = iq >> 2;
+        sub0_ = iq & 3; spi_ = 1;
+        if (da.spi == 4) {
+            const int ntq = band_tiles * KARG(int, a.B), whole = ntq - min(ntq, da.tail);
+            if (iq < whole) { tidx = iq; sub0_ = 0; spi_ = 4; }
+            else { tidx = whole + ((iq - whole) >> 2); sub0_ = (iq - whole) & 3; }
+        }
+        b_ = small_idx ? fdiv(tidx, band_tiles) : tidx / band_tiles;
+        const int ti = tidx - b_ * band_tiles;
         int tile = band_first_of(q_) + ti;
         if (DIST_BANDS == 8 && rr8 == 0 && tiles_y_ % 8 == 0 && tiles_y_ * tiles_x == ntile) {
             // XCD q owns band q of the image's 8 (twice the rows of the half-bands below: the source rows a band reaches
@@ -212,7 +228,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
 
     for (;;) {
         if (tid == 0) {
-            const int n_own = band_tiles_of(xcd) * (4 / da.spi) * KARG(int, a.B);
+            const int n_own = items_of(xcd);
             L.item[slot_par] = one_each ? (first && got_own < n_own ? (xcd << 28) | got_own : -1) : resolve(got_own);
         }
         first = false;
@@ -222,8 +238,8 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         if (item < 0) break;
         if (tid == 0 && !one_each && !own_done) got_own = atomicAdd(&KARG(int*, queue)[xcd], 1);
         DSTAMP(0)   // queue: publish + barrier
-        int b, tx, ty, sub0;
-        decode(item, b, tx, ty, sub0);
+        int b, tx, ty, sub0, spi;
+        decode(item, b, tx, ty, sub0, spi);
         // per BATCH item, for every wave: scaled channel means, the views' homography terms, the camera constants, the item's
         // flags (visible behind the barrier in front of the first block's centring).  Items come out of the queues batch item
         // by batch item: the tables are rebuilt a few times per launch, not once per tile.
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         }
         const bool wide = b < 64 ? L.wide[b] != 0 : false;
         bool item_ready = !new_b;
-        const int spi = da.spi;   // (NP == 2: 4, the launcher sees to it)
+        // (spi: pixel blocks of this item; NP == 2: always 4, the launcher sees to it)
 
         for (int it = 0; it < spi / NP; ++it) {
             // the pixel blocks of this trip: NP == 1: block sub0 + it; NP == 2: blocks (0, 1), (2, 3) of a tile of four 16x1
@@ -861,8 +877,12 @@ hipError_t launch_np(const SweepArgs& a, const char* packed, const float* stats,
     DistArgs da;
     da.a = a; da.packed = packed; da.stats = stats; da.queue = queue; da.tiles_x = tiles_x; da.ntile = tiles;
     da.spi = spi;
+    da.tail = spi == 4 && NP == 1 ? (int)((nblk / 8) * DIST_TAIL_PCT / 100) : 0;   // in workgroups per XCD
     const long long need = 8ll * ((tiles + 7) / 8) * (4 / da.spi) * a.B;   // a workgroup per item of the largest XCD band, times 8
-    if (need <= DIST_ONE_EACH_X * nblk) nblk = need;
+    if (need <= DIST_ONE_EACH_X * nblk) {
+        nblk = need;
+        da.tail = 0;   // (a workgroup per item: no queue, nothing to split)
+    }
     (void)nblk_cap;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, stream, da);
     return hipGetLastError();

@@ -40,6 +40,12 @@
 #ifndef DIST_SPLIT_PLANES
 #define DIST_SPLIT_PLANES 0
 #endif
+// tiles at the end of every XCD queue that are handed out as four single pixel blocks, in percent of the workgroups per XCD:
+// the end of a launch is then a pass long instead of a tile long.  0: 0.408 / 0.377 ms, 100: 0.402 / 0.363, 200: 0.404 / 0.369,
+// 400: 0.409 / 0.379 (profiles/r05_ab/queue_tail_as_single_blocks.txt)
+#ifndef DIST_TAIL_PCT
+#define DIST_TAIL_PCT 100
+#endif
 #ifndef DIST_SPI1_BELOW
 #define DIST_SPI1_BELOW 2  // single pixel blocks as queue items below this many tiles per workgroup
 #endif
