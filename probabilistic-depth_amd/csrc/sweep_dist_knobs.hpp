@@ -50,7 +50,11 @@
 #define DIST_SPI1_BELOW 2  // single pixel blocks as queue items below this many tiles per workgroup
 #endif
 #ifndef DIST_ONE_EACH_X
-#define DIST_ONE_EACH_X 2  // no queue up to this many items per resident workgroup
+// no queue -- a workgroup per item, the hardware's dispatcher instead of the per-XCD counters -- up to this many items per
+// resident workgroup.  Packed entry, us per call at 2 / 6 (profiles/r05_ab/workgroup_per_item_range.txt): B=4 64x128 60.7 / 45.5,
+// B=8 64x128 84.6 / 78.5, B=1 128x256 58.9 / 45.9, B=4 128x256 119 / 102, B=1 256x512 185 / 159, B=2 256x512 229 / 214;
+// beyond: B=3 256x512 (8 x) 294 persistent / 307, B=4 256x512 (10.7 x) 401 / 435
+#define DIST_ONE_EACH_X 6
 #endif
 #ifndef DIST_GUARD_RATIO
 #define DIST_GUARD_RATIO 1.7f   // the guard: energy of the centred features / their spread at a lag of 16 texels, and ...
