@@ -17,8 +17,8 @@
 #define DIST_OCC1 2        // minimum waves per SIMD asked of the compiler at D <= 64: 164 registers, nothing spilled, three
 #endif                     //    workgroups per CU (4: 128 registers, 23 of them spilled: slower)
 #ifndef DIST_OCC2
-#define DIST_OCC2 2
-#endif
+#define DIST_OCC2 3        // ... at D > 64: without the bound the allocator takes 170 registers (two workgroups per CU: config 5 20 % slower),
+#endif                     //    with it 165, nothing spilled
 #ifndef DIST_XPRIO
 #define DIST_XPRIO 1       // wave priority in the matrix phase
 #endif
