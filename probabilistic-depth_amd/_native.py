@@ -379,7 +379,11 @@ def fallback_tiles(B, H, W, gather_flag=1):
         return 0
     n = B * ((W + 15) // 16) * ((H + 3) // 4)
     layout = _queue_slot(B, H, W, 56)
-    direct = _queue_slot(B, H, W, 59) if layout == LAYOUT_DIST16 else (_queue_slot(B, H, W, 54) if layout == LAYOUT_C4_CENTRED else 0)
+    if layout == LAYOUT_DIST16:   # (nonce << 20) | count; a count tagged by another call's nonce is stale (kernels.hpp: DIST_NONCE_SLOT)
+        tagged, nonce = _queue_slot(B, H, W, 59), _queue_slot(B, H, W, 60)
+        direct = (tagged & 0xFFFFF) if nonce != 0 and (tagged >> 20) == nonce else 0
+    else:
+        direct = _queue_slot(B, H, W, 54) if layout == LAYOUT_C4_CENTRED else 0
     return int((_last_workspace[: 4 * n].view(torch.int32) == gather_flag).sum().item()) + direct
 
 

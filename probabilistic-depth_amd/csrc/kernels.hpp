@@ -53,6 +53,10 @@ constexpr int STATS_LAG_PX = 16;
 constexpr int LAYOUT_SLOT = 56;
 constexpr int LAYOUT_C4 = 1, LAYOUT_C4_CENTRED = 2, LAYOUT_DIST16 = 3;   // (0: nothing packed yet)
 constexpr int DIST_DONE_SLOT = 57, DIST_DIRECT_SLOT = 58, DIST_DIRECT_LAST_SLOT = 59;   // sweep_dist.hip: as the CORR_ slots
+// DIST_DIRECT_LAST_SLOT holds (nonce << 20) | count, DIST_NONCE_SLOT the nonce of the last call: a count whose nonce is another
+// call's reads as 0 (where every workgroup runs one item there is no counter of finished workgroups to reset anything by: 2 048
+// returning atomics on one address were a quarter of such a launch)
+constexpr int DIST_NONCE_SLOT = 60;
 constexpr int PICK_SKIP_IF_SET = 1, PICK_RUN_IF_SET = 2;
 
 // First statement of a sweep kernel on a packed source: does the workspace hold the layout this kernel reads?  If not (a C

@@ -31,6 +31,7 @@
 //       workgroup to leave zeroes the queue counters: a call on an already packed source is this one launch.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <climits>
 #include <cstdlib>
 
@@ -58,6 +59,7 @@ struct DistArgs {
     int* queue;
     int tiles_x, ntile, spi;
     int tail;   // (spi == 4) tiles at the end of every XCD queue that are handed out as four single pixel blocks
+    int nonce;  // 1 .. 2047, another one per launch: tags the diagnostics count of this call (kernels.hpp: DIST_NONCE_SLOT)
 };
 #define KARG(type, field) kernarg_at<type>(offsetof(DistArgs, field))
 
@@ -844,17 +846,35 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         for (int i = 0; i < 12; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(int*, queue) + 8) + i, stamp_acc[i]);
 #endif
 
-    // the last workgroup to leave zeroes the queue counters: the next call on this workspace needs no clearing launch
+    // Leaving.  With a queue: the last workgroup to leave zeroes the queue counters (the next call on this workspace needs no
+    // clearing launch) and publishes the call's count of directly evaluated pixel blocks.  Without one (a workgroup per item)
+    // nothing was counted that needs resetting, and a returning atomic per workgroup on one address is what such a launch
+    // cannot afford: a workgroup with direct passes -- rare -- adds them to the published count itself, tagged with the call's
+    // nonce (a count left by another call is replaced).
     if (tid == 0) {
         int* queue = KARG(int*, queue);
-        if (n_direct) atomicAdd(&queue[DIST_DIRECT_SLOT], n_direct);
-        const int done = atomicAdd(&queue[DIST_DONE_SLOT], 1);
-        if (done == (int)gridDim.x - 1) {
-            const int nd = atomicAdd(&queue[DIST_DIRECT_SLOT], 0);
-            for (int q = 0; q < 8; ++q) queue[q] = 0;
-            queue[DIST_DONE_SLOT] = 0;
-            queue[DIST_DIRECT_SLOT] = 0;
-            queue[DIST_DIRECT_LAST_SLOT] = nd;   // diagnostics: pixel blocks of this call evaluated directly
+        const int nonce = KARG(int, nonce);
+        if (blockIdx.x == 0) queue[DIST_NONCE_SLOT] = nonce;
+        if (one_each) {
+            if (n_direct) {
+                int old = atomicAdd(&queue[DIST_DIRECT_LAST_SLOT], 0);
+                for (;;) {
+                    const int nv = (old >> 20) == nonce ? old + n_direct : (nonce << 20) | n_direct;
+                    const int seen = atomicCAS(&queue[DIST_DIRECT_LAST_SLOT], old, nv);
+                    if (seen == old) break;
+                    old = seen;
+                }
+            }
+        } else {
+            if (n_direct) atomicAdd(&queue[DIST_DIRECT_SLOT], n_direct);
+            const int done = atomicAdd(&queue[DIST_DONE_SLOT], 1);
+            if (done == (int)gridDim.x - 1) {
+                const int nd = atomicAdd(&queue[DIST_DIRECT_SLOT], 0);
+                for (int q = 0; q < 8; ++q) queue[q] = 0;
+                queue[DIST_DONE_SLOT] = 0;
+                queue[DIST_DIRECT_SLOT] = 0;
+                queue[DIST_DIRECT_LAST_SLOT] = (nonce << 20) | nd;   // diagnostics: pixel blocks of this call evaluated directly
+            }
         }
     }
 }
@@ -877,6 +897,8 @@ hipError_t launch_np(const SweepArgs& a, const char* packed, const float* stats,
     DistArgs da;
     da.a = a; da.packed = packed; da.stats = stats; da.queue = queue; da.tiles_x = tiles_x; da.ntile = tiles;
     da.spi = spi;
+    static std::atomic<unsigned> launches{0};
+    da.nonce = (int)(launches.fetch_add(1) % 2047u) + 1;
     da.tail = spi == 4 && NP == 1 ? (int)((nblk / 8) * DIST_TAIL_PCT / 100) : 0;   // in workgroups per XCD
     const long long need = 8ll * ((tiles + 7) / 8) * (4 / da.spi) * a.B;   // a workgroup per item of the largest XCD band, times 8
     if (need <= DIST_ONE_EACH_X * nblk) {
