@@ -111,6 +111,10 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     typedef DistLds<MAXB, NAC, NP> Lds;
     constexpr int XSTRIDE = Lds::XSTRIDE;
     __shared__ Lds L;
+#ifdef DIST_STAMPS   // (from the workgroup's first instruction: its start-up counts as "queue")
+    unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#endif
     if (poison_on_foreign_layout(da.a, da.queue, LAYOUT_DIST16)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -216,10 +220,6 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     const bool one_each = (long long)gridDim.x >= 8ll * ((KARG(int, ntile) + 7) / 8) * (4 / da.spi) * KARG(int, a.B);
     __syncthreads();
 
-#ifdef DIST_STAMPS
-    unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
-#endif
     int slot_par = 0;
     int pt = 0;           // running table-pass counter: selects the set of row-table arrays
     int n_direct = 0;     // (thread 0) pixel blocks evaluated directly

@@ -7,7 +7,7 @@ import pdepth_amd
 from pdepth_amd import ops, synth, _native
 NAMES = ["queue", "set-up+loads issued", "positions", "table+centring", "B1", "operands+scan", "slots+X", "wait Q", "B2", "combine", "stores+softmax", "B3+merge+stores"]
 for pose in sys.argv[1:] or ["mono", "stereo"]:
-    B, C, D, H, W, V = 4, 67, 64, 256, 512, 1
+    B, C, D, H, W, V = (int(x) for x in os.environ.get("STAMP_SHAPE", "4,67,64,256,512,1").split(","))
     b = synth.make_batch(2, B, C=C, D=D, H=H, W=W, V=V, pose=pose)
     d = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
     dc = ops.d_candi_tensor(d["d_candi"], "cuda")
