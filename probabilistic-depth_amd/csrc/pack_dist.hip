@@ -84,9 +84,14 @@ __device__ __forceinline__ float wave_shl1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
-template <int NCHK, int ROWS, typename Source>
+// SPLIT (small images: fewer waves than SIMDs -- a wave's chain of 4 NCHK + 1 rounds is then the whole kernel): the four waves of
+// a workgroup share one run of 64 texels, wave w converting channel groups w, w + 4, w + 8; the sums over the channels (N and
+// the neighbour differences) are added up through LDS (`part`: [4][6][64] floats) in the order of the waves.  Which mode runs
+// depends on the image size alone, so the pack of an NCHW call, pdepth_pack_source_f32 and the encoder epilogue agree.
+template <int NCHK, int ROWS, bool SPLIT, typename Source>
 __device__ __forceinline__ void pack_dist_strip(const Source& src, int C, int H, int W, long long e0, const float* mus, float sc,
-                                                char* __restrict__ out, int* __restrict__ item_flags) {
+                                                char* __restrict__ out, int* __restrict__ item_flags, float* part = nullptr) {
+    static_assert(!SPLIT || ROWS == 1, "the split mode is written for one row per strip");
     const int lane = threadIdx.x & 63;
     const int Wp = dist::wp(W), Hp = dist::hp(H);
     const long long PB = dist::plane_bytes(H, W);
@@ -181,16 +186,39 @@ __device__ __forceinline__ void pack_dist_strip(const Source& src, int C, int H,
         }
     };
     float va[NV], vb[NV];
-    issue(0, va);
-#pragma unroll 1
-    for (int g = 0; g < NG; g += 2) {
-        if (g + 1 < NG) issue(g + 1, vb);
+    if (SPLIT) {
+        const int g0 = threadIdx.x >> 6;   // this wave's groups: g0, g0 + 4, g0 + 8 (NG <= 9)
+        if (g0 < NG) issue(g0, va);
+        if (g0 + 4 < NG) issue(g0 + 4, vb);
         __builtin_amdgcn_sched_barrier(0);
-        finish(g, va);
-        if (g + 1 < NG) {
-            if (g + 2 < NG) issue(g + 2, va);
+        if (g0 < NG) finish(g0, va);
+        if (g0 + 8 < NG) issue(g0 + 8, va);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g0 + 4 < NG) finish(g0 + 4, vb);
+        if (g0 + 8 < NG) finish(g0 + 8, va);
+        // the waves' sums, added in the order of the waves by wave 0 (the same bits whatever the timing)
+        float* mine = part + (size_t)g0 * 6 * 64 + lane;
+        mine[0] = n[0]; mine[64] = dx[0]; mine[128] = dx[1]; mine[192] = dy0[0]; mine[256] = dd[0]; mine[320] = ovf ? 1.0f : 0.0f;
+        __syncthreads();
+        if (g0 != 0) return;
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float* o = part + (size_t)w * 6 * 64 + lane;
+            n[0] = n[0] + o[0]; dx[0] = dx[0] + o[64]; dx[1] = dx[1] + o[128]; dy0[0] = dy0[0] + o[192]; dd[0] = dd[0] + o[256];
+            ovf = ovf || o[320] != 0.0f;
+        }
+    } else {
+        issue(0, va);
+#pragma unroll 1
+        for (int g = 0; g < NG; g += 2) {
+            if (g + 1 < NG) issue(g + 1, vb);
             __builtin_amdgcn_sched_barrier(0);
-            finish(g + 1, vb);
+            finish(g, va);
+            if (g + 1 < NG) {
+                if (g + 2 < NG) issue(g + 2, va);
+                __builtin_amdgcn_sched_barrier(0);
+                finish(g + 1, vb);
+            }
         }
     }
     if (e >= nelem) return;
@@ -219,6 +247,12 @@ __device__ __forceinline__ void pack_dist_strip(const Source& src, int C, int H,
 // what the small shapes want (64 x 128: 17 us against 21 / 31 us).
 constexpr int PACK_ROWS = 1;
 
+// the split mode (above): images of up to PDEPTH_PACK_SPLIT_BELOW padded texels
+#ifndef PDEPTH_PACK_SPLIT_BELOW
+#define PDEPTH_PACK_SPLIT_BELOW 16384
+#endif
+inline bool pack_dist_split(int H, int W) { return (long long)dist::hp(H) * dist::wp(W) <= PDEPTH_PACK_SPLIT_BELOW; }
+
 __host__ __device__ inline int pack_dist_waves(int H, int W, int ROWS) {
     return (int)(((long long)((dist::hp(H) + ROWS - 1) / ROWS) * dist::wp(W) + 63) / 64);
 }
@@ -228,6 +262,7 @@ __device__ __forceinline__ float load_item_scale(const float* __restrict__ stats
     const float* st = stats + (size_t)b * STATS_STRIDE;
     const int t = threadIdx.x;
     float am = t < STATS_VAR ? st[STATS_AMAX + t] : 0.0f;
+    const float mean_t = t < dist::MAX_C + 8 ? st[t] : 0.0f;   // (asked for with the maxima: one round trip, not two)
     if (t < 64) {
         if (t + 64 < STATS_VAR) am = fmaxf(am, st[STATS_AMAX + t + 64]);
 #pragma unroll
@@ -236,7 +271,7 @@ __device__ __forceinline__ float load_item_scale(const float* __restrict__ stats
     }
     __syncthreads();
     const float sc = ldexpf(1.0f, dist::scale_exponent(scratch[0]));
-    if (t < dist::MAX_C + 8) mus[t] = st[t] * sc;   // (mu = 0 beyond C)
+    if (t < dist::MAX_C + 8) mus[t] = mean_t * sc;   // (mu = 0 beyond C)
     __syncthreads();
     return sc;
 }
@@ -251,7 +286,7 @@ __device__ __forceinline__ void reset_queue(int* __restrict__ queue) {
     if (threadIdx.x < 64) queue[threadIdx.x] = threadIdx.x == LAYOUT_SLOT ? LAYOUT_DIST16 : 0;
 }
 
-template <int NCHK, int ROWS>
+template <int NCHK, int ROWS, bool SPLIT>
 __global__ __launch_bounds__(256) void pack_dist_kernel(const float* __restrict__ src, long long bstride, long long vstride, int V, int C,
                                                         int H, int W, char* __restrict__ out, int* __restrict__ flags, int nflags,
                                                         int* queue, float* __restrict__ stats) {
@@ -261,16 +296,17 @@ __global__ __launch_bounds__(256) void pack_dist_kernel(const float* __restrict_
     __shared__ float mus[dist::MAX_C + 8];
     __shared__ float scratch[4];
     const float sc = load_item_scale(stats, b, mus, scratch);
-    const int wave = xcd_block_order(gridDim.x, blockIdx.x) * 4 + (threadIdx.x >> 6);
+    __shared__ float part[SPLIT ? 4 * 6 * 64 : 1];
+    const int wave = SPLIT ? (int)blockIdx.x : xcd_block_order(gridDim.x, blockIdx.x) * 4 + (threadIdx.x >> 6);   // (SPLIT: the workgroup's run of texels)
     if (wave >= pack_dist_waves(H, W, ROWS)) return;
     NchwSource s{src + (size_t)b * bstride + (size_t)(bv % V) * vstride, H * W, W};
-    pack_dist_strip<NCHK, ROWS>(s, C, H, W, (long long)wave * 64, mus, sc, out + (size_t)bv * dist::view_bytes(C, H, W),
-                          reinterpret_cast<int*>(stats + (size_t)b * STATS_STRIDE + STATS_FLAGS));
+    pack_dist_strip<NCHK, ROWS, SPLIT>(s, C, H, W, (long long)wave * 64, mus, sc, out + (size_t)bv * dist::view_bytes(C, H, W),
+                                       reinterpret_cast<int*>(stats + (size_t)b * STATS_STRIDE + STATS_FLAGS), part);
 }
 
 // the encoder epilogue (sweep_pack.hip: pack_views_kernel says what it replaces): views 0..V-1 of an item into the packed
 // layout, view V (the reference view) as NCHW [B, Cf + 3, H, W]
-template <int NCHK, int ROWS>
+template <int NCHK, int ROWS, bool SPLIT>
 __global__ __launch_bounds__(256) void pack_views_dist_kernel(const float* __restrict__ feat, const float* __restrict__ rgb, int V, int Cf,
                                                               int H, int W, int rate, int IH, int IW, char* __restrict__ out,
                                                               float* __restrict__ ref_out, int* __restrict__ flags, int nflags, int* queue,
@@ -288,13 +324,24 @@ __global__ __launch_bounds__(256) void pack_views_dist_kernel(const float* __res
         if (pix >= HW) return;
         const int y = pix / W, x = pix - y * W;
         float* o = ref_out + (size_t)b * C * HW + pix;
-        for (int c = 0; c < C; ++c) o[(size_t)c * HW] = s.at(c, y, x);
+        // (sixteen channels' loads in flight, then their stores: a load behind every store is a chain of C round trips --
+        //  at 64x128, where a CU holds one such wave, that chain was the kernel: 21 us)
+#pragma unroll 1
+        for (int c0 = 0; c0 < C; c0 += 16) {
+            float t[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t[j] = s.at(min(c0 + j, C - 1), y, x);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (c0 + j < C) o[(size_t)(c0 + j) * HW] = t[j];
+        }
         return;
     }
-    const int wave = xcd_block_order(gridDim.x, blockIdx.x) * 4 + (threadIdx.x >> 6);
+    __shared__ float part[SPLIT ? 4 * 6 * 64 : 1];
+    const int wave = SPLIT ? (int)blockIdx.x : xcd_block_order(gridDim.x, blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (wave >= pack_dist_waves(H, W, ROWS)) return;
-    pack_dist_strip<NCHK, ROWS>(s, C, H, W, (long long)wave * 64, mus, sc, out + (size_t)(b * V + v) * dist::view_bytes(C, H, W),
-                          reinterpret_cast<int*>(stats + (size_t)b * STATS_STRIDE + STATS_FLAGS));
+    pack_dist_strip<NCHK, ROWS, SPLIT>(s, C, H, W, (long long)wave * 64, mus, sc, out + (size_t)(b * V + v) * dist::view_bytes(C, H, W),
+                                       reinterpret_cast<int*>(stats + (size_t)b * STATS_STRIDE + STATS_FLAGS), part);
 }
 
 }  // namespace
@@ -308,10 +355,11 @@ hipError_t launch_pack_dist(const SweepArgs& a, void* workspace, hipStream_t str
     hipError_t e = launch_feature_stats(a, stats, stream);
     if (e != hipSuccess) return e;
     const int nflags = (int)(sweep_ws_flag_only_bytes(a.B, a.H, a.W) / sizeof(int));
-    dim3 grid((pack_dist_waves(a.H, a.W, PACK_ROWS) + 3) / 4, a.B * a.V);
-#define PDEPTH_PACK_DIST(N, R) hipLaunchKernelGGL((pack_dist_kernel<N, R>), grid, dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V, a.C, \
+    const bool split = pack_dist_split(a.H, a.W);
+    dim3 grid(split ? pack_dist_waves(a.H, a.W, PACK_ROWS) : (pack_dist_waves(a.H, a.W, PACK_ROWS) + 3) / 4, a.B * a.V);
+#define PDEPTH_PACK_DIST(N, R) hipLaunchKernelGGL((pack_dist_kernel<N, R, SPLIT_>), grid, dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V, a.C, \
                                                   a.H, a.W, packed, flags, nflags, queue, stats)
-#define PDEPTH_PACK_DIST_R(N) PDEPTH_PACK_DIST(N, PACK_ROWS)
+#define PDEPTH_PACK_DIST_R(N) do { if (split) { constexpr bool SPLIT_ = true; PDEPTH_PACK_DIST(N, PACK_ROWS); } else { constexpr bool SPLIT_ = false; PDEPTH_PACK_DIST(N, PACK_ROWS); } } while (0)
     switch (dist::nchk(a.C)) {
         case 0: PDEPTH_PACK_DIST_R(0); break;
         case 1: PDEPTH_PACK_DIST_R(1); break;
@@ -332,10 +380,12 @@ hipError_t launch_pack_views_dist(const SweepArgs& a, const float* feat, const f
     if (e != hipSuccess) return e;
     const int nflags = (int)(sweep_ws_flag_only_bytes(a.B, a.H, a.W) / sizeof(int));
     // (source views: 4 waves of 64 x ROWS texels per block; the reference view: 256 pixels per block)
-    dim3 grid(std::max((pack_dist_waves(a.H, a.W, PACK_ROWS) + 3) / 4, (a.H * a.W + 255) / 256), a.B * (a.V + 1));
-#define PDEPTH_PACK_VIEWS_DIST(N, R) hipLaunchKernelGGL((pack_views_dist_kernel<N, R>), grid, dim3(256), 0, stream, feat, rgb, a.V, a.C - 3, a.H, a.W, \
+    const bool split = pack_dist_split(a.H, a.W);
+    dim3 grid(std::max(split ? pack_dist_waves(a.H, a.W, PACK_ROWS) : (pack_dist_waves(a.H, a.W, PACK_ROWS) + 3) / 4, (a.H * a.W + 255) / 256),
+              a.B * (a.V + 1));
+#define PDEPTH_PACK_VIEWS_DIST(N, R) hipLaunchKernelGGL((pack_views_dist_kernel<N, R, SPLIT_>), grid, dim3(256), 0, stream, feat, rgb, a.V, a.C - 3, a.H, a.W, \
                                                         rate, img_h, img_w, packed, ref_out, flags, nflags, queue, stats)
-#define PDEPTH_PACK_VIEWS_DIST_R(N) PDEPTH_PACK_VIEWS_DIST(N, PACK_ROWS)
+#define PDEPTH_PACK_VIEWS_DIST_R(N) do { if (split) { constexpr bool SPLIT_ = true; PDEPTH_PACK_VIEWS_DIST(N, PACK_ROWS); } else { constexpr bool SPLIT_ = false; PDEPTH_PACK_VIEWS_DIST(N, PACK_ROWS); } } while (0)
     switch (dist::nchk(a.C)) {
         case 0: PDEPTH_PACK_VIEWS_DIST_R(0); break;
         case 1: PDEPTH_PACK_VIEWS_DIST_R(1); break;

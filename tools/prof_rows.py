@@ -58,6 +58,9 @@ elif case == "correlation":
 elif case == "correlation_general":
     x1, x2 = torch.randn(4, 64, 64, 128, device="cuda"), torch.randn(4, 64, 64, 128, device="cuda")
     f = lambda: (pdepth_amd._native.correlation_forward(x1, x2, 5, 3, 4, 2, 3, 1), pdepth_amd._native.correlation_forward(x1.half(), x2.half(), 4, 1, 4, 1, 1, 1))
+elif case == "pack_views_small":   # the encoder epilogue at the model-real size (B=1: one source view + the reference view of a 256x512 frame)
+    feat, rgb = torch.randn(2, 64, 64, 128, device="cuda"), torch.rand(2, 3, 256, 512, device="cuda")
+    f = lambda: ops.pack_views(feat, rgb, 2, 64)
 elif case == "pack_views":
     feat, rgb = torch.randn(8, 64, 256, 512, device="cuda"), torch.rand(8, 3, 1024, 2048, device="cuda")
     f = lambda: ops.pack_views(feat, rgb, 2, 64)

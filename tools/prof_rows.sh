@@ -7,7 +7,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/rows_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-for case in cfg5 cfg5_packed cfg3 cfg2_tiled model_real model_real_packed reduce_ex dpv_fuse ufield correlation correlation_general pack_views; do
+for case in cfg5 cfg5_packed cfg3 cfg2_tiled model_real model_real_packed reduce_ex dpv_fuse ufield correlation correlation_general pack_views pack_views_small; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/$case -- python3 tools/prof_rows.py $case 20 > $out/$case.log 2>&1 || true
   echo "== $case (python3 tools/prof_rows.py $case 20; 23 calls incl. warm-up)"
   python3 - $out/$case <<'PY'
