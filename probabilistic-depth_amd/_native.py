@@ -180,8 +180,43 @@ def _dev(t: torch.Tensor, name: str) -> int:
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(dev) -> int:
+    """hipStream_t of torch's current stream on `dev` (the raw getter where this torch has it: the Stream object costs 4 us)."""
+    if _raw_stream is not None and dev.index is not None:
+        return _raw_stream(dev.index)
     return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _on_device:
+    """torch.cuda.device(dev) only when another device is current (the context manager costs more than a small sweep's launch)."""
+
+    def __init__(self, dev):
+        self.ctx = None if dev.index is None or torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
+
+
+_desc_cache = {}   # (B, V, C, D, H, W, metric, algo) -> (workspace bytes, staging layout): two library calls saved per sweep
+
+
+def _workspace_and_layout(lib, desc):
+    key = (desc.B, desc.V, desc.C, desc.D, desc.H, desc.W, desc.metric, desc.algo)
+    hit = _desc_cache.get(key)
+    if hit is None:
+        hit = (lib.pdepth_sweep_workspace_bytes(ctypes.byref(desc)), lib.pdepth_sweep_source_layout(ctypes.byref(desc)))
+        if len(_desc_cache) < 4096:
+            _desc_cache[key] = hit
+    return hit
 
 
 def _inner_contiguous(t: torch.Tensor, n_inner: int) -> bool:
@@ -322,11 +357,11 @@ def sweep(ref, src, K, R, t, rays, cxcy, d_candi, sigma, metric=METRIC_L2, algo=
                      ref.stride(0) if B > 1 else C * H * W,
                      (src.stride(0) if B > 1 else V * C * H * W) if not packed else V * C * H * W,
                      (src.stride(1) if V > 1 else C * H * W) if not packed else C * H * W)
-    ws_bytes = lib.pdepth_sweep_workspace_bytes(ctypes.byref(desc))
+    ws_bytes, layout = _workspace_and_layout(lib, desc)
     if packed:
         if ws_bytes == 0 or packed.ws.numel() < ws_bytes:
             raise RuntimeError("sweep: this shape / algorithm does not run on a packed source")
-        if lib.pdepth_sweep_source_layout(ctypes.byref(desc)) != packed.layout:
+        if layout != packed.layout:
             raise RuntimeError("sweep: the source was packed for another kernel family (layout %d, centred: %s); pack it with "
                                "the algo / n_planes / metric it will be swept with" % (packed.layout, packed.centred))
         ws = packed.ws
@@ -335,7 +370,7 @@ def sweep(ref, src, K, R, t, rays, cxcy, d_candi, sigma, metric=METRIC_L2, algo=
     cost = torch.empty((B, D, H, W), dtype=torch.float32, device=dev) if want_cost else None
     logp = torch.empty((B, D, H, W), dtype=torch.float32, device=dev) if want_logp else None
     depth = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_depth else None
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         if packed:
             rc = lib.pdepth_sweep_dpv_packed_f32(
                 ctypes.byref(desc), ctypes.byref(cam), _dev(ref, "ref"), _dev(d_candi, "d_candi"),
