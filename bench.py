@@ -232,6 +232,7 @@ def main():
     # sustained clocks: from idle (and after the small / host-bound calls above) the GPU's clocks take ~50 steps of this size to
     # settle (PDEPTH_BENCH_TRACE=1 shows the steps falling by 10 %; profiles/r05_ab/bench_clock_ramp.txt); the headline's own W warm-up
     # steps are 2.5 ms.  60 ms of the headline step, untimed, declared in the line (`preheat`); `cold_start` is the number without it.
+    pdist.barrier()   # (N > 1: rank 0 ran the secondary measurements above; every rank starts its preheat now, not a second before)
     t_h0 = time.perf_counter()
     while (time.perf_counter() - t_h0) * 1e3 < a.preheat_ms:
         for _ in range(8):
@@ -250,21 +251,20 @@ def main():
             packed_entry = {"error": str(e)}
     if dp is not None:   # the peaked variant of the headline call, at sustained clocks like the headline
         try:
-            if not a.peaked:
-                fp = lambda: ops.sweep_dpv(dp["ref"], dp["src"], dp["K"], dp["R"], dp["t"], dp["rays"], dp["cxcy"], dc, sigma, algo=a.algo)
-                for _ in range(a.warmup):
-                    fp()
-                torch.cuda.synchronize(dev)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(a.steps):
-                    fp()
-                e1.record()
-                torch.cuda.synchronize(dev)
-                ms = e0.elapsed_time(e1) / a.steps
-                secondary["peaked"] = {"ms_per_step": ms, "value": (hi - lo) / (ms * 1e-3),
-                                       "what": "the headline call on SURVEY 8(d)'s correlated features (src = 0.7 shift(ref) + 0.3 noise)"}
-                del dp
+            fp = lambda: ops.sweep_dpv(dp["ref"], dp["src"], dp["K"], dp["R"], dp["t"], dp["rays"], dp["cxcy"], dc, sigma, algo=a.algo)
+            for _ in range(a.warmup):
+                fp()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.steps):
+                fp()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1) / a.steps
+            secondary["peaked"] = {"ms_per_step": ms, "value": (hi - lo) / (ms * 1e-3),
+                                   "what": "the headline call on SURVEY 8(d)'s correlated features (src = 0.7 shift(ref) + 0.3 noise)"}
+            del dp
         except RuntimeError as e:
             secondary["error"] = str(e)
     depth = out[2]
