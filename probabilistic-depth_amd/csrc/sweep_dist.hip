@@ -739,7 +739,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                             const float w00 = ey * ex, w01 = ey * fwj, w10 = fnj * ex, w11 = fnj * fwj;
                             const size_t t00 = ((size_t)(cyy + dist::RING) * Wp + cxx + dist::RING) * 16;
                             float part = 0.0f;
-#pragma unroll 1
+#pragma unroll DIST_DIRECT_UNROLL
                             for (int g = 0; g < 4 * NCHK + 1; ++g) {
                                 // planes of the group's high and low parts; the pixel's: chunk g >> 2 (tail: 2 NCHK), K slice g & 3 (tail: 0 | 2)
                                 const bool tail = g == 4 * NCHK;

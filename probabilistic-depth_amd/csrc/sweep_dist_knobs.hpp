@@ -37,6 +37,11 @@
 #ifndef DIST_ABL_NOB3
 #define DIST_ABL_NOB3 0    // timing only (wrong results): no barrier in front of the merge of the waves' softmax parts
 #endif
+// channel groups of the direct evaluation whose taps are in flight together (3 / 9: 168 registers under a launch bound of 3
+// waves per SIMD, no scratch -- and config 5, 1.3 % of whose passes go this way, 8 % slower)
+#ifndef DIST_DIRECT_UNROLL
+#define DIST_DIRECT_UNROLL 1
+#endif
 #ifndef DIST_SPLIT_PLANES
 #define DIST_SPLIT_PLANES 0
 #endif
