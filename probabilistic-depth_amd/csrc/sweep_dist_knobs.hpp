@@ -2,10 +2,10 @@
 #pragma once
 
 #ifndef DIST_MAXB1
-#define DIST_MAXB1 22      // blocks of 16 texels a pass can take, D <= 64
+#define DIST_MAXB1 34      // blocks of 16 texels a pass can take, D <= 64 (22 until the end of round 5: the headline is indifferent, wide baselines evaluate fewer passes directly; three workgroups per CU either way)
 #endif
 #ifndef DIST_MAXB2
-#define DIST_MAXB2 32      // ... D > 64
+#define DIST_MAXB2 34      // ... D > 64 (the most that leaves three workgroups per CU: 35 -> two; config 5: 32 -> 34 = 6 809 -> 1 482 direct passes, 5.58 -> 5.03 ms per call)
 #endif
 #ifndef DIST_MAXB_NP2
 #define DIST_MAXB_NP2 26   // ... of a pass over two pixel blocks (D <= 64): 75 KB of LDS per workgroup, two per CU

@@ -182,7 +182,7 @@ def test_passes_that_do_not_fit_are_evaluated_directly(dev):
     passes take the direct evaluation inside the same launch (no tile flags, no second kernel) and meet the same bounds;
     the diagnostics counter says that it happened."""
     total = {"auto": 0, "corr": 0}
-    for seed, (H, W, D, V) in enumerate(((96, 200, 64, 1), (120, 260, 128, 2))):
+    for seed, (H, W, D, V) in enumerate(((192, 400, 64, 1), (120, 260, 128, 2))):
         b = synth.make_batch(900 + seed, 1, C=35, D=D, H=H, W=W, V=V, pose="wide")
         g = torch.Generator().manual_seed(seed)
         mu = (torch.rand(35, generator=g) * 2 - 1) * 3.0
