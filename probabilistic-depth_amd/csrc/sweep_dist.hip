@@ -879,6 +879,12 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     }
 }
 
+// 1 .. 2047, another one per launch of any instantiation (kernels.hpp: DIST_NONCE_SLOT)
+inline int next_nonce() {
+    static std::atomic<unsigned> launches{0};
+    return (int)(launches.fetch_add(1) % 2047u) + 1;
+}
+
 template <int NCHK, int NH, int NP>
 hipError_t launch_np(const SweepArgs& a, const char* packed, const float* stats, int* queue, int tiles_x, int tiles, int spi, long long nblk_cap,
                      hipStream_t stream) {
@@ -897,8 +903,7 @@ hipError_t launch_np(const SweepArgs& a, const char* packed, const float* stats,
     DistArgs da;
     da.a = a; da.packed = packed; da.stats = stats; da.queue = queue; da.tiles_x = tiles_x; da.ntile = tiles;
     da.spi = spi;
-    static std::atomic<unsigned> launches{0};
-    da.nonce = (int)(launches.fetch_add(1) % 2047u) + 1;
+    da.nonce = next_nonce();
     da.tail = spi == 4 && NP == 1 ? (int)((nblk / 8) * DIST_TAIL_PCT / 100) : 0;   // in workgroups per XCD
     const long long need = 8ll * ((tiles + 7) / 8) * (4 / da.spi) * a.B;   // a workgroup per item of the largest XCD band, times 8
     if (need <= DIST_ONE_EACH_X * nblk) {
