@@ -220,6 +220,13 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     const bool one_each = (long long)gridDim.x >= 8ll * ((KARG(int, ntile) + 7) / 8) * (4 / da.spi) * KARG(int, a.B);
     __syncthreads();
 
+    // Persistent grid: the workgroups a CU starts with would run their first passes in lockstep -- every phase of all three at
+    // once on the same pipes; the second and third begin 5 and 11 us later (they drift apart by themselves within a few
+    // passes; -0.9 % / -1.8 % of the headline launch, profiles/r05_ab/staggered_start.txt).  Not where a workgroup runs one item.
+    if (DIST_STAGGER && !one_each) {
+        const int slot = ((int)blockIdx.x >> 3) / 32 % 3;
+        for (int i = 0; i < slot * DIST_STAGGER; ++i) __builtin_amdgcn_s_sleep(100);
+    }
     int slot_par = 0;
     int pt = 0;           // running table-pass counter: selects the set of row-table arrays
     int n_direct = 0;     // (thread 0) pixel blocks evaluated directly

@@ -51,6 +51,9 @@
 #ifndef DIST_TAIL_PCT
 #define DIST_TAIL_PCT 100
 #endif
+#ifndef DIST_STAGGER
+#define DIST_STAGGER 2       // start-up stagger of the persistent workgroups, in sleeps of 6 400 cycles per CU slot (0: off; 1 / 3 / 4: less)
+#endif
 #ifndef DIST_SPI1_BELOW
 #define DIST_SPI1_BELOW 2  // single pixel blocks as queue items below this many tiles per workgroup
 #endif
