@@ -49,6 +49,8 @@ namespace {
 
 using namespace wv;
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 
 constexpr int DIST_MAXV = 8;   // source views whose homography terms a workgroup keeps in LDS
 
@@ -70,22 +72,22 @@ struct DistArgs {
 // for every term (DIST_EXACT_EXP restores it).
 __device__ __forceinline__ float dist_exp(float x) {
     if (DIST_EXACT_EXP) return exp_nonpos(x);
-    return __builtin_amdgcn_exp2f(fmaxf(x, -1000.0f) * 1.44269502162933349609375f);
+    return __builtin_amdgcn_exp2f((x < -1000.0f ? -1000.0f : x) * 1.44269502162933349609375f);   // (a NaN passes through, as in exp_nonpos)
 }
 
-template <int MAXB, int NAC, int NP>
+template <int MAXB, int NAC>
 struct __attribute__((aligned(16))) DistLds {
     static constexpr int XSTRIDE = MAXB * 16 + 4;   // floats per pixel of the Y buffer (stride / 4 odd: conflict-free b128 stores)
-    float Ys[NP][16 * XSTRIDE];  // Y[pixel block][pixel][slot]
+    float Ys[16 * XSTRIDE];      // Y[pixel][slot]
     float Qs[(MAXB + 3) / 4 * 256 + 8];   // Q record (Dx0, Dy0, Dd, Dx1) per slot (moved in groups of four blocks: whole groups)
-    _Float16 Bs[NP][NAC * 4 * 16 * 8];   // pixel-side operands of a block's 16 pixels: [chunk][kq][pixel][8], -2 x (high | low) parts
-    float rp[NP][4 * 16 * 2];    // per wave and pixel: partial |r'|^2, |r|^2 (scaled)
+    _Float16 Bs[NAC * 4 * 16 * 8];   // pixel-side operands of the block's 16 pixels: [chunk][kq][pixel][8], -2 x (high | low) parts
+    float rp[4 * 16 * 2];        // per wave and pixel: partial |r'|^2, |r|^2 (scaled)
     float mus[dist::MAX_C + 8];  // channel means x scale of the batch item in work
     float xf[DIST_MAXV * 12];    // per view: K@R (9), K@t (3)
     float cst[8];                // cx, cy, 1/cx, 1/cy, W/2, H/2, scale, 2^(-2e)/sigma
-    float red[NP][4 * 16 * 4];   // epilogue exchange: (max, sum, sum d) per wave and pixel
+    float red[4 * 16 * 4];       // epilogue exchange: (max, sum, sum d) per wave and pixel
     float dcl[128];              // depth candidates
-    int cmin[2][64], cmax[2][64];   // per cell row (modulo 64): min / max x0; two sets, alternating by table pass
+    int ctab[2][64 * 2];         // per cell row (modulo 64): (min, max) x0; two sets, alternating by pass
     int ired[2][2];              // min / max cell row of the pass; two sets
     int brow[MAXB + 2];          // per block of the pass: its row (written alike by every wave, read back by the same wave)
     int item[2];                 // work item: current / next
@@ -94,21 +96,20 @@ struct __attribute__((aligned(16))) DistLds {
 };
 
 // NCHK = chunks of 32 channels (dist_layout.hpp); NH = groups of 64 planes (ceil(D / 64): 1 or 2), each a pass of its own per
-// view: thread (n, tq) owns planes 64 h + 4 tq .. + 3 of pass h; NP = pixel blocks per pass (1 | 2).
+// view: thread (n, tq) owns planes 64 h + 4 tq .. + 3 of pass h.
 //
-// NP = 2: a pass covers TWO blocks of 16 pixels -- the 8x2 blocks of a tile stacked to 8x4, or two 16x1 rows -- that share
-// one row table, one cut into texel blocks and every texel load (a block's operands are multiplied against both pixel
-// blocks: 8.2 instead of 12.2 texel blocks per 16 pixels on the forward-motion pose).  The machinery of a pass (set-up,
-// table, scan, three barriers) is what two thirds of the time of a pass went to at NP = 1; here it serves 2048 samples.
-template <int NCHK, int NH, int NP>
+// Everything a pass needs beyond its own registers lives in LDS or is re-read from the kernel-argument segment where it is
+// used (KARG): the kernel keeps no spilled scalar registers (tests/test_isa_guard.py).  Round 5's build of this kernel carried
+// 120 of them -- 14 % of its vector instructions were v_readlane / v_writelane traffic.
+template <int NCHK, int NH>
 __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_dist_kernel(DistArgs da) {
     constexpr int NAC = 2 * NCHK + 1;              // operand chunks of a texel / pixel: high[NCHK], low[NCHK], tail
-    constexpr int CPAD = 32 * NCHK + 8;            // channels, padded
-    constexpr int MCH = (CPAD + 15) / 16;          // channels per thread of the cooperative reference load
-    constexpr int MAXB = NP == 2 ? DIST_MAXB_NP2 : (NH == 1 ? DIST_MAXB1 : DIST_MAXB2);
-    constexpr int NC = 4 * NH;                     // planes (costs) per thread and pixel block
+    constexpr int MP = NCHK + 1;                   // rounds of the cooperative reference load: 16 channel PAIRS per round (the last: the tail's 4)
+    constexpr int MAXB = NH == 1 ? DIST_MAXB1 : DIST_MAXB2;
+    constexpr int NC = 4 * NH;                     // planes (costs) per thread
     constexpr int QPL = 8 * NCHK + 4;              // the Q plane
-    typedef DistLds<MAXB, NAC, NP> Lds;
+    constexpr int NS = NH == 1 ? DIST_SETS1 : DIST_SETS2;   // texel operand register sets = blocks of a wave in flight
+    typedef DistLds<MAXB, NAC> Lds;
     constexpr int XSTRIDE = Lds::XSTRIDE;
     __shared__ Lds L;
 #ifdef DIST_STAMPS   // (from the workgroup's first instruction: its start-up counts as "queue")
@@ -118,19 +119,14 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     if (poison_on_foreign_layout(da.a, da.queue, LAYOUT_DIST16)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int D = KARG(int, a.D), H = KARG(int, a.H), W = KARG(int, a.W), V = KARG(int, a.V), C = KARG(int, a.C);
-    const int Wp = dist::wp(W);
-    const int PB = (int)dist::plane_bytes(H, W);   // (sweep_dist_supports: a view's planes lie below 2^31 bytes)
 
     {
         const float* dc = KARG(const float*, a.d_candi);
+        const int D = KARG(int, a.D);
         for (int k = tid; k < 64 * NH; k += 256) L.dcl[k] = dc[min(k, D - 1)];
     }
-    if (tid < 64) {
-        L.cmin[0][tid] = INT_MAX; L.cmax[0][tid] = INT_MIN;
-        L.cmin[1][tid] = INT_MAX; L.cmax[1][tid] = INT_MIN;
-        L.wide[tid] = 1;
-    }
+    if (tid < 128) { L.ctab[0][tid] = (tid & 1) ? INT_MIN : INT_MAX; L.ctab[1][tid] = (tid & 1) ? INT_MIN : INT_MAX; }
+    if (tid < 64) L.wide[tid] = 1;
     if (tid < 2) { L.ired[tid][0] = INT_MAX; L.ired[tid][1] = INT_MIN; }
     __syncthreads();
     // Shape of the pixel blocks of a batch item: 16x1 where the epipolar lines of view 0 run along the source rows (a
@@ -140,7 +136,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     // ---- work queue (per XCD) -------------------------------------------------------------------------------------------
     // Workgroups are dealt round-robin over the 8 XCDs; XCD q owns the tiles of band q (its own queue counter), so that
     // neighbouring tiles, whose source texels overlap, meet in that XCD's L2.  A workgroup whose queue is exhausted takes
-    // items of the others.  m = items per tile (1: a tile's four pixel blocks in sequence; 4: one block per item).
+    // items of the others.
     const int xcd = blockIdx.x & 7;
     auto band_tiles_of = [&](int q) { const int nt = KARG(int, ntile); return (nt >> 3) + (q < (nt & 7) ? 1 : 0); };
     auto band_first_of = [&](int q) {
@@ -152,8 +148,8 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     // for); or single pixel blocks throughout (spi == 1: small problems)
     auto items_of = [&](int q) {
         const int ntq = band_tiles_of(q) * KARG(int, a.B);
-        if (da.spi != 4) return 4 * ntq;
-        const int tl = min(ntq, da.tail);
+        if (KARG(int, spi) != 4) return 4 * ntq;
+        const int tl = min(ntq, KARG(int, tail));
         return ntq + 3 * tl;
     };
     bool own_done = false;
@@ -176,7 +172,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     // floor(nn / dd) for 0 <= nn < 2^22, 0 < dd (an integer divide costs ~40 dependent instructions)
     auto fdiv = [](int nn, int dd) { return (int)(((float)nn + 0.5f) * __builtin_amdgcn_rcpf((float)dd)); };
     auto decode = [&](int item, int& b_, int& tx_, int& ty_, int& sub0_, int& spi_) {
-        const int ntile = KARG(int, ntile), tiles_x = KARG(int, tiles_x);
+        const int ntile = KARG(int, ntile), tiles_x = KARG(int, tiles_x), H = KARG(int, a.H);
         const int qq = ntile >> 3, rr8 = ntile & 7;
         const bool small_idx = (long long)ntile * 4 * KARG(int, a.B) < (1ll << 22);
         const int tiles_y_ = (H + 3) / 4;
@@ -184,8 +180,8 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         // index of the tile in the queue's order (batch item by batch item), first pixel block and number of blocks of the item
         int tidx = iq >> 2;
         sub0_ = iq & 3; spi_ = 1;
-        if (da.spi == 4) {
-            const int ntq = band_tiles * KARG(int, a.B), whole = ntq - min(ntq, da.tail);
+        if (KARG(int, spi) == 4) {
+            const int ntq = band_tiles * KARG(int, a.B), whole = ntq - min(ntq, KARG(int, tail));
             if (iq < whole) { tidx = iq; sub0_ = 0; spi_ = 4; }
             else { tidx = whole + ((iq - whole) >> 2); sub0_ = (iq - whole) & 3; }
         }
@@ -202,7 +198,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         } else if (rr8 == 0 && tiles_y_ % 16 == 0 && tiles_y_ * tiles_x == ntile) {
             // XCD q owns half-bands q and 8 + q of the image's 16: on a forward motion the cost of a tile grows with its
             // distance from the image centre, and this way every XCD gets the same mix; the heavier half first and, inside
-            // a half, columns from both image borders inwards.  (Any static partition is valid: dry queues steal.)
+            // a half, columns left to right.  (Any static partition is valid: dry queues steal.)
             const int hb_rows = tiles_y_ / 16, half_tiles = hb_rows * tiles_x;
             const int second = ti >= half_tiles ? 1 : 0, tih = ti - second * half_tiles;
             const int hbi = (q_ < 4) == (second == 0) ? q_ : 8 + q_;
@@ -217,7 +213,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         tx_ = tile - ty_ * tiles_x;
     };
     // (when the grid covers every item -- small problems -- workgroup i takes item i of its XCD's band: no atomics)
-    const bool one_each = (long long)gridDim.x >= 8ll * ((KARG(int, ntile) + 7) / 8) * (4 / da.spi) * KARG(int, a.B);
+    const bool one_each = (long long)gridDim.x >= 8ll * ((KARG(int, ntile) + 7) / 8) * (4 / KARG(int, spi)) * KARG(int, a.B);
     __syncthreads();
 
     // Persistent grid: the workgroups a CU starts with would run their first passes in lockstep -- every phase of all three at
@@ -228,7 +224,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         for (int i = 0; i < slot * DIST_STAGGER; ++i) __builtin_amdgcn_s_sleep(100);
     }
     int slot_par = 0;
-    int pt = 0;           // running table-pass counter: selects the set of row-table arrays
+    int pt = 0;           // running pass counter: selects the set of row-table arrays
     int n_direct = 0;     // (thread 0) pixel blocks evaluated directly
     int b_tables = -1;    // batch item whose tables (means, homography terms, camera constants) are in LDS
     // (thread 0) the atomic on the own queue is issued at the top of an item and its result looked at when the item is done
@@ -249,13 +245,14 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         DSTAMP(0)   // queue: publish + barrier
         int b, tx, ty, sub0, spi;
         decode(item, b, tx, ty, sub0, spi);
+        const int H = KARG(int, a.H), W = KARG(int, a.W), V = KARG(int, a.V), C = KARG(int, a.C), D = KARG(int, a.D);
         // per BATCH item, for every wave: scaled channel means, the views' homography terms, the camera constants, the item's
         // flags (visible behind the barrier in front of the first block's centring).  Items come out of the queues batch item
         // by batch item: the tables are rebuilt a few times per launch, not once per tile.
         const bool new_b = b != b_tables;
         if (new_b) {
             b_tables = b;
-            const float* st = da.stats + (size_t)b * STATS_STRIDE;
+            const float* st = KARG(const float*, stats) + (size_t)b * STATS_STRIDE;
             if (wave == 0) {
                 // the scale (dist_layout.hpp: the same function of the same numbers as in the pack kernel) and the guard
                 float am = st[STATS_AMAX + lane], sv = st[STATS_VAR + lane], sl_ = st[STATS_LAG + lane];
@@ -273,10 +270,9 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 // 2.4 -> 1.0e-4 .. 1.4e-4 m, where the reference's form keeps 3e-5.  An item is evaluated directly where the
                 // ratio exceeds DIST_GUARD_RATIO AND the energy is large enough against sigma for the difference to show
                 // (unit-variance features: 67; features whose energy is all spread gain nothing from the direct form).
-                const float sg_ = KARG(float, a.sigma);
-                const bool outside = sv > DIST_GUARD_RATIO * sl_ && sv * 10.0f > DIST_GUARD_ENERGY * fabsf(sg_);
+                const float sg = KARG(float, a.sigma);
+                const bool outside = sv > DIST_GUARD_RATIO * sl_ && sv * 10.0f > DIST_GUARD_ENERGY * fabsf(sg);
                 if (lane == 0) {
-                    const float sg = KARG(float, a.sigma);
                     L.cst[6] = sc; L.cst[7] = ldexpf(refined_rcp(sg), -2 * e);
                     const int pf = reinterpret_cast<const int*>(st + STATS_FLAGS)[0];
                     L.iflag = (pf != 0 ? 1 : 0) | (outside ? 2 : 0);
@@ -287,7 +283,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 const int v = tid - 128;
                 ViewXform xf;
                 make_view_xform(KARG(const float*, a.K) + b * 9, KARG(const float*, a.R) + ((size_t)b * V + v) * 9,
-                                KARG(const float*, a.t) + ((size_t)b * V + v) * 3, da.a.blas_mode, xf);
+                                KARG(const float*, a.t) + ((size_t)b * V + v) * 3, KARG(int, a.blas_mode), xf);
 #pragma unroll
                 for (int i = 0; i < 9; ++i) L.xf[v * 12 + i] = xf.kr[i];
 #pragma unroll
@@ -302,68 +298,60 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         }
         const bool wide = b < 64 ? L.wide[b] != 0 : false;
         bool item_ready = !new_b;
-        // (spi: pixel blocks of this item; NP == 2: always 4, the launcher sees to it)
 
-        for (int it = 0; it < spi / NP; ++it) {
-            // the pixel blocks of this trip: NP == 1: block sub0 + it; NP == 2: blocks (0, 1), (2, 3) of a tile of four 16x1
-            // rows, blocks (0, 2), (1, 3) of a tile of 8x2 blocks (stacked to 8x4)
-            int subs[NP];
-#pragma unroll
-            for (int s = 0; s < NP; ++s) subs[s] = NP == 1 ? sub0 + it : (wide ? 2 * it + s : it + 2 * s);
-            if ((wide ? ty * 4 + subs[0] : ty * 4 + 2 * (subs[0] >> 1)) >= H) continue;   // the blocks lie below the image (uniform)
-            // lane roles: in the vector phases thread (n, tq) owns pixel n of each block and planes 64 h + 4 tq .. + 3; in the
+        for (int it = 0; it < spi; ++it) {
+            const int sub = sub0 + it;   // the pixel block of this trip
+            if ((wide ? ty * 4 + sub : ty * 4 + 2 * (sub >> 1)) >= H) continue;   // the block lies below the image (uniform)
+            // lane roles: in the vector phases thread (n, tq) owns pixel n of the block and planes 64 h + 4 tq .. + 3; in the
             // matrix phase lane (n, kq) of a wave feeds texel / pixel n and K slice kq.  (opaque: the optimiser otherwise
             // hoists every lane-derived invariant of the phases to the top of the kernel)
             const int tid = opaque_v((int)threadIdx.x), lane = tid & 63;   // (shadow the kernel's: re-derived per trip)
             const int n = lane & 15, kq = lane >> 4, tq = wave * 4 + kq;
-            const int HW = opaque_s(H * W);
-            int p[NP];
-            bool xlive[NP];
-            float ray[NP][3], rv[NP][MCH];
-            // the pixels' rays, and this thread's share of the blocks' reference features: channels tq, tq + 16, ... of pixel n
-            // (buffer loads: 32-bit offsets, the channel as the scalar offset; channels beyond C = 0)
+            const int a32 = (lane ^ 32) << 2;   // (bperm_f: the lane of pixel n two K slices on)
+            const int HW = H * W;
+            int p;
+            bool xlive;
+            float ray[3], rv[MP][2];
+            // the pixel's ray, and this thread's share of the block's reference features: channel pairs tq, tq + 16, ... of
+            // pixel n (buffer loads: 32-bit offsets, the channel as the scalar offset; channels beyond C = 0); the tail's four
+            // pairs are wave 0's
             {
                 const __amdgpu_buffer_rsrc_t rray =
-                    __builtin_amdgcn_make_buffer_rsrc((void*)(da.a.rays + (size_t)b * 3 * HW), 0, 3 * HW * 4, 0x00020000);
-                const __amdgpu_buffer_rsrc_t rref =
-                    __builtin_amdgcn_make_buffer_rsrc((void*)(da.a.ref + (size_t)b * da.a.ref_bstride), 0, C * HW * 4, 0x00020000);
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(KARG(const float*, a.rays) + (size_t)b * 3 * HW), 0, 3 * HW * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rref = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(KARG(const float*, a.ref) + (size_t)b * KARG(long long, a.ref_bstride)), 0, C * HW * 4, 0x00020000);
+                const int x = wide ? tx * 16 + n : tx * 16 + 8 * (sub & 1) + (n & 7);
+                const int y = wide ? ty * 4 + sub : ty * 4 + 2 * (sub >> 1) + (n >> 3);
+                xlive = x < W && y < H;
+                p = min(y, H - 1) * W + min(x, W - 1);
 #pragma unroll
-                for (int s = 0; s < NP; ++s) {
-                    const int x = wide ? tx * 16 + n : tx * 16 + 8 * (subs[s] & 1) + (n & 7);
-                    const int y = wide ? ty * 4 + subs[s] : ty * 4 + 2 * (subs[s] >> 1) + (n >> 3);
-                    xlive[s] = x < W && y < H;
-                    p[s] = min(y, H - 1) * W + min(x, W - 1);
+                for (int i = 0; i < 3; ++i) ray[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rray, p * 4, i * HW * 4, 0));
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) ray[s][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rray, p[s] * 4, i * HW * 4, 0));
+                for (int mm = 0; mm < MP; ++mm) {
+                    if (mm == NCHK && wave != 0) { rv[mm][0] = 0.0f; rv[mm][1] = 0.0f; continue; }   // uniform
 #pragma unroll
-                    for (int mm = 0; mm < MCH; ++mm)
-                        rv[s][mm] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            rref, tq + 16 * mm < C ? (tq * HW + p[s]) * 4 : OOB, 16 * mm * HW * 4, 0));
+                    for (int i = 0; i < 2; ++i)
+                        rv[mm][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rref, 2 * tq + i < C - 32 * mm ? ((2 * tq + i) * HW + p) * 4 : OOB, 32 * mm * HW * 4, 0));
                 }
             }
             DSTAMP(1)   // item set-up, pixel loads issued
-            float rr[NP], zc[NP];          // |r'|^2 and |r|^2 of the pixels, scaled (set with the first pass)
+            float rr = 0.0f, zc = 0.0f;    // |r'|^2 and |r|^2 of the pixel, scaled (set with the first pass)
             bool centred = false;
-            unsigned failmask[NP];         // uniform over the workgroup: passes (view v, plane group h) left to the direct evaluation
-            float cost[NP][NC];
+            unsigned failmask = 0;         // uniform over the workgroup: passes (view v, plane group h) left to the direct evaluation
+            float cost[NC];
 #pragma unroll
-            for (int s = 0; s < NP; ++s) {
-                rr[s] = 0.0f; zc[s] = 0.0f; failmask[s] = 0;
-#pragma unroll
-                for (int j = 0; j < NC; ++j) cost[s][j] = 0.0f;
-            }
+            for (int j = 0; j < NC; ++j) cost[j] = 0.0f;
 
             for (int v = 0; v < V; ++v) {
-                const char* srcv = da.packed + (size_t)((size_t)b * V + v) * dist::view_bytes(C, H, W);
-                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)srcv, 0, (int)dist::view_bytes(C, H, W), 0x00020000);
-
+                const char* srcv = KARG(const char*, packed) + (size_t)((size_t)b * V + v) * dist::view_bytes(C, H, W);
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
                     if (!item_ready) { PDEPTH_LDS_BARRIER(); item_ready = true; }   // (the item's tables above are in LDS)
                     // ---- sample positions of this thread's planes of the pass (NO_CELL: no tap in the image, plane beyond D,
                     //      pixel beyond the image)
-                    int cell[NP][4];
-                    float fw[NP][4], fn[NP][4];
+                    int cell[4];
+                    float fw[4], fn[4];
                     {
                         ViewXform xf;
                         {
@@ -371,375 +359,312 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                                       k2 = *reinterpret_cast<const v4f*>(&L.xf[v * 12 + 8]);
                             xf.kr[0] = k0.x; xf.kr[1] = k0.y; xf.kr[2] = k0.z; xf.kr[3] = k0.w; xf.kr[4] = k1.x; xf.kr[5] = k1.y;
                             xf.kr[6] = k1.z; xf.kr[7] = k1.w; xf.kr[8] = k2.x; xf.kt[0] = k2.y; xf.kt[1] = k2.z; xf.kt[2] = k2.w;
-                            xf.separate = da.a.blas_mode;
+                            xf.separate = KARG(int, a.blas_mode);
                         }
                         const v4f c0 = *reinterpret_cast<const v4f*>(&L.cst[0]);
                         const v2f c1 = *reinterpret_cast<const v2f*>(&L.cst[4]);
+                        const v4f dk = *reinterpret_cast<const v4f*>(&L.dcl[64 * h + 4 * tq]);
+                        float t2a, t2b, t2c;
+                        ray_term2(xf, ray[0], ray[1], ray[2], t2a, t2b, t2c);
 #pragma unroll
-                        for (int s = 0; s < NP; ++s) {
-                            float t2a, t2b, t2c;
-                            ray_term2(xf, ray[s][0], ray[s][1], ray[s][2], t2a, t2b, t2c);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const int k = 64 * h + 4 * tq + j;
-                                float ix, iy;
-                                // (scalar instructions: packed fp32 -- two planes per v_pk_* instruction -- now and then loses the low
-                                //  half of a result in lanes 48..63 beside v_mfma_f32_16x16x32_f16 on gfx950: wave_util.hpp)
-                                plane_sample_pos_fast(xf, t2a, t2b, t2c, L.dcl[k], c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ix, iy);
-                                cell[s][j] = cell_of(ix, iy, W, H, fw[s][j], fn[s][j]);
-                                if (k >= D || !xlive[s]) cell[s][j] = NO_CELL;
-                            }
-                            // (pinned: the optimiser otherwise carries the positions AND their floors to the combine instead of the fractions)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(fw[s][j])); asm volatile("" : "+v"(fn[s][j])); }
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = 64 * h + 4 * tq + j;
+                            float ix, iy;
+                            // (scalar instructions: packed fp32 -- two planes per v_pk_* instruction -- now and then loses the low
+                            //  half of a result in lanes 48..63 beside v_mfma_f32_16x16x32_f16 on gfx950: wave_util.hpp)
+                            plane_sample_pos_fast(xf, t2a, t2b, t2c, dk[j], c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ix, iy);
+                            cell[j] = cell_of(ix, iy, W, H, fw[j], fn[j]);
+                            if (k >= D || !xlive) cell[j] = NO_CELL;
                         }
+                        // (pinned: the optimiser otherwise carries the positions AND their floors to the combine instead of the fractions)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(fw[j])); asm volatile("" : "+v"(fn[j])); }
                     }
                     DSTAMP(2)   // (wait for the rays) sample positions
                     if (!centred) {
-                        // (first pass of the trip) this thread's channels of pixel n of each block: -2 x' = -2 (r - mu) 2^e in one
-                        // rounding (scaling by a power of two commutes with it), split into fp16 high and low parts, into the
-                        // pixel-side operand image of the block; and its share of |r'|^2 and |r|^2.  Channel c = tq + 16 mm: chunk
-                        // (c >> 5) for c < 32 NCHK, K slot c & 31; else the tail chunk: K slots t (its high part, against the
-                        // texel's high part), 8 + t (high, against the texel's low part), 16 + t (low).
+                        // (first pass of the trip) this thread's channel pairs of pixel n: -2 x' = -2 (r - mu) 2^e in one rounding
+                        // (scaling by a power of two commutes with it), split into fp16 high and low parts (two channels per
+                        // conversion), into the pixel-side operand image of the block; and its share of |r'|^2 and |r|^2.  Pair
+                        // tq of round mm = channels 32 mm + 2 tq, + 1: chunk mm, K slots 2 tq, 2 tq + 1 (K slice tq >> 2 = wave);
+                        // the tail round (wave 0, pair kq): K slots 2 kq (high part, against the texel's high part), 8 + 2 kq (high,
+                        // against the texel's low part), 16 + 2 kq (low).  A feature beyond the fp16 range after scaling becomes
+                        // inf - inf in the products: the pixel's costs are NaN (never a clamped number).
                         const float sc = L.cst[6], sm2 = -2.0f * sc;
+                        float pr = 0.0f, pz = 0.0f;
+                        int* const Bw = reinterpret_cast<int*>(L.Bs);   // (pairs of halves)
 #pragma unroll
-                        for (int s = 0; s < NP; ++s) {
-                            float pr = 0.0f, pz = 0.0f;
-#pragma unroll
-                            for (int mm = 0; mm < MCH; ++mm) {
-                                const int c = tq + 16 * mm;
-                                const bool has = c < CPAD;   // (only the last round can fall beyond the padded channels)
-                                const float m2 = 2.0f * L.mus[min(c, dist::MAX_C + 7)];
-                                const float xm = has ? __builtin_fmaf(rv[s][mm], sm2, m2) : 0.0f;
-                                const float rs = has ? rv[s][mm] * sc : 0.0f;
-                                pr = __builtin_fmaf(xm, xm, pr);
-                                pz = __builtin_fmaf(rs, rs, pz);
-                                const float xc = __builtin_amdgcn_fmed3f(xm, -64000.0f, 64000.0f);
-                                const _Float16 bh = (_Float16)xc;
-                                const _Float16 bl = (_Float16)(xc - (float)bh);
-                                if (16 * mm < 32 * NCHK) {   // (compile time: the round lies in a chunk of 32)
-                                    const int chunk = (16 * mm) >> 5, kqq = 2 * (mm & 1) + (tq >> 3), jj = tq & 7;
-                                    L.Bs[s][((chunk * 4 + kqq) * 16 + n) * 8 + jj] = bh;
-                                    L.Bs[s][(((NCHK + chunk) * 4 + kqq) * 16 + n) * 8 + jj] = bl;
-                                } else if (has) {
-                                    const int t = tq;   // (c - 32 NCHK)
-                                    L.Bs[s][(((2 * NCHK) * 4 + 0) * 16 + n) * 8 + t] = bh;
-                                    L.Bs[s][(((2 * NCHK) * 4 + 1) * 16 + n) * 8 + t] = bh;
-                                    L.Bs[s][(((2 * NCHK) * 4 + 2) * 16 + n) * 8 + t] = bl;
-                                }
+                        for (int mm = 0; mm < MP; ++mm) {
+                            if (mm == NCHK && wave != 0) continue;   // uniform
+                            const v2f mu2 = *reinterpret_cast<const v2f*>(&L.mus[32 * mm + 2 * tq]);
+                            const float x0 = __builtin_fmaf(rv[mm][0], sm2, 2.0f * mu2.x), x1 = __builtin_fmaf(rv[mm][1], sm2, 2.0f * mu2.y);
+                            const float s0 = rv[mm][0] * sc, s1 = rv[mm][1] * sc;
+                            pr = __builtin_fmaf(x0, x0, pr); pr = __builtin_fmaf(x1, x1, pr);
+                            pz = __builtin_fmaf(s0, s0, pz); pz = __builtin_fmaf(s1, s1, pz);
+                            const h2 bh = __builtin_convertvector(v2f{x0, x1}, h2);
+                            const h2 bl = __builtin_convertvector(v2f{x0 - (float)bh.x, x1 - (float)bh.y}, h2);
+                            if (mm < NCHK) {
+                                Bw[((mm * 4 + wave) * 16 + n) * 4 + kq] = __builtin_bit_cast(int, bh);
+                                Bw[(((NCHK + mm) * 4 + wave) * 16 + n) * 4 + kq] = __builtin_bit_cast(int, bl);
+                            } else {
+                                Bw[(((2 * NCHK) * 4 + 0) * 16 + n) * 4 + kq] = __builtin_bit_cast(int, bh);
+                                Bw[(((2 * NCHK) * 4 + 1) * 16 + n) * 4 + kq] = __builtin_bit_cast(int, bh);
+                                Bw[(((2 * NCHK) * 4 + 2) * 16 + n) * 4 + kq] = __builtin_bit_cast(int, bl);
                             }
-                            pr = 0.25f * pr;
-                            pr = pr + __shfl_xor(pr, 16); pr = pr + __shfl_xor(pr, 32);
-                            pz = pz + __shfl_xor(pz, 16); pz = pz + __shfl_xor(pz, 32);
-                            if (kq == 0) *reinterpret_cast<v2f*>(&L.rp[s][(wave * 16 + n) * 2]) = v2f{pr, pz};
+                        }
+                        pr = 0.25f * pr;
+                        pr = pr + xor16_f(pr); pr = pr + bperm_f(a32, pr);
+                        pz = pz + xor16_f(pz); pz = pz + bperm_f(a32, pz);
+                        if (kq == 0) *reinterpret_cast<v2f*>(&L.rp[(wave * 16 + n) * 2]) = v2f{pr, pz};
+                    }
+                    // ---- row table: the texels this thread's planes touch ---------------------------------------------------------
+                    // Exact runs: consecutive planes whose cells share a row are folded first and go in as ONE update of that row (two
+                    // LDS atomics, issued behind the last plane of the run) -- on a rectified pair all four planes of a thread, and
+                    // all 256 threads, meet in one or two rows, and atomics on one address are served lane by lane.  Straight-line
+                    // code: a plane continues the run of the plane before it, or closes it.
+                    const int par = pt & 1;
+                    {
+                        int ylo = 32767, yhi = -32768;
+                        int rmin = 0, rmax = 0, ry = 0;
+                        bool open = false;   // a run is open: row ry, texels rmin .. rmax
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool vj = cell[j] != NO_CELL;
+                            const int yj = cell_y(cell[j]), xj = cell_x(cell[j]);   // (NO_CELL: -32768, -32768)
+                            const bool cont = open && vj && yj == ry;
+                            if (open && !cont) {   // the run ends in front of plane j
+                                atomicMin(&L.ctab[par][(ry & 63) * 2], rmin);
+                                atomicMax(&L.ctab[par][(ry & 63) * 2 + 1], rmax);
+                            }
+                            rmin = cont ? min(rmin, xj) : xj;
+                            rmax = cont ? max(rmax, xj) : xj;
+                            ry = yj;
+                            open = vj;
+                            ylo = min(ylo, vj ? yj : 32767);
+                            yhi = max(yhi, yj);
+                        }
+                        if (open) {
+                            atomicMin(&L.ctab[par][(ry & 63) * 2], rmin);
+                            atomicMax(&L.ctab[par][(ry & 63) * 2 + 1], rmax);
+                        }
+                        const int wmin = wave_min_i(ylo), wmax = wave_max_i(yhi);
+                        if (lane == 0 && wmin <= wmax) { atomicMin(&L.ired[par][0], wmin); atomicMax(&L.ired[par][1], wmax); }
+                    }
+                    DSTAMP(3)   // table atomics, (wait for the reference features) centring
+                    PDEPTH_LDS_BARRIER();   // tables (and the operand images) complete
+                    DSTAMP(4)   // barrier
+                    if (!centred) {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const v2f pp = *reinterpret_cast<const v2f*>(&L.rp[(w * 16 + n) * 2]);
+                            rr = rr + pp.x; zc = zc + pp.y;
+                        }
+                        // the specials of the tail chunk (K slots 24..31 = lanes kq == 3): the constants that multiply the texel's
+                        // pieces of N, and |r'|^2 as three fp16 pieces against the texel's constants (dist_layout.hpp) -- into the
+                        // operand image (every wave writes the same values; a wave reads what it wrote itself).  |r'|^2 beyond
+                        // the pieces' range, or not a number: NaN pieces, NaN costs.
+                        if (kq == 3) {
+                            const dist::Pieces pq = dist::split_pieces(rr < 2.0e9f ? rr : __builtin_nanf(""));
+                            h8 sp;
+                            sp[0] = (_Float16)dist::PIECE_C1; sp[1] = (_Float16)dist::PIECE_C2; sp[2] = (_Float16)dist::PIECE_C3;
+                            sp[3] = pq.p1; sp[4] = pq.p2; sp[5] = pq.p3; sp[6] = (_Float16)0.f; sp[7] = (_Float16)0.f;
+                            *reinterpret_cast<h8*>(&L.Bs[(((NAC - 1) * 4 + 3) * 16 + n) * 8]) = sp;
+                        }
+                        centred = true;
+                    }
+                    // the pixel-side operands of lane (n, kq): high[NCHK], low[NCHK], tail -- from LDS every pass
+                    h8 Bv[NAC];
+#pragma unroll
+                    for (int i = 0; i < NAC; ++i) Bv[i] = *reinterpret_cast<const h8*>(&L.Bs[((i * 4 + kq) * 16 + n) * 8]);
+                    // ---- the row table, cut into blocks of 16 texels: every wave for itself, lane = texel row yb + lane -----
+                    const int yb = __builtin_amdgcn_readfirstlane(L.ired[par][0]), yt = __builtin_amdgcn_readfirstlane(L.ired[par][1]);
+                    int nb = 0, lo = 0, nblk = 0, fb = 0;
+                    bool fits = true;
+                    if (yb <= yt) {
+                        const int ncell = yt - yb + 1;
+                        if (ncell + 1 > 64 || ncell + 1 > MAXB) {   // (every texel row takes a block; rows are kept modulo 64)
+                            fits = false;
+                        } else {
+                            // the cells of rows lane - 1 and lane touch texel row lane (rows outside the pass: empty entries)
+                            const v2i e0 = *reinterpret_cast<const v2i*>(&L.ctab[par][((yb + lane) & 63) * 2]);
+                            const v2i e1 = *reinterpret_cast<const v2i*>(&L.ctab[par][((yb + lane - 1) & 63) * 2]);
+                            const int l0 = min(e0.x, e1.x), h0 = max(e0.y, e1.y);
+                            // (blocks start at a multiple of 4 texels of the padded row: 64-byte pieces for the loads of four lanes)
+                            lo = ((l0 + dist::RING) & ~3) - dist::RING;
+                            nblk = l0 <= h0 ? (h0 - lo + 2 + 15) >> 4 : 0;   // texels lo .. hi + 1
+                            const int incl = wave_scan_incl(nblk);
+                            nb = __builtin_amdgcn_readlane(incl, 63);
+                            fits = nb <= MAXB;
+                            fb = incl - nblk;
                         }
                     }
-                    // ---- the pass on a set of pixel blocks: both (mask 3), or -- when their common window does not fit the Y
-                    //      buffer -- one after the other (masks 1, 2); NP == 1: mask 1
-                    int mask = (1 << NP) - 1;
-                    // NP == 1: a pass whose window does not fit the Y buffer is retried as two passes of 32 planes each (psel 1:
-                    // the planes of waves 0 and 1, psel 2: those of waves 2 and 3 -- half the epipolar segment each); a half that
-                    // still does not fit is left to the direct evaluation
-                    int psel = 0;
-                    for (;;) {
-                        const int par = pt & 1;
-                        const bool mine = psel == 0 || (wave >> 1) == psel - 1;   // this wave's planes take part in the trip
-                        // ---- row table: contributions of this thread's planes ------------------------------------------------
+                    const int iflag = __builtin_amdgcn_readfirstlane(L.iflag);
+                    if (iflag != 0) fits = false;   // (the item is evaluated directly)
+                    if (DIST_FORCE_DIRECT == -1 || DIST_FORCE_DIRECT == v) fits = false;   // (test builds)
+                    ++pt;
+                    const int rowoff = 16 * fb - lo;    // slot of texel x of this lane's row = x + rowoff
+                    const bool go = fits && nb > 0;
+                    DSTAMP(5)   // operands from LDS, row table cut into blocks
+                    // ---- Y = |s' - r'|^2 for the blocks of the pass, on the matrix pipe ------------------------------------
+                    int sl0[4], sl1[4];   // slots of the top / bottom row of this thread's cells
+                    {
+                        const int PB = (int)dist::plane_bytes(H, W), Wp = dist::wp(W);
+                        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)srcv, 0, (int)dist::view_bytes(C, H, W), 0x00020000);
+                        v4i rs4;   // the same descriptor, spelled out for the inline asm
                         {
-                            int lmin = INT_MAX, lmax = INT_MIN;
-#pragma unroll
-                            for (int s = 0; s < NP; ++s) {
-                                if (!(mask >> s & 1) || !mine) continue;   // uniform
-                                int run = INT_MIN, rmin = 0, rmax = 0;   // consecutive planes of equal row are folded first
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    if (cell[s][j] != NO_CELL) {
-                                        const int cyy = cell_y(cell[s][j]), cxx = cell_x(cell[s][j]);
-                                        lmin = min(lmin, cyy); lmax = max(lmax, cyy);
-                                        if (cyy != run) {
-                                            if (run != INT_MIN) { atomicMin(&L.cmin[par][run & 63], rmin); atomicMax(&L.cmax[par][run & 63], rmax); }
-                                            run = cyy; rmin = cxx; rmax = cxx;
-                                        } else {
-                                            rmin = min(rmin, cxx); rmax = max(rmax, cxx);
-                                        }
-                                    }
-                                }
-                                if (run != INT_MIN) { atomicMin(&L.cmin[par][run & 63], rmin); atomicMax(&L.cmax[par][run & 63], rmax); }
-                            }
-                            const int wmin = wave_min_i(lmin), wmax = wave_max_i(lmax);
-                            if (lane == 0 && wmin <= wmax) { atomicMin(&L.ired[par][0], wmin); atomicMax(&L.ired[par][1], wmax); }
+                            const unsigned long long pa = reinterpret_cast<unsigned long long>(srcv);
+                            rs4.x = (int)(unsigned)pa; rs4.y = (int)(unsigned)(pa >> 32) & 0xffff; rs4.z = (int)dist::view_bytes(C, H, W); rs4.w = 0x00020000;
                         }
-                        DSTAMP(3)   // table atomics, (wait for the reference features) centring
-                        PDEPTH_LDS_BARRIER();   // tables (and the operand images) complete
-                        DSTAMP(4)   // barrier
-                        if (!centred) {
-#pragma unroll
-                            for (int s = 0; s < NP; ++s)
-#pragma unroll
-                                for (int w = 0; w < 4; ++w) {
-                                    const v2f pp = *reinterpret_cast<const v2f*>(&L.rp[s][(w * 16 + n) * 2]);
-                                    rr[s] = rr[s] + pp.x; zc[s] = zc[s] + pp.y;
-                                }
-                            // the specials of the tail chunk (K slots 24..31 = lanes kq == 3): the constants that multiply the texel's
-                            // pieces of N, and |r'|^2 as three fp16 pieces against the texel's constants (dist_layout.hpp) -- into the
-                            // operand image (every wave writes the same values; a wave reads what it wrote itself)
-                            if (kq == 3) {
-#pragma unroll
-                                for (int s = 0; s < NP; ++s) {
-                                    const dist::Pieces pq = dist::split_pieces(fminf(rr[s], 2.0e9f));
-                                    h8 sp;
-                                    sp[0] = (_Float16)dist::PIECE_C1; sp[1] = (_Float16)dist::PIECE_C2; sp[2] = (_Float16)dist::PIECE_C3;
-                                    sp[3] = pq.p1; sp[4] = pq.p2; sp[5] = pq.p3; sp[6] = (_Float16)0.f; sp[7] = (_Float16)0.f;
-                                    *reinterpret_cast<h8*>(&L.Bs[s][(((NAC - 1) * 4 + 3) * 16 + n) * 8]) = sp;
-                                }
-                            }
-                            centred = true;
-                        }
-                        // the pixel-side operands of lane (n, kq): high[NCHK], low[NCHK], tail -- from LDS every pass (NP == 1) or
-                        // every texel block (NP == 2: 40 registers otherwise)
-                        h8 Bv[NP][NAC];
-                        if (NP == 1) {
-#pragma unroll
-                            for (int i = 0; i < NAC; ++i) Bv[0][i] = *reinterpret_cast<const h8*>(&L.Bs[0][((i * 4 + kq) * 16 + n) * 8]);
-                        }
-                        // ---- the row table, cut into blocks of 16 texels: every wave for itself, lane = texel row yb + lane -----
-                        const int yb = __builtin_amdgcn_readfirstlane(L.ired[par][0]), yt = __builtin_amdgcn_readfirstlane(L.ired[par][1]);
-                        int nb = 0, lo = INT_MAX, hi = INT_MIN, nblk = 0, fb = 0;
-                        bool fits = true;
-                        if (yb <= yt) {
-                            const int ncell = yt - yb + 1;
-                            if (ncell + 1 > 64 || ncell + 1 > MAXB) {   // (every texel row takes a block; rows are kept modulo 64)
-                                fits = false;
-                            } else {
-                                // the cells of rows lane - 1 and lane touch texel row lane
-                                if (lane < ncell) { lo = L.cmin[par][(yb + lane) & 63]; hi = L.cmax[par][(yb + lane) & 63]; }
-                                if (lane >= 1 && lane <= ncell) {
-                                    lo = min(lo, L.cmin[par][(yb + lane - 1) & 63]);
-                                    hi = max(hi, L.cmax[par][(yb + lane - 1) & 63]);
-                                }
-                                // (blocks start at a multiple of 4 texels of the padded row: 64-byte pieces for the loads of four lanes)
-                                if (lo <= hi) lo = ((lo + dist::RING) & ~3) - dist::RING;
-                                nblk = lo <= hi ? (hi - lo + 2 + 15) >> 4 : 0;   // texels lo .. hi + 1
-                                const int incl = wave_scan_incl(nblk);
-                                nb = __builtin_amdgcn_readlane(incl, 63);
-                                fits = nb <= MAXB;
-                                fb = incl - nblk;
-                            }
-                        }
-                        if (L.iflag != 0) fits = false;   // (the item is evaluated directly)
-                        if (DIST_FORCE_DIRECT == -1 || DIST_FORCE_DIRECT == v) fits = false;   // (test builds)
-                        ++pt;
-                        if (NP == 2 && !fits && mask == 3 && L.iflag == 0) {
-                            // the common window of the two blocks is too large: the blocks one after the other (every wave has read the
-                            // tables: behind the barrier wave 1 cleans them)
-                            PDEPTH_LDS_BARRIER();
-                            if (wave == 1) {
-                                L.cmin[par][lane] = INT_MAX; L.cmax[par][lane] = INT_MIN;
-                                if (lane == 0) { L.ired[par][0] = INT_MAX; L.ired[par][1] = INT_MIN; }
-                            }
-                            mask = 1;
-                            continue;
-                        }
-                        if (NP == 1 && !fits && psel == 0 && L.iflag == 0 && DIST_SPLIT_PLANES && DIST_FORCE_DIRECT == -2) {
-                            PDEPTH_LDS_BARRIER();   // (every wave has read the tables: behind the barrier wave 1 cleans them)
-                            if (wave == 1) {
-                                L.cmin[par][lane] = INT_MAX; L.cmax[par][lane] = INT_MIN;
-                                if (lane == 0) { L.ired[par][0] = INT_MAX; L.ired[par][1] = INT_MIN; }
-                            }
-                            psel = 1;
-                            continue;
-                        }
-                        const int rowoff = 16 * fb - lo;    // slot of texel x of this lane's row = x + rowoff
-                        const bool go = fits && nb > 0;
-                        DSTAMP(5)   // operands from LDS, row table cut into blocks
-                        // ---- Y = |s' - r'|^2 for the blocks of the pass, on the matrix pipe ------------------------------------
-                        int sl[NP][4];   // slots of the top (low 16 bits) / bottom row of this thread's cells; < 0: no cell
-                        {
-                            v4i rs4;   // the descriptor of rsrc, spelled out for the inline asm
-                            {
-                                const unsigned long long pa = reinterpret_cast<unsigned long long>(srcv);
-                                rs4.x = (int)(unsigned)pa; rs4.y = (int)(unsigned)(pa >> 32) & 0xffff; rs4.z = (int)dist::view_bytes(C, H, W); rs4.w = 0x00020000;
-                            }
-                            const int voffA = opaque_v(n * 16 + kq * PB);
-                            // a block's texel operands in consumption order: (high c, low c) for c < NCHK, tail; ONE register set, every
-                            // chunk refilled with the next block's right behind its last multiplication (a block in flight per wave)
-                            h8 S[NAC];
-                            // Block j of the pass (lane j): the byte offset of its first texel in plane 0.  Its row = the lane rho with
-                            // fb <= j < fb + nblk: the row lanes scatter their index through LDS (every wave writes the same values and
-                            // reads back what it wrote), its first texel lo[rho] + 16 (j - fb[rho]).
-                            int boff = 0;
-                            if (go) {
-#pragma unroll
-                                for (int i = 0; i < 2; ++i)   // (a row rarely needs more than two blocks: no loop for those)
-                                    if (i < nblk) L.brow[fb + i] = lane;
-                                for (int i = 2; i < nblk; ++i) L.brow[fb + i] = lane;
-                                const int rho = L.brow[min(lane, MAXB - 1)];
-                                const int xs = __builtin_amdgcn_ds_bpermute(4 * rho, lo) + 16 * (lane - __builtin_amdgcn_ds_bpermute(4 * rho, fb));
-                                boff = lane < nb ? ((yb + rho + dist::RING) * Wp + xs + dist::RING) * 16 : OOB;
-                            }
-                            auto fetch = [&](int i, int soff) {   // chunk i: planes 4 i .. 4 i + 3 (the lane's: + kq, in voffA)
-                                S[i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffA, soff + i * 4 * PB, 0));
-                            };
-                            // wave w: blocks w q .. w q + q - 1 (consecutive blocks: consecutive slots)
-                            const int q = (nb + 3) >> 2, b0 = wave * q, b1 = min(nb, b0 + q);
-                            if (DIST_XPRIO) __builtin_amdgcn_s_setprio(DIST_XPRIO);
-                            if (go) {
-                                // the Q records of the pass's cells, from memory straight to LDS: blocks 4 g .. 4 g + 3 per instruction
-                                // (lane = (block, texel)); wave w moves groups w and w + 4
-#pragma unroll
-                                for (int gq = 0; gq < (MAXB + 15) / 16; ++gq) {
-                                    const int g = wave + 4 * gq;
-                                    if (4 * g < nb) {   // uniform
-                                        const int bo = __builtin_amdgcn_ds_bpermute(4 * (4 * g + kq), boff);
-                                        const int vq = 4 * g + kq < nb ? bo + n * 16 : OOB;
-                                        dma_b128(rs4, lds_addr_of(&L.Qs[g * 256]), vq, QPL * PB);
-                                    }
-                                }
-                                if (b0 < b1) {
-                                    const int soff = __builtin_amdgcn_readlane(boff, b0);
-#pragma unroll
-                                    for (int c = 0; c < NCHK; ++c) { fetch(c, soff); fetch(NCHK + c, soff); }
-                                    fetch(NAC - 1, soff);
-                                }
-                            }
-                            // the slots of this thread's cells (under the first block's loads)
-#pragma unroll
-                            for (int s = 0; s < NP; ++s)
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    const bool has = fits && mine && (mask >> s & 1) && cell[s][j] != NO_CELL;
-                                    const int r = has ? cell_y(cell[s][j]) - yb : 0;
-                                    const int o0 = __builtin_amdgcn_ds_bpermute(4 * r, rowoff), o1 = __builtin_amdgcn_ds_bpermute(4 * r + 4, rowoff);
-                                    const int cxx = cell_x(cell[s][j]);
-                                    sl[s][j] = has ? (cxx + o0) | ((cxx + o1) << 16) : -1;
-                                }
-                            if (go) {
+                        const int voffA = opaque_v(n * 16 + kq * PB);
+                        // a block's texel operands in consumption order: (high c, low c) for c < NCHK, tail; NS register sets: NS
+                        // blocks of the wave are in flight, every chunk refilled with the operands of the block after the next
+                        // right behind its last multiplication.  (One set -- round 5 -- left every block of a wave waiting a whole
+                        // memory latency for its operands: three to four latencies per pass on a forward motion.)
+                        h8 S[NS][NAC];
+                        // Block j of the pass (lane j): the byte offset of its first texel in plane 0.  Its row = the lane rho with
+                        // fb <= j < fb + nblk: the row lanes scatter their index through LDS (every wave writes the same values and
+                        // reads back what it wrote), its first texel lo[rho] + 16 (j - fb[rho]).
+                        int boff = 0;
+                        if (go) {
 #pragma unroll 1
-                                for (int bi = b0; bi < b1; ++bi) {   // (rolled: unrolled, the compiler hoists the later blocks' work and spills)
-                                    const bool more = bi + 1 < b1;   // uniform
-                                    const int soff = more ? __builtin_amdgcn_readlane(boff, bi + 1) : 0;
-                                    // (a texel chunk against both pixel blocks, then its refill; a block outside the mask is multiplied all
-                                    //  the same: its Y is not read)
-                                    v4f acc[NP];
+                            for (int i = 0; i < nblk; ++i) L.brow[fb + i] = lane;
+                            const int rho = L.brow[min(lane, MAXB - 1)];
+                            const int xs = __builtin_amdgcn_ds_bpermute(4 * rho, lo) + 16 * (lane - __builtin_amdgcn_ds_bpermute(4 * rho, fb));
+                            boff = lane < nb ? ((yb + rho + dist::RING) * Wp + xs + dist::RING) * 16 : OOB;
+                        }
+                        auto fetch = [&](int set, int i, int soff) {   // chunk i: planes 4 i .. 4 i + 3 (the lane's: + kq, in voffA)
+                            S[set][i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffA, soff + i * 4 * PB, 0));
+                        };
+                        auto fetch_block = [&](int set, int soff) {
 #pragma unroll
-                                    for (int s = 0; s < NP; ++s) acc[s] = v4f{0.f, 0.f, 0.f, 0.f};
-                                    if (NP == 2) {
-                                        const int bo = opaque_v((kq * 16 + n) * 8);   // (opaque: read per block, not hoisted out of the loop)
+                            for (int c = 0; c < NCHK; ++c) { fetch(set, c, soff); fetch(set, NCHK + c, soff); }
+                            fetch(set, NAC - 1, soff);
+                        };
+                        // wave w: blocks w q .. w q + q - 1 (consecutive blocks: consecutive slots)
+                        const int q = (nb + 3) >> 2, b0 = wave * q, b1 = min(nb, b0 + q);
+                        if (DIST_XPRIO) __builtin_amdgcn_s_setprio(DIST_XPRIO);
+                        if (go) {
+                            // the Q records of the pass's cells, from memory straight to LDS: blocks 4 g .. 4 g + 3 per instruction
+                            // (lane = (block, texel)); wave w moves groups w and w + 4
 #pragma unroll
-                                        for (int s = 0; s < NP; ++s)
+                            for (int gq = 0; gq < (MAXB + 15) / 16; ++gq) {
+                                const int g = wave + 4 * gq;
+                                if (4 * g < nb) {   // uniform
+                                    const int bo = __builtin_amdgcn_ds_bpermute(4 * (4 * g + kq), boff);
+                                    const int vq = 4 * g + kq < nb ? bo + n * 16 : OOB;
+                                    dma_b128(rs4, lds_addr_of(&L.Qs[g * 256]), vq, QPL * PB);
+                                }
+                            }
 #pragma unroll
-                                            for (int c = 0; c < NAC; ++c) Bv[s][c] = *reinterpret_cast<const h8*>(&L.Bs[s][c * 512 + bo]);
-                                    }
+                            for (int u = 0; u < NS; ++u)
+                                if (b0 + u < b1) fetch_block(u, __builtin_amdgcn_readlane(boff, b0 + u));
+                        }
+                        // the slots of this thread's cells (under the first blocks' loads)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool has = fits && cell[j] != NO_CELL;
+                            const int r = has ? cell_y(cell[j]) - yb : 0;
+                            const int o0 = __builtin_amdgcn_ds_bpermute(4 * r, rowoff), o1 = __builtin_amdgcn_ds_bpermute(4 * r + 4, rowoff);
+                            const int cxx = cell_x(cell[j]);
+                            sl0[j] = has ? cxx + o0 : -1;
+                            sl1[j] = cxx + o1;
+                        }
+                        if (go) {
+#pragma unroll 1
+                            for (int bi = b0; bi < b1; bi += NS) {   // (rolled: unrolled, the compiler hoists the later blocks' work and spills)
+#pragma unroll
+                                for (int u = 0; u < NS; ++u) {
+                                    const int bj = bi + u;
+                                    if (bj >= b1) break;   // uniform
+                                    const bool more = bj + NS < b1;   // uniform
+                                    const int soff = more ? __builtin_amdgcn_readlane(boff, bj + NS) : 0;
+                                    v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                                     for (int c = 0; c < NCHK; ++c) {
-#pragma unroll
-                                        for (int s = 0; s < NP; ++s) {
-                                            acc[s] = DIST_MFMA(S[c], Bv[s][c], acc[s]);
-                                            acc[s] = DIST_MFMA(S[c], Bv[s][NCHK + c], acc[s]);
-                                        }
-                                        if (more) fetch(c, soff);
-#pragma unroll
-                                        for (int s = 0; s < NP; ++s) acc[s] = DIST_MFMA(S[NCHK + c], Bv[s][c], acc[s]);
-                                        if (more) fetch(NCHK + c, soff);
+                                        acc = DIST_MFMA(S[u][c], Bv[c], acc);
+                                        acc = DIST_MFMA(S[u][c], Bv[NCHK + c], acc);
+                                        if (more) fetch(u, c, soff);
+                                        acc = DIST_MFMA(S[u][NCHK + c], Bv[c], acc);
+                                        if (more) fetch(u, NCHK + c, soff);
                                     }
-#pragma unroll
-                                    for (int s = 0; s < NP; ++s) acc[s] = DIST_MFMA(S[NAC - 1], Bv[s][NAC - 1], acc[s]);
-                                    if (more) fetch(NAC - 1, soff);
-#pragma unroll
-                                    for (int s = 0; s < NP; ++s)   // Y[texel 4 kq ..][pixel n] of the block
-                                        *reinterpret_cast<v4f*>(&L.Ys[s][n * XSTRIDE + 16 * bi + 4 * kq]) = acc[s];
+                                    acc = DIST_MFMA(S[u][NAC - 1], Bv[NAC - 1], acc);
+                                    if (more) fetch(u, NAC - 1, soff);
+                                    // Y[texel 4 kq ..][pixel n] of the block
+                                    *reinterpret_cast<v4f*>(&L.Ys[n * XSTRIDE + 16 * bj + 4 * kq]) = acc;
                                 }
-                                DSTAMP(6)   // slots, loads + multiplications
-                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's Q records have landed in LDS
                             }
-                            if (DIST_XPRIO) __builtin_amdgcn_s_setprio(0);
+                            DSTAMP(6)   // slots, loads + multiplications
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's Q records have landed in LDS
                         }
-                        DSTAMP(7)   // wait for the Q records
-                        PDEPTH_LDS_BARRIER();   // Y and the Q records of the pass are complete
-                        DSTAMP(8)   // barrier
-                        // (every wave has read the tables of this pass: wave 1 cleans them for the pass after the next)
-                        if (wave == 1) {
-                            L.cmin[par][lane] = INT_MAX; L.cmax[par][lane] = INT_MIN;
-                            if (lane == 0) { L.ired[par][0] = INT_MAX; L.ired[par][1] = INT_MIN; }
-                        }
-
-                        // ---- combine: cost of this thread's planes of the pass ---------------------------------------------
-                        const float cinv = L.cst[7];
-#pragma unroll
-                        for (int s = 0; s < NP; ++s) {
-                            if (!(mask >> s & 1)) continue;   // uniform
-                            if (!fits) {   // (evaluated directly behind the view loop: bits 2 (v NH + h), + 1 = the lower / upper 32 planes)
-                                failmask[s] |= (psel == 0 ? 3u : 1u << (psel - 1)) << (2 * (v * NH + h));
-                                continue;
-                            }
-                            if (!mine) continue;
-                            const float* yr = &L.Ys[s][n * XSTRIDE];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                // (no tap inside the image: the taps read zero, cost = |r|^2 -- and NaN where the position itself
-                                //  is not finite, as the reference's weights inf - floor(inf) make it)
-                                float qv = zc[s] + (fw[s][j] + fn[s][j]) * 0.0f;
-                                if (sl[s][j] >= 0) {
-                                    const int s0 = sl[s][j] & 0xffff, s1 = sl[s][j] >> 16;
-                                    const float Y00 = yr[s0], Y01 = yr[s0 + 1], Y10 = yr[s1], Y11 = yr[s1 + 1];
-                                    const v4f qa = *reinterpret_cast<const v4f*>(&L.Qs[s0 * 4]);   // Dx0, Dy0, Dd, Dx1
-                                    const float dy1 = L.Qs[s0 * 4 + 5];                            // Dy0 of the right neighbour
-                                    const float ex = 1.0f - fw[s][j], ey = 1.0f - fn[s][j];
-                                    const float w00 = ey * ex, w01 = ey * fw[s][j], w10 = fn[s][j] * ex, w11 = fn[s][j] * fw[s][j];
-                                    const float ys = __builtin_fmaf(w11, Y11, __builtin_fmaf(w10, Y10, __builtin_fmaf(w01, Y01, w00 * Y00)));
-                                    const float qi = __builtin_fmaf(w11, qa.z, __builtin_fmaf(w10, qa.y, w01 * qa.x));
-                                    const float qo = __builtin_fmaf(w01, dy1, w10 * qa.w);
-                                    qv = ys - __builtin_fmaf(w11, qo, w00 * qi);
-                                }
-                                cost[s][4 * h + j] = cost[s][4 * h + j] + qv * cinv;
-                            }
-                        }
-                        DSTAMP(9)   // combine
-                        if (NP == 1 && psel == 1) {   // (the upper planes of a pass that did not fit whole; the next trip's barrier in
-                            psel = 2;                 //  front of its matrix phase keeps its Y writes behind this trip's reads)
-                            continue;
-                        }
-                        if (NP == 2 && mask == 1) {   // (the second block of a pair that did not fit together)
-                            PDEPTH_LDS_BARRIER();     // every wave is done with the Y buffer of the first
-                            mask = 2;
-                            continue;
-                        }
-                        break;
+                        if (DIST_XPRIO) __builtin_amdgcn_s_setprio(0);
                     }
+                    DSTAMP(7)   // wait for the Q records
+                    PDEPTH_LDS_BARRIER();   // Y and the Q records of the pass are complete
+                    DSTAMP(8)   // barrier
+                    // (every wave has read the tables of this pass: wave 1 cleans them for the pass after the next)
+                    if (wave == 1) {
+                        *reinterpret_cast<v2i*>(&L.ctab[par][lane * 2]) = v2i{INT_MAX, INT_MIN};
+                        if (lane == 0) { L.ired[par][0] = INT_MAX; L.ired[par][1] = INT_MIN; }
+                    }
+
+                    // ---- combine: cost of this thread's planes of the pass ---------------------------------------------
+                    if (!fits) {   // (evaluated directly behind the view loop)
+                        failmask |= 1u << (v * NH + h);
+                    } else {
+                        const float cinv = L.cst[7];
+                        const float* yr = &L.Ys[n * XSTRIDE];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            // (no tap inside the image: the taps read zero, cost = |r|^2 -- and NaN where the position itself
+                            //  is not finite, as the reference's weights inf - floor(inf) make it)
+                            float qv = zc + (fw[j] + fn[j]) * 0.0f;
+                            if (sl0[j] >= 0) {
+                                const int s0 = sl0[j], s1 = sl1[j];
+                                const float Y00 = yr[s0], Y01 = yr[s0 + 1], Y10 = yr[s1], Y11 = yr[s1 + 1];
+                                const v4f qa = *reinterpret_cast<const v4f*>(&L.Qs[s0 * 4]);   // Dx0, Dy0, Dd, Dx1
+                                const float dy1 = L.Qs[s0 * 4 + 5];                            // Dy0 of the right neighbour
+                                const float ex = 1.0f - fw[j], ey = 1.0f - fn[j];
+                                const float w00 = ey * ex, w01 = ey * fw[j], w10 = fn[j] * ex, w11 = fn[j] * fw[j];
+                                const float ys = __builtin_fmaf(w11, Y11, __builtin_fmaf(w10, Y10, __builtin_fmaf(w01, Y01, w00 * Y00)));
+                                const float qi = __builtin_fmaf(w11, qa.z, __builtin_fmaf(w10, qa.y, w01 * qa.x));
+                                const float qo = __builtin_fmaf(w01, dy1, w10 * qa.w);
+                                qv = ys - __builtin_fmaf(w11, qo, w00 * qi);
+                            }
+                            cost[4 * h + j] = cost[4 * h + j] + qv * cinv;
+                        }
+                    }
+                    DSTAMP(9)   // combine
                 }
             }
 
-#pragma unroll
-            for (int s = 0; s < NP; ++s) {
-                if (failmask[s] == 0) continue;   // uniform
+            if (failmask != 0) {   // uniform
                 // Passes left to the direct evaluation: the reference's own form on the packed features -- per plane the four
                 // taps of every group of 8 channels by two 16-byte loads each (high + low parts), the pixel's centred reference
                 // features from the operand image in LDS.  An item whose features did not fit the fp16 range: NaN.
                 const v4f c0 = *reinterpret_cast<const v4f*>(&L.cst[0]), c1 = *reinterpret_cast<const v4f*>(&L.cst[4]);
                 const bool ovf = (L.iflag & 1) != 0;
+                const int PB = (int)dist::plane_bytes(H, W), Wp = dist::wp(W);
 #pragma unroll 1
                 for (int vh = 0; vh < V * NH; ++vh) {
-                    if (!(failmask[s] >> (2 * vh) & 3u)) continue;
+                    if (!(failmask >> vh & 1u)) continue;
                     if (tid == 0) ++n_direct;
-                    if (!(failmask[s] >> (2 * vh + (wave >> 1)) & 1u)) continue;   // (this wave's half of the planes went through)
                     const int v = vh / NH, h = vh - v * NH;
                     ViewXform xf;
 #pragma unroll
                     for (int i = 0; i < 9; ++i) xf.kr[i] = L.xf[v * 12 + i];
 #pragma unroll
                     for (int i = 0; i < 3; ++i) xf.kt[i] = L.xf[v * 12 + 9 + i];
-                    xf.separate = da.a.blas_mode;
+                    xf.separate = KARG(int, a.blas_mode);
                     float t2a, t2b, t2c;
-                    ray_term2(xf, ray[s][0], ray[s][1], ray[s][2], t2a, t2b, t2c);
-                    const char* srcv = da.packed + (size_t)((size_t)b * V + v) * dist::view_bytes(C, H, W);
+                    ray_term2(xf, ray[0], ray[1], ray[2], t2a, t2b, t2c);
+                    const char* srcv = KARG(const char*, packed) + (size_t)((size_t)b * V + v) * dist::view_bytes(C, H, W);
 #pragma unroll 1
                     for (int j = 0; j < 4; ++j) {
                         const int k = 64 * h + 4 * tq + j;
                         float ix, iy, fwj, fnj;
                         plane_sample_pos_fast(xf, t2a, t2b, t2c, L.dcl[k], c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ix, iy);
                         int cellj = cell_of(ix, iy, W, H, fwj, fnj);
-                        if (k >= D || !xlive[s]) cellj = NO_CELL;
-                        float qv = zc[s] + (fwj + fnj) * 0.0f;   // (no tap inside the image)
+                        if (k >= D || !xlive) cellj = NO_CELL;
+                        float qv = zc + (fwj + fnj) * 0.0f;   // (no tap inside the image)
                         if (cellj != NO_CELL) {
                             const int cxx = cell_x(cellj), cyy = cell_y(cellj);
                             const float ex = 1.0f - fwj, ey = 1.0f - fnj;
@@ -756,8 +681,8 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                                 const h8 a10 = *reinterpret_cast<const h8*>(ph + (size_t)Wp * 16), a11 = *reinterpret_cast<const h8*>(ph + (size_t)Wp * 16 + 16);
                                 const h8 l00 = *reinterpret_cast<const h8*>(pl), l01 = *reinterpret_cast<const h8*>(pl + 16);
                                 const h8 l10 = *reinterpret_cast<const h8*>(pl + (size_t)Wp * 16), l11 = *reinterpret_cast<const h8*>(pl + (size_t)Wp * 16 + 16);
-                                const h8 rh = *reinterpret_cast<const h8*>(&L.Bs[s][(((tail ? 2 * NCHK : (g >> 2)) * 4 + (tail ? 0 : (g & 3))) * 16 + n) * 8]);
-                                const h8 rl = *reinterpret_cast<const h8*>(&L.Bs[s][(((tail ? 2 * NCHK : NCHK + (g >> 2)) * 4 + (tail ? 2 : (g & 3))) * 16 + n) * 8]);
+                                const h8 rh = *reinterpret_cast<const h8*>(&L.Bs[(((tail ? 2 * NCHK : (g >> 2)) * 4 + (tail ? 0 : (g & 3))) * 16 + n) * 8]);
+                                const h8 rl = *reinterpret_cast<const h8*>(&L.Bs[(((tail ? 2 * NCHK : NCHK + (g >> 2)) * 4 + (tail ? 2 : (g & 3))) * 16 + n) * 8]);
 #pragma unroll
                                 for (int i = 0; i < 8; ++i) {
                                     float val = ((float)a00[i] + (float)l00[i]) * w00;
@@ -774,76 +699,73 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                         if (ovf) qv = __builtin_nanf("");
                         const float cj = qv * L.cst[7];
 #pragma unroll
-                        for (int jj = 0; jj < NC; ++jj) cost[s][jj] = cost[s][jj] + (jj == 4 * h + j ? cj : 0.0f);
+                        for (int jj = 0; jj < NC; ++jj) cost[jj] = cost[jj] + (jj == 4 * h + j ? cj : 0.0f);
                     }
                 }
             }
             // ---- epilogue: cost store, log-softmax over D, expectation ----------------------------------------------------
             // (buffer stores: one 32-bit lane offset, the plane as the scalar offset: plane 64 h + 16 wave + 4 kq + j)
-            float* const cost_out = da.a.cost_out;
-            float* const logp_out = da.a.logp_out;
-            float* const depth_out = da.a.depth_out;
-            if (cost_out) {
+            // (the planes' scalar offsets are formed here, from a value the optimiser cannot trace back: hoisted to the top of
+            //  the item they were four spilled scalars, read back lane by lane with five wait states each in front of a store)
+            const int HW4 = opaque_s(HW * 4);
+            const int ovoff = xlive ? 4 * kq * HW4 + p * 4 : OOB;
+            const int pl0 = 16 * wave * HW4;
+            if (float* const cost_out = KARG(float*, a.cost_out)) {
                 const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(cost_out + (size_t)b * D * HW), 0, D * HW * 4, 0x00020000);
 #pragma unroll
-                for (int s = 0; s < NP; ++s) {
-                    const int ovoff = xlive[s] ? (4 * kq * HW + p[s]) * 4 : OOB;
-#pragma unroll
-                    for (int j = 0; j < NC; ++j)   // (planes beyond D lie beyond the descriptor: dropped)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cost[s][j]), rc, ovoff, (64 * (j >> 2) + 16 * wave + (j & 3)) * HW * 4, DIST_STORE_AUX);
-                }
+                for (int j = 0; j < NC; ++j)   // (planes beyond D lie beyond the descriptor: dropped)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cost[j]), rc, ovoff, pl0 + (64 * (j >> 2) + (j & 3)) * HW4, DIST_STORE_AUX);
             }
+            float* const logp_out = KARG(float*, a.logp_out);
+            float* const depth_out = KARG(float*, a.depth_out);
             if (logp_out || depth_out) {
                 // per wave: max, sum exp, sum d exp over its planes of pixel n; merged over the four waves through LDS
-#pragma unroll
-                for (int s = 0; s < NP; ++s) {
+                {
                     float mx = -INFINITY;
 #pragma unroll
                     for (int j = 0; j < NC; ++j)
-                        if (64 * (j >> 2) + 4 * tq + (j & 3) < D) mx = fmaxf(mx, cost[s][j]);
-                    mx = fmaxf(mx, __shfl_xor(mx, 16));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                        mx = max_raw(mx, 64 * (j >> 2) + 4 * tq + (j & 3) < D ? cost[j] : -INFINITY);
+                    mx = max_raw(mx, xor16_f(mx));
+                    mx = max_raw(mx, bperm_f(a32, mx));
                     float ssum = 0.0f, esum = 0.0f;
 #pragma unroll
                     for (int j = 0; j < NC; ++j) {
                         const int k = 64 * (j >> 2) + 4 * tq + (j & 3);
-                        const float ek = k < D ? dist_exp(cost[s][j] - mx) : 0.0f;
+                        const float ek = k < D ? dist_exp(cost[j] - mx) : 0.0f;
                         ssum = ssum + ek;
                         esum = __builtin_fmaf(L.dcl[k], ek, esum);
                     }
-                    ssum = ssum + __shfl_xor(ssum, 16); ssum = ssum + __shfl_xor(ssum, 32);
-                    esum = esum + __shfl_xor(esum, 16); esum = esum + __shfl_xor(esum, 32);
-                    if (kq == 0) *reinterpret_cast<v4f*>(&L.red[s][(wave * 16 + n) * 4]) = v4f{mx, ssum, esum, 0.0f};
+                    ssum = ssum + xor16_f(ssum); ssum = ssum + bperm_f(a32, ssum);
+                    esum = esum + xor16_f(esum); esum = esum + bperm_f(a32, esum);
+                    if (kq == 0) *reinterpret_cast<v4f*>(&L.red[(wave * 16 + n) * 4]) = v4f{mx, ssum, esum, 0.0f};
                 }
                 DSTAMP(10)   // cost stores, partial softmax
                 if (!DIST_ABL_NOB3) PDEPTH_LDS_BARRIER();
+                {
+                    v4f part[4];
 #pragma unroll
-                for (int s = 0; s < NP; ++s) {
-                    float M = -INFINITY;
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) M = fmaxf(M, L.red[s][(w * 16 + n) * 4]);
+                    for (int w = 0; w < 4; ++w) part[w] = *reinterpret_cast<const v4f*>(&L.red[(w * 16 + n) * 4]);
+                    const float M = max_raw(max_raw(part[0].x, part[1].x), max_raw(part[2].x, part[3].x));
                     float S_ = 0.0f, E = 0.0f;
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
-                        const v4f part = *reinterpret_cast<const v4f*>(&L.red[s][(w * 16 + n) * 4]);
                         // (a wave whose planes all lie beyond D: max -inf, sums 0)
-                        const float scw = part.x == -INFINITY ? 0.0f : dist_exp(part.x - M);
-                        S_ = __builtin_fmaf(part.y, scw, S_);
-                        E = __builtin_fmaf(part.z, scw, E);
+                        const float scw = part[w].x == -INFINITY ? 0.0f : dist_exp(part[w].x - M);
+                        S_ = __builtin_fmaf(part[w].y, scw, S_);
+                        E = __builtin_fmaf(part[w].z, scw, E);
                     }
                     const float ls = logf(S_);
-                    const int ovoff = xlive[s] ? (4 * kq * HW + p[s]) * 4 : OOB;
                     if (logp_out) {
                         const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(logp_out + (size_t)b * D * HW), 0, D * HW * 4, 0x00020000);
 #pragma unroll
                         for (int j = 0; j < NC; ++j)
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (cost[s][j] - M) - ls), rl, ovoff,
-                                                                  (64 * (j >> 2) + 16 * wave + (j & 3)) * HW * 4, DIST_STORE_AUX);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (cost[j] - M) - ls), rl, ovoff,
+                                                                  pl0 + (64 * (j >> 2) + (j & 3)) * HW4, DIST_STORE_AUX);
                     }
-                    if (depth_out && xlive[s] && tq == 0) depth_out[(size_t)b * HW + p[s]] = E / S_;
+                    if (depth_out && xlive && tq == 0) depth_out[(size_t)b * HW + p] = E / S_;
                 }
             } else {
-                PDEPTH_LDS_BARRIER();   // (every wave is done with the blocks' operand images before the next trip's centring)
+                PDEPTH_LDS_BARRIER();   // (every wave is done with the block's operand image before the next trip's centring)
             }
             DSTAMP(11)   // barrier + merge + stores
         }   // pixel blocks of the item
@@ -892,10 +814,9 @@ inline int next_nonce() {
     return (int)(launches.fetch_add(1) % 2047u) + 1;
 }
 
-template <int NCHK, int NH, int NP>
-hipError_t launch_np(const SweepArgs& a, const char* packed, const float* stats, int* queue, int tiles_x, int tiles, int spi, long long nblk_cap,
-                     hipStream_t stream) {
-    auto kern = sweep_dist_kernel<NCHK, NH, NP>;
+template <int NCHK, int NH>
+hipError_t launch_np(const SweepArgs& a, const char* packed, const float* stats, int* queue, int tiles_x, int tiles, int spi, hipStream_t stream) {
+    auto kern = sweep_dist_kernel<NCHK, NH>;
     // persistent grid: as many workgroups as the chip holds at once (registers and LDS decide: asked once per
     // instantiation and device), a multiple of 8; fewer when there is less work
     static int per_cu[64] = {0};
@@ -911,26 +832,22 @@ hipError_t launch_np(const SweepArgs& a, const char* packed, const float* stats,
     da.a = a; da.packed = packed; da.stats = stats; da.queue = queue; da.tiles_x = tiles_x; da.ntile = tiles;
     da.spi = spi;
     da.nonce = next_nonce();
-    da.tail = spi == 4 && NP == 1 ? (int)((nblk / 8) * DIST_TAIL_PCT / 100) : 0;   // in workgroups per XCD
+    da.tail = spi == 4 ? (int)((nblk / 8) * DIST_TAIL_PCT / 100) : 0;   // in workgroups per XCD
     const long long need = 8ll * ((tiles + 7) / 8) * (4 / da.spi) * a.B;   // a workgroup per item of the largest XCD band, times 8
     if (need <= DIST_ONE_EACH_X * nblk) {
         nblk = need;
         da.tail = 0;   // (a workgroup per item: no queue, nothing to split)
     }
-    (void)nblk_cap;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, stream, da);
     return hipGetLastError();
 }
 
 template <int NCHK, int NH>
 hipError_t launch_inst(const SweepArgs& a, const char* packed, const float* stats, int* queue, int tiles_x, int tiles, hipStream_t stream) {
-    // small problems: one pixel block per item, so that every CU gets work; else whole tiles, two pixel blocks per pass (D <= 64)
+    // small problems: one pixel block per item, so that every CU gets work; else whole tiles
     const long long resident = 3ll * sweep_device_cus();
     const int spi = (long long)tiles * a.B < DIST_SPI1_BELOW * resident ? 1 : 4;
-    if constexpr (NH == 1 && DIST_NP2 != 0) {
-        if (spi == 4) return launch_np<NCHK, NH, 2>(a, packed, stats, queue, tiles_x, tiles, spi, resident, stream);
-    }
-    return launch_np<NCHK, NH, 1>(a, packed, stats, queue, tiles_x, tiles, spi, resident, stream);
+    return launch_np<NCHK, NH>(a, packed, stats, queue, tiles_x, tiles, spi, stream);
 }
 
 }  // namespace

@@ -14,11 +14,17 @@
 #define DIST_NP2 0         // 1: whole tiles at D <= 64 run two pixel blocks per pass (built, parity-green, measured 25 % SLOWER: it
 #endif                     //    saves 4 % of the vector instructions and leaves two workgroups per CU instead of three)
 #ifndef DIST_OCC1
-#define DIST_OCC1 2        // minimum waves per SIMD asked of the compiler at D <= 64: 164 registers, nothing spilled, three
-#endif                     //    workgroups per CU (4: 128 registers, 23 of them spilled: slower)
+#define DIST_OCC1 3        // minimum waves per SIMD asked of the compiler at D <= 64: 167 registers with two texel operand sets, nothing spilled,
+#endif                     //    three workgroups per CU (2: the allocator takes 178 -- two workgroups per CU)
 #ifndef DIST_OCC2
 #define DIST_OCC2 3        // ... at D > 64: without the bound the allocator takes 170 registers (two workgroups per CU: config 5 20 % slower),
 #endif                     //    with it 165, nothing spilled
+#ifndef DIST_SETS1
+#define DIST_SETS1 2       // texel operand register sets of a wave (= its blocks in flight) at D <= 64 ...
+#endif
+#ifndef DIST_SETS2
+#define DIST_SETS2 1       // ... and at D > 64 (2: 168 registers under the launch bound, 8 of them spilled)
+#endif
 #ifndef DIST_XPRIO
 #define DIST_XPRIO 1       // wave priority in the matrix phase
 #endif
@@ -90,6 +96,8 @@
 // (every stamp is a scalar memory read and a wait for it: the phases stretch, their proportions are indicative only)
 #ifdef DIST_STAMPS
 #define DSTAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += t_ - stamp_t; stamp_t = t_; }
+#elif defined(DIST_MARKS)   // static instruction census per phase (tools/dbg/isa_census.py)
+#define DSTAMP(i) asm volatile("; MARK " #i ::: "memory");
 #else
 #define DSTAMP(i)
 #endif

@@ -15,7 +15,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int OOB = 0x7fffffff;        // buffer offset beyond every descriptor: the load returns 0
-constexpr int NO_CELL = INT_MIN;
+constexpr int NO_CELL = (int)0x80008000u;   // (cell_x, cell_y of it: -32768, -32768 -- neutral in a max)
 
 __device__ __forceinline__ int opaque_v(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
@@ -44,18 +44,21 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
     return v;
 }
-#define PDEPTH_DPP_STEP(OP, ctrl) v = OP(v, __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false))
-__device__ __forceinline__ int wave_min_i(int v) {
-    PDEPTH_DPP_STEP(min, 0xB1); PDEPTH_DPP_STEP(min, 0x4E); PDEPTH_DPP_STEP(min, 0x141); PDEPTH_DPP_STEP(min, 0x140);
-    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-    PDEPTH_DPP_STEP(max, 0xB1); PDEPTH_DPP_STEP(max, 0x4E); PDEPTH_DPP_STEP(max, 0x141); PDEPTH_DPP_STEP(max, 0x140);
-    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-#undef PDEPTH_DPP_STEP
+// min / max over the 64 lanes, the DPP modifier on the min / max itself (the compiler expands update_dpp + min into a move, two
+// wait states and the operation per step: 25 instructions per reduction where these take 9); the first step's operand is
+// written right in front: a DPP read of a VGPR a vector instruction has just written needs two wait states
+#define PDEPTH_WAVE_REDUCE(NAME, OP, SOP)                                                                                  \
+    __device__ __forceinline__ int NAME(int v) {                                                                           \
+        asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"          \
+                     OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                        \
+                     OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                            \
+                     OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));                                    \
+        return SOP(SOP(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),                                 \
+                   SOP(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));                               \
+    }
+PDEPTH_WAVE_REDUCE(wave_min_i, "v_min_i32_dpp", min)
+PDEPTH_WAVE_REDUCE(wave_max_i, "v_max_i32_dpp", max)
+#undef PDEPTH_WAVE_REDUCE
 
 // plane_sample_pos_fast() of geometry.hpp for two planes at a time in packed fp32 (v_pk_mul / v_pk_add / v_pk_fma_f32:
 // each component rounds exactly like the scalar instruction, so the positions are bit-identical)
@@ -98,13 +101,30 @@ __device__ __forceinline__ int cell_of(float ix, float iy, int W, int H, float& 
     const float xfl = floorf(ix), yfl = floorf(iy);
     fw = ix - xfl;
     fn = iy - yfl;
-    const int x0 = (int)fminf(fmaxf(xfl, -2.0f), (float)(W + 1));
-    const int y0 = (int)fminf(fmaxf(yfl, -2.0f), (float)(H + 1));
+    // (v_med3_f32: one instruction, no canonicalising v_max in front as fminf / fmaxf get; a NaN comes out as one of the bounds
+    //  and is caught by the ordered compare below)
+    const int x0 = (int)__builtin_amdgcn_fmed3f(xfl, -2.0f, (float)(W + 1));
+    const int y0 = (int)__builtin_amdgcn_fmed3f(yfl, -2.0f, (float)(H + 1));
     const bool any = ix == ix && iy == iy && (unsigned)(x0 + 1) < (unsigned)(W + 1) && (unsigned)(y0 + 1) < (unsigned)(H + 1);
     return any ? (y0 << 16) | (x0 & 0xffff) : NO_CELL;
 }
 __device__ __forceinline__ int cell_x(int xy) { return (int)(short)(xy & 0xffff); }
 __device__ __forceinline__ int cell_y(int xy) { return xy >> 16; }
+
+// x of lane ^ 16 (ds_swizzle: the pattern is part of the instruction) / of the lane whose byte address `a32` holds
+// ((lane ^ 32) << 2, computed once): __shfl_xor spends three vector instructions per call on that address
+__device__ __forceinline__ float xor16_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401f));
+}
+__device__ __forceinline__ float bperm_f(int a32, float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a32, __builtin_bit_cast(int, x)));
+}
+// max without the canonicalising v_max_f32 x, x, x the compiler puts in front of fmaxf (a NaN operand: the other one)
+__device__ __forceinline__ float max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 template <typename T>
 __device__ __forceinline__ T kernarg_at(size_t offset) {
