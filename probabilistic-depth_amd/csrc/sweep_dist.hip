@@ -59,8 +59,9 @@ struct DistArgs {
     const char* packed;
     const float* stats;
     int* queue;
-    int tiles_x, ntile, spi;
-    int tail;   // (spi == 4) tiles at the end of every XCD queue that are handed out as four single pixel blocks
+    int* qcnt;      // the eight per-XCD queue counters, qstride ints apart (in the workspace's tile-flag ints, which this kernel family does not use otherwise)
+    int qstride;
+    int tiles_x, ntile;
     int nonce;  // 1 .. 2047, another one per launch: tags the diagnostics count of this call (kernels.hpp: DIST_NONCE_SLOT)
 };
 #define KARG(type, field) kernarg_at<type>(offsetof(DistArgs, field))
@@ -143,22 +144,20 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         const int nt = KARG(int, ntile), qq = nt >> 3, rr8 = nt & 7;
         return q < rr8 ? q * (qq + 1) : rr8 * (qq + 1) + (q - rr8) * qq;
     };
-    // items of queue q: whole tiles (spi == 4), the last `tail` of them as four single pixel blocks each -- the end of a launch
-    // is then a pass long, not a tile long (a workgroup that finds the queues dry has at most one pass's neighbours to wait
-    // for); or single pixel blocks throughout (spi == 1: small problems)
-    auto items_of = [&](int q) {
-        const int ntq = band_tiles_of(q) * KARG(int, a.B);
-        if (KARG(int, spi) != 4) return 4 * ntq;
-        const int tl = min(ntq, KARG(int, tail));
-        return ntq + 3 * tl;
-    };
+    // items of queue q: the pixel blocks of its tiles, four per tile, in the order of the tiles.  The ~96 workgroups of an XCD
+    // pop consecutive items within a microsecond of one another: at any time they cover a compact patch of ~24 neighbouring
+    // tiles, and the four blocks of a tile -- which share nearly all their source texels -- are in work TOGETHER, sharing
+    // them through the XCD's L2 at once.  (Round 5 handed out whole tiles, a workgroup running a tile's four blocks one
+    // after the other, 9 us apart: L2 hit rate 67 %, with single blocks 84 % and half the misses -- profiles/r06_ab/.)
+    auto items_of = [&](int q) { return 4 * band_tiles_of(q) * KARG(int, a.B); };
     bool own_done = false;
     auto steal = [&]() -> int {   // (queue << 28) | index in the queue, or -1: every queue is exhausted
-        int* queue = KARG(int*, queue);
+        int* qcnt = KARG(int*, qcnt);
+        const int qs = KARG(int, qstride);
         for (int j = 1; j < 8; ++j) {
             const int q = (xcd + j) & 7, nq = items_of(q);
-            if (*(volatile int*)&queue[q] >= nq) continue;
-            const int got = atomicAdd(&queue[q], 1);
+            if (__hip_atomic_load(&qcnt[q * qs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nq) continue;
+            const int got = atomicAdd(&qcnt[q * qs], 1);
             if (got < nq) return (q << 28) | got;
         }
         return -1;
@@ -171,20 +170,15 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     };
     // floor(nn / dd) for 0 <= nn < 2^22, 0 < dd (an integer divide costs ~40 dependent instructions)
     auto fdiv = [](int nn, int dd) { return (int)(((float)nn + 0.5f) * __builtin_amdgcn_rcpf((float)dd)); };
-    auto decode = [&](int item, int& b_, int& tx_, int& ty_, int& sub0_, int& spi_) {
+    auto decode = [&](int item, int& b_, int& tx_, int& ty_, int& sub_) {
         const int ntile = KARG(int, ntile), tiles_x = KARG(int, tiles_x), H = KARG(int, a.H);
         const int qq = ntile >> 3, rr8 = ntile & 7;
         const bool small_idx = (long long)ntile * 4 * KARG(int, a.B) < (1ll << 22);
         const int tiles_y_ = (H + 3) / 4;
         const int q_ = item >> 28, iq = item & 0x0fffffff, band_tiles = band_tiles_of(q_);
-        // index of the tile in the queue's order (batch item by batch item), first pixel block and number of blocks of the item
-        int tidx = iq >> 2;
-        sub0_ = iq & 3; spi_ = 1;
-        if (KARG(int, spi) == 4) {
-            const int ntq = band_tiles * KARG(int, a.B), whole = ntq - min(ntq, KARG(int, tail));
-            if (iq < whole) { tidx = iq; sub0_ = 0; spi_ = 4; }
-            else { tidx = whole + ((iq - whole) >> 2); sub0_ = (iq - whole) & 3; }
-        }
+        // index of the tile in the queue's order (batch item by batch item), and the pixel block of the tile
+        const int tidx = iq >> 2;
+        sub_ = iq & 3;
         b_ = small_idx ? fdiv(tidx, band_tiles) : tidx / band_tiles;
         const int ti = tidx - b_ * band_tiles;
         int tile = band_first_of(q_) + ti;
@@ -213,7 +207,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         tx_ = tile - ty_ * tiles_x;
     };
     // (when the grid covers every item -- small problems -- workgroup i takes item i of its XCD's band: no atomics)
-    const bool one_each = (long long)gridDim.x >= 8ll * ((KARG(int, ntile) + 7) / 8) * (4 / KARG(int, spi)) * KARG(int, a.B);
+    const bool one_each = (long long)gridDim.x >= 8ll * ((KARG(int, ntile) + 7) / 8) * 4 * KARG(int, a.B);
     __syncthreads();
 
     // Persistent grid: the workgroups a CU starts with would run their first passes in lockstep -- every phase of all three at
@@ -227,24 +221,37 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     int pt = 0;           // running pass counter: selects the set of row-table arrays
     int n_direct = 0;     // (thread 0) pixel blocks evaluated directly
     int b_tables = -1;    // batch item whose tables (means, homography terms, camera constants) are in LDS
-    // (thread 0) the atomic on the own queue is issued at the top of an item and its result looked at when the item is done
-    int got_own = (tid == 0 && !one_each) ? atomicAdd(&KARG(int*, queue)[xcd], 1) : (int)(blockIdx.x >> 3);
-    bool first = true;
+    // The queue runs one item ahead: (thread 0) the atomic that pops item i + 1 is issued when item i starts, its result is
+    // resolved and published in LDS in front of the LAST barrier of item i -- the workgroup goes from one pixel block to
+    // the next without a barrier of the queue's own.
+    int got_own = (tid == 0 && !one_each) ? atomicAdd(&KARG(int*, qcnt)[xcd * KARG(int, qstride)], 1) : (int)(blockIdx.x >> 3);
+    // resolve_next(): BEFORE the block's stores are issued -- the result of the atomic is waited for with a vmcnt, and memory
+    // operations complete in issue order: behind the stores that wait is the stores' whole latency, for thread 0's wave and, at
+    // the next barrier, for the workgroup (2 us per pixel block when it was there).
+    int next_item = -1;
+    auto resolve_next = [&]() { if (tid == 0) next_item = one_each ? -1 : resolve(got_own); };
+    auto publish_next = [&]() {   // (thread 0, in front of a workgroup barrier)
+        if (tid == 0) {
+            L.item[slot_par] = next_item;
+            if (!one_each && !own_done) got_own = atomicAdd(&KARG(int*, qcnt)[xcd * KARG(int, qstride)], 1);
+        }
+    };
+    if (tid == 0) {
+        L.item[0] = one_each ? (got_own < items_of(xcd) ? (xcd << 28) | got_own : -1) : resolve(got_own);
+        if (!one_each && !own_done) got_own = atomicAdd(&KARG(int*, qcnt)[xcd * KARG(int, qstride)], 1);
+    }
+    PDEPTH_LDS_BARRIER();   // the first item is published
 
     for (;;) {
-        if (tid == 0) {
-            const int n_own = items_of(xcd);
-            L.item[slot_par] = one_each ? (first && got_own < n_own ? (xcd << 28) | got_own : -1) : resolve(got_own);
-        }
-        first = false;
-        PDEPTH_LDS_BARRIER();   // the item is published; every wave is done with the previous one's LDS
-        const int item = __builtin_amdgcn_readfirstlane(*(volatile int*)&L.item[slot_par]);
+        // (a plain LDS read: behind the barrier's memory clobber it cannot be hoisted.  Through a volatile generic pointer --
+        //  round 5 -- it was a FLAT load, and a flat load is waited for with vmcnt(0): every item began by waiting out the
+        //  previous pixel block's stores, 2 us per item)
+        const int item = __builtin_amdgcn_readfirstlane(L.item[slot_par]);
         slot_par ^= 1;
         if (item < 0) break;
-        if (tid == 0 && !one_each && !own_done) got_own = atomicAdd(&KARG(int*, queue)[xcd], 1);
-        DSTAMP(0)   // queue: publish + barrier
-        int b, tx, ty, sub0, spi;
-        decode(item, b, tx, ty, sub0, spi);
+        DSTAMP(0)   // queue
+        int b, tx, ty, sub;
+        decode(item, b, tx, ty, sub);
         const int H = KARG(int, a.H), W = KARG(int, a.W), V = KARG(int, a.V), C = KARG(int, a.C), D = KARG(int, a.D);
         // per BATCH item, for every wave: scaled channel means, the views' homography terms, the camera constants, the item's
         // flags (visible behind the barrier in front of the first block's centring).  Items come out of the queues batch item
@@ -299,9 +306,13 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         const bool wide = b < 64 ? L.wide[b] != 0 : false;
         bool item_ready = !new_b;
 
-        for (int it = 0; it < spi; ++it) {
-            const int sub = sub0 + it;   // the pixel block of this trip
-            if ((wide ? ty * 4 + sub : ty * 4 + 2 * (sub >> 1)) >= H) continue;   // the block lies below the image (uniform)
+        {
+            if ((wide ? ty * 4 + sub : ty * 4 + 2 * (sub >> 1)) >= H) {   // the block lies below the image (uniform)
+                resolve_next();
+                publish_next();
+                PDEPTH_LDS_BARRIER();
+                continue;
+            }
             // lane roles: in the vector phases thread (n, tq) owns pixel n of the block and planes 64 h + 4 tq .. + 3; in the
             // matrix phase lane (n, kq) of a wave feeds texel / pixel n and K slice kq.  (opaque: the optimiser otherwise
             // hoists every lane-derived invariant of the phases to the top of the kernel)
@@ -328,11 +339,13 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 for (int i = 0; i < 3; ++i) ray[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rray, p * 4, i * HW * 4, 0));
 #pragma unroll
                 for (int mm = 0; mm < MP; ++mm) {
-                    if (mm == NCHK && wave != 0) { rv[mm][0] = 0.0f; rv[mm][1] = 0.0f; continue; }   // uniform
+                    // (the tail round's loads are issued by every wave -- beyond the descriptor in waves 1..3 -- : registers that
+                    //  only wave 0 loads made the compiler wait, at the top of every trip, for the previous trip's stores)
+                    const bool mine = mm < NCHK || wave == 0;
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
                         rv[mm][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            rref, 2 * tq + i < C - 32 * mm ? ((2 * tq + i) * HW + p) * 4 : OOB, 32 * mm * HW * 4, 0));
+                            rref, mine && 2 * tq + i < C - 32 * mm ? ((2 * tq + i) * HW + p) * 4 : OOB, 32 * mm * HW * 4, 0));
                 }
             }
             DSTAMP(1)   // item set-up, pixel loads issued
@@ -375,6 +388,12 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                             plane_sample_pos_fast(xf, t2a, t2b, t2c, dk[j], c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ix, iy);
                             cell[j] = cell_of(ix, iy, W, H, fw[j], fn[j]);
                             if (k >= D || !xlive) cell[j] = NO_CELL;
+                            if (DIST_ABL & 1) {   // timing only: the position chain a second time (how much of the kernel is vector issue?)
+                                float ix2, iy2, f2, g2;
+                                plane_sample_pos_fast(xf, t2a, t2b, t2c, dk[j] * 1.0001f, c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ix2, iy2);
+                                const int c2 = cell_of(ix2, iy2, W, H, f2, g2);
+                                asm volatile("" :: "v"(c2), "v"(f2), "v"(g2));
+                            }
                         }
                         // (pinned: the optimiser otherwise carries the positions AND their floors to the combine instead of the fractions)
 #pragma unroll
@@ -532,6 +551,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                             boff = lane < nb ? ((yb + rho + dist::RING) * Wp + xs + dist::RING) * 16 : OOB;
                         }
                         auto fetch = [&](int set, int i, int soff) {   // chunk i: planes 4 i .. 4 i + 3 (the lane's: + kq, in voffA)
+                            if (DIST_ABL & 2) { S[set][i] = Bv[i]; return; }   // timing only: no texel loads
                             S[set][i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffA, soff + i * 4 * PB, 0));
                         };
                         auto fetch_block = [&](int set, int soff) {
@@ -707,6 +727,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
             // (buffer stores: one 32-bit lane offset, the plane as the scalar offset: plane 64 h + 16 wave + 4 kq + j)
             // (the planes' scalar offsets are formed here, from a value the optimiser cannot trace back: hoisted to the top of
             //  the item they were four spilled scalars, read back lane by lane with five wait states each in front of a store)
+            resolve_next();
             const int HW4 = opaque_s(HW * 4);
             const int ovoff = xlive ? 4 * kq * HW4 + p * 4 : OOB;
             const int pl0 = 16 * wave * HW4;
@@ -740,6 +761,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                     if (kq == 0) *reinterpret_cast<v4f*>(&L.red[(wave * 16 + n) * 4]) = v4f{mx, ssum, esum, 0.0f};
                 }
                 DSTAMP(10)   // cost stores, partial softmax
+                publish_next();
                 if (!DIST_ABL_NOB3) PDEPTH_LDS_BARRIER();
                 {
                     v4f part[4];
@@ -765,10 +787,11 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                     if (depth_out && xlive && tq == 0) depth_out[(size_t)b * HW + p] = E / S_;
                 }
             } else {
-                PDEPTH_LDS_BARRIER();   // (every wave is done with the block's operand image before the next trip's centring)
+                publish_next();
+                PDEPTH_LDS_BARRIER();   // (every wave is done with the block's operand image before the next block's centring)
             }
             DSTAMP(11)   // barrier + merge + stores
-        }   // pixel blocks of the item
+        }   // the pixel block
     }   // items
 #ifdef DIST_STAMPS
     if (lane == 0)
@@ -799,7 +822,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
             const int done = atomicAdd(&queue[DIST_DONE_SLOT], 1);
             if (done == (int)gridDim.x - 1) {
                 const int nd = atomicAdd(&queue[DIST_DIRECT_SLOT], 0);
-                for (int q = 0; q < 8; ++q) queue[q] = 0;
+                for (int q = 0; q < 8; ++q) KARG(int*, qcnt)[q * KARG(int, qstride)] = 0;
                 queue[DIST_DONE_SLOT] = 0;
                 queue[DIST_DIRECT_SLOT] = 0;
                 queue[DIST_DIRECT_LAST_SLOT] = (nonce << 20) | nd;   // diagnostics: pixel blocks of this call evaluated directly
@@ -815,7 +838,7 @@ inline int next_nonce() {
 }
 
 template <int NCHK, int NH>
-hipError_t launch_np(const SweepArgs& a, const char* packed, const float* stats, int* queue, int tiles_x, int tiles, int spi, hipStream_t stream) {
+hipError_t launch_inst(const SweepArgs& a, const char* packed, const float* stats, int* queue, int tiles_x, int tiles, hipStream_t stream) {
     auto kern = sweep_dist_kernel<NCHK, NH>;
     // persistent grid: as many workgroups as the chip holds at once (registers and LDS decide: asked once per
     // instantiation and device), a multiple of 8; fewer when there is less work
@@ -830,24 +853,21 @@ hipError_t launch_np(const SweepArgs& a, const char* packed, const float* stats,
     long long nblk = ((long long)sweep_device_cus() * per_cu[dev] + 7) & ~7ll;
     DistArgs da;
     da.a = a; da.packed = packed; da.stats = stats; da.queue = queue; da.tiles_x = tiles_x; da.ntile = tiles;
-    da.spi = spi;
-    da.nonce = next_nonce();
-    da.tail = spi == 4 ? (int)((nblk / 8) * DIST_TAIL_PCT / 100) : 0;   // in workgroups per XCD
-    const long long need = 8ll * ((tiles + 7) / 8) * (4 / da.spi) * a.B;   // a workgroup per item of the largest XCD band, times 8
-    if (need <= DIST_ONE_EACH_X * nblk) {
-        nblk = need;
-        da.tail = 0;   // (a workgroup per item: no queue, nothing to split)
+    // The queue counters: memory-side atomics on ONE line are served one after the other (~13 ns each: 32 768 pops of the
+    // headline launch on eight neighbouring ints took 0.42 ms whatever the kernel did in between); 256 bytes apart they are not.
+    {
+        const int nflags = (int)(sweep_ws_flag_only_bytes(a.B, a.H, a.W) / sizeof(int));   // >= 64
+        int qs = DIST_QSTRIDE;
+        while (qs * 8 > nflags) qs >>= 1;
+        da.qcnt = queue - nflags;
+        da.qstride = qs;
     }
+    da.nonce = next_nonce();
+    // up to DIST_ONE_EACH_X items per resident workgroup there is no queue: a workgroup per item (sweep_dist_knobs.hpp)
+    const long long need = 8ll * ((tiles + 7) / 8) * 4 * a.B;   // a workgroup per pixel block of the largest XCD band, times 8
+    if (need <= DIST_ONE_EACH_X * nblk) nblk = need;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, stream, da);
     return hipGetLastError();
-}
-
-template <int NCHK, int NH>
-hipError_t launch_inst(const SweepArgs& a, const char* packed, const float* stats, int* queue, int tiles_x, int tiles, hipStream_t stream) {
-    // small problems: one pixel block per item, so that every CU gets work; else whole tiles
-    const long long resident = 3ll * sweep_device_cus();
-    const int spi = (long long)tiles * a.B < DIST_SPI1_BELOW * resident ? 1 : 4;
-    return launch_np<NCHK, NH>(a, packed, stats, queue, tiles_x, tiles, spi, stream);
 }
 
 }  // namespace

@@ -40,6 +40,15 @@
 // 1: a pass whose texel blocks do not fit LDS is retried as two passes of 32 planes before the direct evaluation.  Built,
 // parity-green, off: config 5 (6 809 of 524 288 passes direct) 5.23 -> 5.13 ms per call with 10 registers spilled, 5.92 ms
 // without spills (193 registers: two workgroups per CU); the headline 2-3 % slower (profiles/r05_ab/split_planes.txt)
+#ifndef DIST_QSTRIDE
+#define DIST_QSTRIDE 64    // ints between the queue counters of two XCDs
+#endif
+#ifndef DIST_ILV
+#define DIST_ILV 1         // whole items are pixel block s of four vertically adjacent tiles (sweep_dist.hip: decode)
+#endif
+#ifndef DIST_ABL
+#define DIST_ABL 0         // timing only (wrong results), bits: 1 = every sample position computed twice, 2 = no texel loads
+#endif
 #ifndef DIST_ABL_NOB3
 #define DIST_ABL_NOB3 0    // timing only (wrong results): no barrier in front of the merge of the waves' softmax parts
 #endif

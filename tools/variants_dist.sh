@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../probabilistic-depth_amd/csrc"
 make -j8 >/dev/null
 mkdir -p ../../gpurun_variants
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Wno-inline-asm"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-atomic-optimizer-strategy=None -Wall -Wno-unused-function -Wno-inline-asm"
 SRC=${SRC:-sweep_dist}
 OTHERS=$(echo "capi.o sweep_direct.o sweep_pack.o pack_dist.o sweep_dist.o sweep_corr.o sweep_tiled.o dpv.o warp.o extras.o correlation_general.o ufield.o sweep_tiled_n2.o" | sed "s/\b$SRC\.o//")
 while [ $# -ge 2 ]; do
