@@ -62,6 +62,8 @@ struct DistArgs {
     int* qcnt;      // the eight per-XCD queue counters, qstride ints apart (in the workspace's tile-flag ints, which this kernel family does not use otherwise)
     int qstride;
     int tiles_x, ntile;
+    int one_each;   // no queue: workgroup i runs item i (launch_inst says when)
+    int nblk;       // workgroups of the launch
     int nonce;  // 1 .. 2047, another one per launch: tags the diagnostics count of this call (kernels.hpp: DIST_NONCE_SLOT)
 };
 #define KARG(type, field) kernarg_at<type>(offsetof(DistArgs, field))
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     // neighbouring tiles, whose source texels overlap, meet in that XCD's L2.  A workgroup whose queue is exhausted takes
     // items of the others.
     const int xcd = blockIdx.x & 7;
+    if (blockIdx.x == 0 && tid == 0) KARG(int*, queue)[DIST_NONCE_SLOT] = KARG(int, nonce);   // (diagnostics: whose count DIST_DIRECT_LAST_SLOT holds)
     auto band_tiles_of = [&](int q) { const int nt = KARG(int, ntile); return (nt >> 3) + (q < (nt & 7) ? 1 : 0); };
     auto band_first_of = [&](int q) {
         const int nt = KARG(int, ntile), qq = nt >> 3, rr8 = nt & 7;
@@ -150,12 +153,13 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     // them through the XCD's L2 at once.  (Round 5 handed out whole tiles, a workgroup running a tile's four blocks one
     // after the other, 9 us apart: L2 hit rate 67 %, with single blocks 84 % and half the misses -- profiles/r06_ab/.)
     auto items_of = [&](int q) { return 4 * band_tiles_of(q) * KARG(int, a.B); };
-    bool own_done = false;
+    int own_done = 0;   // (ints, not bools: a uniform bool that lives across the kernel is kept as a 64-bit lane mask)
     auto steal = [&]() -> int {   // (queue << 28) | index in the queue, or -1: every queue is exhausted
         int* qcnt = KARG(int*, qcnt);
         const int qs = KARG(int, qstride);
+#pragma unroll 1   // (unrolled, the seven queue numbers and their shifted forms were fourteen spilled scalars of the whole kernel)
         for (int j = 1; j < 8; ++j) {
-            const int q = (xcd + j) & 7, nq = items_of(q);
+            const int q = (opaque_s(xcd) + j) & 7, nq = items_of(q);
             if (__hip_atomic_load(&qcnt[q * qs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nq) continue;
             const int got = atomicAdd(&qcnt[q * qs], 1);
             if (got < nq) return (q << 28) | got;
@@ -164,8 +168,8 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     };
     auto resolve = [&](int got) -> int {
         const int n_own = items_of(xcd);
-        if (!own_done && got < n_own) return (xcd << 28) | got;
-        own_done = true;
+        if (!own_done && got < n_own) return (opaque_s(xcd) << 28) | got;
+        own_done = 1;
         return steal();
     };
     // floor(nn / dd) for 0 <= nn < 2^22, 0 < dd (an integer divide costs ~40 dependent instructions)
@@ -206,39 +210,41 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         ty_ = small_idx ? fdiv(tile, tiles_x) : tile / tiles_x;
         tx_ = tile - ty_ * tiles_x;
     };
-    // (when the grid covers every item -- small problems -- workgroup i takes item i of its XCD's band: no atomics)
-    const bool one_each = (long long)gridDim.x >= 8ll * ((KARG(int, ntile) + 7) / 8) * 4 * KARG(int, a.B);
+    // (when the grid covers every item -- small problems -- workgroup i takes item i of its XCD's band: no atomics.  Re-read from
+    //  the kernel arguments where it is used: a flag that lives across the kernel is a scalar register pair spilled)
+#define ONE_EACH (KARG(int, one_each) != 0)
     __syncthreads();
 
     // Persistent grid: the workgroups a CU starts with would run their first passes in lockstep -- every phase of all three at
     // once on the same pipes; the second and third begin 5 and 11 us later (they drift apart by themselves within a few
     // passes; -0.9 % / -1.8 % of the headline launch, profiles/r05_ab/staggered_start.txt).  Not where a workgroup runs one item.
-    if (DIST_STAGGER && !one_each) {
+    if (DIST_STAGGER && !ONE_EACH) {
         const int slot = ((int)blockIdx.x >> 3) / 32 % 3;
         for (int i = 0; i < slot * DIST_STAGGER; ++i) __builtin_amdgcn_s_sleep(100);
     }
-    int slot_par = 0;
-    int pt = 0;           // running pass counter: selects the set of row-table arrays
+    // loop-carried scalars of the kernel in ONE register: bit 0 = the slot of L.item in use, bit 1 = the set of row-table arrays of
+    // the pass (alternating), bits 2.. = 1 + the batch item whose tables (means, homography terms, camera constants) are in LDS
+    int state = 0;
     int n_direct = 0;     // (thread 0) pixel blocks evaluated directly
-    int b_tables = -1;    // batch item whose tables (means, homography terms, camera constants) are in LDS
     // The queue runs one item ahead: (thread 0) the atomic that pops item i + 1 is issued when item i starts, its result is
     // resolved and published in LDS in front of the LAST barrier of item i -- the workgroup goes from one pixel block to
     // the next without a barrier of the queue's own.
-    int got_own = (tid == 0 && !one_each) ? atomicAdd(&KARG(int*, qcnt)[xcd * KARG(int, qstride)], 1) : (int)(blockIdx.x >> 3);
+    int got_own = (tid == 0 && !ONE_EACH) ? atomicAdd(&KARG(int*, qcnt)[xcd * KARG(int, qstride)], 1) : (int)(blockIdx.x >> 3);
     // resolve_next(): BEFORE the block's stores are issued -- the result of the atomic is waited for with a vmcnt, and memory
     // operations complete in issue order: behind the stores that wait is the stores' whole latency, for thread 0's wave and, at
     // the next barrier, for the workgroup (2 us per pixel block when it was there).
     int next_item = -1;
-    auto resolve_next = [&]() { if (tid == 0) next_item = one_each ? -1 : resolve(got_own); };
+    // ("thread 0" asked of a value the optimiser cannot see through: the lane mask of `tid == 0` is not kept across the kernel)
+    auto resolve_next = [&]() { if (opaque_v((int)threadIdx.x) == 0) next_item = ONE_EACH ? -1 : resolve(got_own); };
     auto publish_next = [&]() {   // (thread 0, in front of a workgroup barrier)
-        if (tid == 0) {
-            L.item[slot_par] = next_item;
-            if (!one_each && !own_done) got_own = atomicAdd(&KARG(int*, qcnt)[xcd * KARG(int, qstride)], 1);
+        if (opaque_v((int)threadIdx.x) == 0) {
+            L.item[state & 1] = next_item;
+            if (!ONE_EACH && !own_done) got_own = atomicAdd(&KARG(int*, qcnt)[xcd * KARG(int, qstride)], 1);
         }
     };
     if (tid == 0) {
-        L.item[0] = one_each ? (got_own < items_of(xcd) ? (xcd << 28) | got_own : -1) : resolve(got_own);
-        if (!one_each && !own_done) got_own = atomicAdd(&KARG(int*, qcnt)[xcd * KARG(int, qstride)], 1);
+        L.item[0] = ONE_EACH ? (got_own < items_of(xcd) ? (xcd << 28) | got_own : -1) : resolve(got_own);
+        if (!ONE_EACH && !own_done) got_own = atomicAdd(&KARG(int*, qcnt)[xcd * KARG(int, qstride)], 1);
     }
     PDEPTH_LDS_BARRIER();   // the first item is published
 
@@ -246,19 +252,23 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         // (a plain LDS read: behind the barrier's memory clobber it cannot be hoisted.  Through a volatile generic pointer --
         //  round 5 -- it was a FLAT load, and a flat load is waited for with vmcnt(0): every item began by waiting out the
         //  previous pixel block's stores, 2 us per item)
-        const int item = __builtin_amdgcn_readfirstlane(L.item[slot_par]);
-        slot_par ^= 1;
+        const int item = __builtin_amdgcn_readfirstlane(L.item[state & 1]);
+        state ^= 1;
         if (item < 0) break;
         DSTAMP(0)   // queue
+        const int wave = opaque_s(__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6));   // (per item: its multiples are not kept -- spilled -- across the kernel)
         int b, tx, ty, sub;
         decode(item, b, tx, ty, sub);
         const int H = KARG(int, a.H), W = KARG(int, a.W), V = KARG(int, a.V), C = KARG(int, a.C), D = KARG(int, a.D);
         // per BATCH item, for every wave: scaled channel means, the views' homography terms, the camera constants, the item's
         // flags (visible behind the barrier in front of the first block's centring).  Items come out of the queues batch item
         // by batch item: the tables are rebuilt a few times per launch, not once per tile.
-        const bool new_b = b != b_tables;
+        const bool new_b = b + 1 != state >> 2;
         if (new_b) {
-            b_tables = b;
+            state = (state & 3) | ((b + 1) << 2);
+            // (the lane's roles re-derived here: hoisted out of the item loop, the invariants of this rarely run block were
+            //  spilled registers of the whole kernel)
+            const int tid = opaque_v((int)threadIdx.x), lane = tid & 63;
             const float* st = KARG(const float*, stats) + (size_t)b * STATS_STRIDE;
             if (wave == 0) {
                 // the scale (dist_layout.hpp: the same function of the same numbers as in the pack kernel) and the guard
@@ -440,7 +450,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                     // LDS atomics, issued behind the last plane of the run) -- on a rectified pair all four planes of a thread, and
                     // all 256 threads, meet in one or two rows, and atomics on one address are served lane by lane.  Straight-line
                     // code: a plane continues the run of the plane before it, or closes it.
-                    const int par = pt & 1;
+                    const int par = (state >> 1) & 1;
                     {
                         int ylo = 32767, yhi = -32768;
                         int rmin = 0, rmax = 0, ry = 0;
@@ -490,10 +500,14 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                         }
                         centred = true;
                     }
-                    // the pixel-side operands of lane (n, kq): high[NCHK], low[NCHK], tail -- from LDS every pass
+                    // the pixel-side operands of lane (n, kq): high[NCHK], low[NCHK], tail -- from LDS once per pass, or (DIST_BV_LDS)
+                    // chunk by chunk in front of the multiplications of every block: twenty registers for a second texel operand set
                     h8 Bv[NAC];
+                    const _Float16* const bsl = &L.Bs[(kq * 16 + n) * 8];
+                    if (!DIST_BV_LDS) {
 #pragma unroll
-                    for (int i = 0; i < NAC; ++i) Bv[i] = *reinterpret_cast<const h8*>(&L.Bs[((i * 4 + kq) * 16 + n) * 8]);
+                        for (int i = 0; i < NAC; ++i) Bv[i] = *reinterpret_cast<const h8*>(bsl + i * 512);
+                    }
                     // ---- the row table, cut into blocks of 16 texels: every wave for itself, lane = texel row yb + lane -----
                     const int yb = __builtin_amdgcn_readfirstlane(L.ired[par][0]), yt = __builtin_amdgcn_readfirstlane(L.ired[par][1]);
                     int nb = 0, lo = 0, nblk = 0, fb = 0;
@@ -519,7 +533,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                     const int iflag = __builtin_amdgcn_readfirstlane(L.iflag);
                     if (iflag != 0) fits = false;   // (the item is evaluated directly)
                     if (DIST_FORCE_DIRECT == -1 || DIST_FORCE_DIRECT == v) fits = false;   // (test builds)
-                    ++pt;
+                    state ^= 2;
                     const int rowoff = 16 * fb - lo;    // slot of texel x of this lane's row = x + rowoff
                     const bool go = fits && nb > 0;
                     DSTAMP(5)   // operands from LDS, row table cut into blocks
@@ -528,11 +542,6 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                     {
                         const int PB = (int)dist::plane_bytes(H, W), Wp = dist::wp(W);
                         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)srcv, 0, (int)dist::view_bytes(C, H, W), 0x00020000);
-                        v4i rs4;   // the same descriptor, spelled out for the inline asm
-                        {
-                            const unsigned long long pa = reinterpret_cast<unsigned long long>(srcv);
-                            rs4.x = (int)(unsigned)pa; rs4.y = (int)(unsigned)(pa >> 32) & 0xffff; rs4.z = (int)dist::view_bytes(C, H, W); rs4.w = 0x00020000;
-                        }
                         const int voffA = opaque_v(n * 16 + kq * PB);
                         // a block's texel operands in consumption order: (high c, low c) for c < NCHK, tail; NS register sets: NS
                         // blocks of the wave are in flight, every chunk refilled with the operands of the block after the next
@@ -551,7 +560,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                             boff = lane < nb ? ((yb + rho + dist::RING) * Wp + xs + dist::RING) * 16 : OOB;
                         }
                         auto fetch = [&](int set, int i, int soff) {   // chunk i: planes 4 i .. 4 i + 3 (the lane's: + kq, in voffA)
-                            if (DIST_ABL & 2) { S[set][i] = Bv[i]; return; }   // timing only: no texel loads
+                            if (DIST_ABL & 2) { S[set][i] = *reinterpret_cast<const h8*>(bsl + i * 512); return; }   // timing only: no texel loads
                             S[set][i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffA, soff + i * 4 * PB, 0));
                         };
                         auto fetch_block = [&](int set, int soff) {
@@ -571,7 +580,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                                 if (4 * g < nb) {   // uniform
                                     const int bo = __builtin_amdgcn_ds_bpermute(4 * (4 * g + kq), boff);
                                     const int vq = 4 * g + kq < nb ? bo + n * 16 : OOB;
-                                    dma_b128(rs4, lds_addr_of(&L.Qs[g * 256]), vq, QPL * PB);
+                                    dma_b128(rsrc, lds_addr_of(&L.Qs[g * 256]), vq, QPL * PB);
                                 }
                             }
 #pragma unroll
@@ -598,16 +607,32 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                                     const bool more = bj + NS < b1;   // uniform
                                     const int soff = more ? __builtin_amdgcn_readlane(boff, bj + NS) : 0;
                                     v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+                                    if (DIST_BV_LDS) {
 #pragma unroll
-                                    for (int c = 0; c < NCHK; ++c) {
-                                        acc = DIST_MFMA(S[u][c], Bv[c], acc);
-                                        acc = DIST_MFMA(S[u][c], Bv[NCHK + c], acc);
-                                        if (more) fetch(u, c, soff);
-                                        acc = DIST_MFMA(S[u][NCHK + c], Bv[c], acc);
-                                        if (more) fetch(u, NCHK + c, soff);
+                                        for (int c = 0; c < NCHK; ++c) {
+                                            const h8 bh = *reinterpret_cast<const h8*>(bsl + c * 512);
+                                            const h8 bl = *reinterpret_cast<const h8*>(bsl + (NCHK + c) * 512);
+                                            acc = DIST_MFMA(S[u][c], bh, acc);
+                                            acc = DIST_MFMA(S[u][NCHK + c], bh, acc);
+                                            if (more) fetch(u, NCHK + c, soff);
+                                            acc = DIST_MFMA(S[u][c], bl, acc);
+                                            if (more) fetch(u, c, soff);
+                                        }
+                                        const h8 bt = *reinterpret_cast<const h8*>(bsl + (NAC - 1) * 512);
+                                        acc = DIST_MFMA(S[u][NAC - 1], bt, acc);
+                                        if (more) fetch(u, NAC - 1, soff);
+                                    } else {
+#pragma unroll
+                                        for (int c = 0; c < NCHK; ++c) {
+                                            acc = DIST_MFMA(S[u][c], Bv[c], acc);
+                                            acc = DIST_MFMA(S[u][c], Bv[NCHK + c], acc);
+                                            if (more) fetch(u, c, soff);
+                                            acc = DIST_MFMA(S[u][NCHK + c], Bv[c], acc);
+                                            if (more) fetch(u, NCHK + c, soff);
+                                        }
+                                        acc = DIST_MFMA(S[u][NAC - 1], Bv[NAC - 1], acc);
+                                        if (more) fetch(u, NAC - 1, soff);
                                     }
-                                    acc = DIST_MFMA(S[u][NAC - 1], Bv[NAC - 1], acc);
-                                    if (more) fetch(u, NAC - 1, soff);
                                     // Y[texel 4 kq ..][pixel n] of the block
                                     *reinterpret_cast<v4f*>(&L.Ys[n * XSTRIDE + 16 * bj + 4 * kq]) = acc;
                                 }
@@ -660,6 +685,9 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 // Passes left to the direct evaluation: the reference's own form on the packed features -- per plane the four
                 // taps of every group of 8 channels by two 16-byte loads each (high + low parts), the pixel's centred reference
                 // features from the operand image in LDS.  An item whose features did not fit the fp16 range: NaN.
+                // (the shapes re-read here: kept from the top of the item for this rarely run block, they were spilled scalars)
+                const int H = KARG(int, a.H), W = KARG(int, a.W), V = KARG(int, a.V), C = KARG(int, a.C), D = KARG(int, a.D);
+                const int b = opaque_s((state >> 2) - 1);   // (the batch item in work)
                 const v4f c0 = *reinterpret_cast<const v4f*>(&L.cst[0]), c1 = *reinterpret_cast<const v4f*>(&L.cst[4]);
                 const bool ovf = (L.iflag & 1) != 0;
                 const int PB = (int)dist::plane_bytes(H, W), Wp = dist::wp(W);
@@ -803,11 +831,10 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     // nothing was counted that needs resetting, and a returning atomic per workgroup on one address is what such a launch
     // cannot afford: a workgroup with direct passes -- rare -- adds them to the published count itself, tagged with the call's
     // nonce (a count left by another call is replaced).
-    if (tid == 0) {
+    if (opaque_v((int)threadIdx.x) == 0) {
         int* queue = KARG(int*, queue);
         const int nonce = KARG(int, nonce);
-        if (blockIdx.x == 0) queue[DIST_NONCE_SLOT] = nonce;
-        if (one_each) {
+        if (ONE_EACH) {
             if (n_direct) {
                 int old = atomicAdd(&queue[DIST_DIRECT_LAST_SLOT], 0);
                 for (;;) {
@@ -820,7 +847,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         } else {
             if (n_direct) atomicAdd(&queue[DIST_DIRECT_SLOT], n_direct);
             const int done = atomicAdd(&queue[DIST_DONE_SLOT], 1);
-            if (done == (int)gridDim.x - 1) {
+            if (done == KARG(int, nblk) - 1) {
                 const int nd = atomicAdd(&queue[DIST_DIRECT_SLOT], 0);
                 for (int q = 0; q < 8; ++q) KARG(int*, qcnt)[q * KARG(int, qstride)] = 0;
                 queue[DIST_DONE_SLOT] = 0;
@@ -865,7 +892,9 @@ hipError_t launch_inst(const SweepArgs& a, const char* packed, const float* stat
     da.nonce = next_nonce();
     // up to DIST_ONE_EACH_X items per resident workgroup there is no queue: a workgroup per item (sweep_dist_knobs.hpp)
     const long long need = 8ll * ((tiles + 7) / 8) * 4 * a.B;   // a workgroup per pixel block of the largest XCD band, times 8
-    if (need <= DIST_ONE_EACH_X * nblk) nblk = need;
+    da.one_each = need <= DIST_ONE_EACH_X * nblk;
+    if (da.one_each) nblk = need;
+    da.nblk = (int)nblk;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, stream, da);
     return hipGetLastError();
 }

@@ -2,28 +2,25 @@
 #pragma once
 
 #ifndef DIST_MAXB1
-#define DIST_MAXB1 34      // blocks of 16 texels a pass can take, D <= 64 (22 until the end of round 5: the headline is indifferent, wide baselines evaluate fewer passes directly; three workgroups per CU either way)
+#define DIST_MAXB1 24      // blocks of 16 texels a pass can take, D <= 64: the most that leaves FOUR workgroups per CU (38 KB of LDS; round 5: 34 at three)
 #endif
 #ifndef DIST_MAXB2
 #define DIST_MAXB2 34      // ... D > 64 (the most that leaves three workgroups per CU: 35 -> two; config 5: 32 -> 34 = 6 809 -> 1 482 direct passes, 5.58 -> 5.03 ms per call)
 #endif
-#ifndef DIST_MAXB_NP2
-#define DIST_MAXB_NP2 26   // ... of a pass over two pixel blocks (D <= 64): 75 KB of LDS per workgroup, two per CU
-#endif
-#ifndef DIST_NP2
-#define DIST_NP2 0         // 1: whole tiles at D <= 64 run two pixel blocks per pass (built, parity-green, measured 25 % SLOWER: it
-#endif                     //    saves 4 % of the vector instructions and leaves two workgroups per CU instead of three)
 #ifndef DIST_OCC1
-#define DIST_OCC1 3        // minimum waves per SIMD asked of the compiler at D <= 64: 167 registers with two texel operand sets, nothing spilled,
-#endif                     //    three workgroups per CU (2: the allocator takes 178 -- two workgroups per CU)
+#define DIST_OCC1 4        // minimum waves per SIMD asked of the compiler at D <= 64: 128 registers (one texel operand set), four workgroups per CU:
+#endif                     //    0.332 -> 0.307 ms against three workgroups with two operand sets (profiles/r06_ab/)
 #ifndef DIST_OCC2
 #define DIST_OCC2 3        // ... at D > 64: without the bound the allocator takes 170 registers (two workgroups per CU: config 5 20 % slower),
 #endif                     //    with it 165, nothing spilled
 #ifndef DIST_SETS1
-#define DIST_SETS1 2       // texel operand register sets of a wave (= its blocks in flight) at D <= 64 ...
+#define DIST_SETS1 1       // texel operand register sets of a wave (= its blocks in flight) at D <= 64 (2 at three workgroups per CU: 4 % faster than 1 there, 7 % slower than 1 at four) ...
 #endif
 #ifndef DIST_SETS2
-#define DIST_SETS2 1       // ... and at D > 64 (2: 168 registers under the launch bound, 8 of them spilled)
+#define DIST_SETS2 2       // ... and at D > 64 (168 registers under the launch bound, 8 of them spilled: config 5 3.89 -> 3.51 ms all the same)
+#endif
+#ifndef DIST_BV_LDS
+#define DIST_BV_LDS 0      // 1: the pixel-side operands are read from LDS in front of every block's multiplications instead of once per pass
 #endif
 #ifndef DIST_XPRIO
 #define DIST_XPRIO 1       // wave priority in the matrix phase
@@ -37,14 +34,8 @@
 #ifndef DIST_COL_ALT
 #define DIST_COL_ALT 0     // columns of a band from both image borders inwards (1) | left to right (0: 1.2 % faster on the forward motion, 5 % fewer L2 misses)
 #endif
-// 1: a pass whose texel blocks do not fit LDS is retried as two passes of 32 planes before the direct evaluation.  Built,
-// parity-green, off: config 5 (6 809 of 524 288 passes direct) 5.23 -> 5.13 ms per call with 10 registers spilled, 5.92 ms
-// without spills (193 registers: two workgroups per CU); the headline 2-3 % slower (profiles/r05_ab/split_planes.txt)
 #ifndef DIST_QSTRIDE
-#define DIST_QSTRIDE 64    // ints between the queue counters of two XCDs
-#endif
-#ifndef DIST_ILV
-#define DIST_ILV 1         // whole items are pixel block s of four vertically adjacent tiles (sweep_dist.hip: decode)
+#define DIST_QSTRIDE 64    // ints between the queue counters of two XCDs (1 -- all eight on one line, round 5 --: memory-side atomics on one line are served one by one, ~13 ns each)
 #endif
 #ifndef DIST_ABL
 #define DIST_ABL 0         // timing only (wrong results), bits: 1 = every sample position computed twice, 2 = no texel loads
@@ -57,26 +48,13 @@
 #ifndef DIST_DIRECT_UNROLL
 #define DIST_DIRECT_UNROLL 1
 #endif
-#ifndef DIST_SPLIT_PLANES
-#define DIST_SPLIT_PLANES 0
-#endif
-// tiles at the end of every XCD queue that are handed out as four single pixel blocks, in percent of the workgroups per XCD:
-// the end of a launch is then a pass long instead of a tile long.  0: 0.408 / 0.377 ms, 100: 0.402 / 0.363, 200: 0.404 / 0.369,
-// 400: 0.409 / 0.379 (profiles/r05_ab/queue_tail_as_single_blocks.txt)
-#ifndef DIST_TAIL_PCT
-#define DIST_TAIL_PCT 100
-#endif
 #ifndef DIST_STAGGER
-#define DIST_STAGGER 2       // start-up stagger of the persistent workgroups, in sleeps of 6 400 cycles per CU slot (0: off; 1 / 3 / 4: less)
-#endif
-#ifndef DIST_SPI1_BELOW
-#define DIST_SPI1_BELOW 2  // single pixel blocks as queue items below this many tiles per workgroup
+#define DIST_STAGGER 0       // start-up stagger of the persistent workgroups, in sleeps of 6 400 cycles per CU slot (round 5: 2; with single pixel blocks as items the workgroups drift apart within a pass: 0 is as fast on the headline, 5 % faster at B = 1)
 #endif
 #ifndef DIST_ONE_EACH_X
-// no queue -- a workgroup per item, the hardware's dispatcher instead of the per-XCD counters -- up to this many items per
-// resident workgroup.  Packed entry, us per call at 2 / 6 (profiles/r05_ab/workgroup_per_item_range.txt): B=4 64x128 60.7 / 45.5,
-// B=8 64x128 84.6 / 78.5, B=1 128x256 58.9 / 45.9, B=4 128x256 119 / 102, B=1 256x512 185 / 159, B=2 256x512 229 / 214;
-// beyond: B=3 256x512 (8 x) 294 persistent / 307, B=4 256x512 (10.7 x) 401 / 435
+// no queue -- a workgroup per item (pixel block), the hardware's dispatcher instead of the per-XCD counters -- up to this many items
+// per resident workgroup (2 / 6 / 12 / 24: the headline and config 5 are indifferent; B = 1 256x512 -- 10.7 items per workgroup --
+// 94 us persistent, 114 us with a workgroup per item: profiles/r06_ab/)
 #define DIST_ONE_EACH_X 6
 #endif
 #ifndef DIST_GUARD_RATIO

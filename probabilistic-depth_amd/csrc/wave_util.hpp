@@ -26,7 +26,8 @@ __device__ __forceinline__ int opaque_s(int x) { asm volatile("" : "+s"(x)); ret
 // LDS-DMA (buffer_load ... lds): a wave-instruction moves 16 bytes per active lane from memory to LDS address
 // m0 + 16 * lane, no registers in between.  Issued from inline asm (the compiler must not know that these loads write LDS,
 // or it drains them in front of the next LDS read); counted in vmcnt like every load: the issuing wave waits for them by hand.
-__device__ __forceinline__ void dma_b128(v4i rsrc, unsigned lds_addr, int voff, int soff) {
+template <typename Rsrc>   // (v4i, or the compiler's own __amdgpu_buffer_rsrc_t: the descriptor the builtin loads of the same view use)
+__device__ __forceinline__ void dma_b128(Rsrc rsrc, unsigned lds_addr, int voff, int soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
