@@ -120,8 +120,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
 #endif
     if (poison_on_foreign_layout(da.a, da.queue, LAYOUT_DIST16)) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x;
 
     {
         const float* dc = KARG(const float*, a.d_candi);
@@ -273,7 +272,9 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
             if (wave == 0) {
                 // the scale (dist_layout.hpp: the same function of the same numbers as in the pack kernel) and the guard
                 float am = st[STATS_AMAX + lane], sv = st[STATS_VAR + lane], sl_ = st[STATS_LAG + lane];
-                if (lane + 64 < STATS_VAR) { am = fmaxf(am, st[STATS_AMAX + lane + 64]); sv += st[STATS_VAR + lane + 64]; sl_ += st[STATS_LAG + lane + 64]; }
+                if (lane + 64 < STATS_VAR) {
+                    am = fmaxf(am, st[STATS_AMAX + lane + 64]); sv += st[STATS_VAR + lane + 64]; sl_ += st[STATS_LAG + lane + 64];
+                }
 #pragma unroll
                 for (int sh = 32; sh >= 1; sh >>= 1) {
                     am = fmaxf(am, __shfl_xor(am, sh)); sv += __shfl_xor(sv, sh); sl_ += __shfl_xor(sl_, sh);
@@ -822,7 +823,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         }   // the pixel block
     }   // items
 #ifdef DIST_STAMPS
-    if (lane == 0)
+    if ((threadIdx.x & 63) == 0)
         for (int i = 0; i < 12; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(int*, queue) + 8) + i, stamp_acc[i]);
 #endif
 

@@ -53,11 +53,16 @@ __device__ __forceinline__ float block_max_256(float v, float* scratch) {
     return fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
 }
 
+// The sample: rows of EVERY view that enters the cost -- the V source views and, where the caller has it (the NCHW entry, the
+// encoder epilogue), the reference view (`extra`): the maximum that sets the fp16 scale, the energy and the lagged spread of the
+// guard and the constant that is subtracted are the pooled ones.  (Round 5 sampled source view 0 only: a view unlike it, or a
+// reference with another exposure, was invisible to the scale and to the guard.)  nv views `vstride` floats apart.
 template <bool POOLED>
-__device__ __forceinline__ void channel_stats(const float* __restrict__ plane, int H, int W, int rate, int IW, float* __restrict__ mu_out,
-                                              float* __restrict__ var_out, int centre) {
+__device__ __forceinline__ void channel_stats(const float* __restrict__ plane, long long vstride, int nv, const float* __restrict__ extra, int H,
+                                              int W, int rate, int IW, float* __restrict__ mu_out, float* __restrict__ var_out, int centre) {
     __shared__ float scratch[4];
-    const int nrows = min(H, STATS_ROWS), total = nrows * W;
+    const int nvw = nv + (extra ? 1 : 0);
+    const int nrows = min(H, nvw == 1 ? STATS_ROWS : max(2, min(STATS_ROWS, 16 / nvw))), per_view = nrows * W, total = nvw * per_view;
     // the partner of a sample for the lagged spread: STATS_LAG_PX texels to the right (to the left in the last columns)
     const int lag = W > 2 * STATS_LAG_PX ? STATS_LAG_PX : (W > 1 ? W / 2 : 0);
     float s = 0.0f, s2 = 0.0f, am = 0.0f, dl = 0.0f;
@@ -69,16 +74,18 @@ __device__ __forceinline__ void channel_stats(const float* __restrict__ plane, i
             const int i = i0 + 256 * u;
             v[u] = 0.0f; w[u] = 0.0f;
             if (i < total) {
-                const int r = i / W, x = i - r * W, y = stats_row(r, nrows, H);
+                const int vw = i / per_view, iv = i - vw * per_view;
+                const float* pl = vw < nv ? plane + (size_t)vw * vstride : extra;
+                const int r = iv / W, x = iv - r * W, y = stats_row(r, nrows, H);
                 const int x2 = x + lag < W ? x + lag : x - lag;
                 if (POOLED) {
                     // (the mean of the pooled channel = the mean of the image itself: one image row per sampled map row, every
                     //  rate-th column -- the variance, which only feeds the guards, is the image's, an upper bound)
-                    v[u] = plane[((size_t)y * rate) * IW + (size_t)x * rate];
-                    w[u] = plane[((size_t)y * rate) * IW + (size_t)x2 * rate];
+                    v[u] = pl[((size_t)y * rate) * IW + (size_t)x * rate];
+                    w[u] = pl[((size_t)y * rate) * IW + (size_t)x2 * rate];
                 } else {
-                    v[u] = plane[(size_t)y * W + x];
-                    w[u] = plane[(size_t)y * W + x2];
+                    v[u] = pl[(size_t)y * W + x];
+                    w[u] = pl[(size_t)y * W + x2];
                 }
             }
         }
@@ -110,7 +117,8 @@ __device__ __forceinline__ void channel_stats(const float* __restrict__ plane, i
 
 // flags != nullptr: the call's workspace bookkeeping is done here (the sweep kernel that packs the source itself has no
 // pack kernel in front of it): tile flags and queue slots cleared, the pack counters of the sweep kernel zeroed.
-__global__ __launch_bounds__(256) void feature_stats_kernel(const float* __restrict__ src, long long bstride, int C, int H, int W,
+__global__ __launch_bounds__(256) void feature_stats_kernel(const float* __restrict__ src, long long bstride, long long vstride, int V,
+                                                            const float* __restrict__ ref, long long ref_bstride, int C, int H, int W,
                                                             float* __restrict__ stats, int centre, int* __restrict__ flags, int nflags,
                                                             int* __restrict__ pack_ctr, int nctr) {
     const int c = blockIdx.x, b = blockIdx.y;
@@ -127,7 +135,8 @@ __global__ __launch_bounds__(256) void feature_stats_kernel(const float* __restr
     }
     if (c == 0 && threadIdx.x < STATS_NFLAG) reinterpret_cast<int*>(st + STATS_FLAGS)[threadIdx.x] = 0;
     if (c >= STATS_VAR) return;   // (only the first 80 channels are recorded: the centring kernels take C <= 72)
-    channel_stats<false>(src + (size_t)b * bstride + (size_t)c * H * W, H, W, 1, W, st + c, st + STATS_VAR + c, centre);
+    channel_stats<false>(src + (size_t)b * bstride + (size_t)c * H * W, vstride, V, ref ? ref + (size_t)b * ref_bstride + (size_t)c * H * W : nullptr,
+                         H, W, 1, W, st + c, st + STATS_VAR + c, centre);
 }
 
 // the same for the encoder epilogue: feat [B*(V+1), Cf, H, W], rgb [B*(V+1), 3, H*rate, W*rate]; source view 0 of item b
@@ -142,8 +151,9 @@ __global__ __launch_bounds__(256) void view_stats_kernel(const float* __restrict
     if (c == 0 && threadIdx.x < STATS_NFLAG) reinterpret_cast<int*>(st + STATS_FLAGS)[threadIdx.x] = 0;
     if (c >= STATS_VAR) return;
     const size_t bv = (size_t)b * (V + 1);
-    if (c < Cf) channel_stats<false>(feat + (bv * Cf + c) * H * W, H, W, 1, W, st + c, st + STATS_VAR + c, centre);
-    else channel_stats<true>(rgb + (bv * 3 + (c - Cf)) * (size_t)IH * IW, H, W, rate, IW, st + c, st + STATS_VAR + c, centre);
+    // (the V source views and the reference view behind them: V + 1 views of the item)
+    if (c < Cf) channel_stats<false>(feat + (bv * Cf + c) * H * W, (long long)Cf * H * W, V + 1, nullptr, H, W, 1, W, st + c, st + STATS_VAR + c, centre);
+    else channel_stats<true>(rgb + (bv * 3 + (c - Cf)) * (size_t)IH * IW, 3ll * IH * IW, V + 1, nullptr, H, W, rate, IW, st + c, st + STATS_VAR + c, centre);
 }
 
 // the first block of a pack kernel: queue counters and slots cleared, the tiled kernel's guard set (header)
@@ -376,8 +386,8 @@ hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t strea
     float4* packed = reinterpret_cast<float4*>(static_cast<char*>(workspace) + flag_bytes(a.B, a.H, a.W));
     float* stats = reinterpret_cast<float*>(static_cast<char*>(workspace) + sweep_ws_stats_offset(a.B, a.V, a.C, a.H, a.W));
     const int HW = a.H * a.W;
-    hipLaunchKernelGGL(feature_stats_kernel, dim3(a.C < STATS_VAR ? a.C : STATS_VAR, a.B), dim3(256), 0, stream, a.src, a.src_bstride, a.C,
-                       a.H, a.W, stats, (centre && a.C <= 72) ? 1 : 0, (int*)nullptr, 0, (int*)nullptr, 0);
+    hipLaunchKernelGGL(feature_stats_kernel, dim3(a.C < STATS_VAR ? a.C : STATS_VAR, a.B), dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, 1,
+                       (const float*)nullptr, 0ll, a.C, a.H, a.W, stats, (centre && a.C <= 72) ? 1 : 0, (int*)nullptr, 0, (int*)nullptr, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     dim3 pgrid((HW + 255) / 256, a.B * a.V);
@@ -392,8 +402,8 @@ hipError_t launch_pack_c4(const SweepArgs& a, void* workspace, hipStream_t strea
 }
 
 hipError_t launch_feature_stats(const SweepArgs& a, float* stats, hipStream_t stream) {
-    hipLaunchKernelGGL(feature_stats_kernel, dim3(a.C < STATS_VAR ? a.C : STATS_VAR, a.B), dim3(256), 0, stream, a.src, a.src_bstride, a.C,
-                       a.H, a.W, stats, 1, (int*)nullptr, 0, (int*)nullptr, 0);
+    hipLaunchKernelGGL(feature_stats_kernel, dim3(a.C < STATS_VAR ? a.C : STATS_VAR, a.B), dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V,
+                       a.ref, a.ref_bstride, a.C, a.H, a.W, stats, 1, (int*)nullptr, 0, (int*)nullptr, 0);
     return hipGetLastError();
 }
 hipError_t launch_view_stats(const SweepArgs& a, const float* feat, const float* rgb, int rate, int img_h, int img_w, float* stats, hipStream_t stream) {
@@ -410,8 +420,8 @@ int* sweep_ws_pack_counters(const SweepArgs& a, void* workspace) {
 }
 hipError_t launch_stats_only(const SweepArgs& a, void* workspace, hipStream_t stream) {
     float* stats = reinterpret_cast<float*>(static_cast<char*>(workspace) + sweep_ws_stats_offset(a.B, a.V, a.C, a.H, a.W));
-    hipLaunchKernelGGL(feature_stats_kernel, dim3(a.C < STATS_VAR ? a.C : STATS_VAR, a.B), dim3(256), 0, stream, a.src, a.src_bstride, a.C,
-                       a.H, a.W, stats, 1, reinterpret_cast<int*>(workspace), (int)(flag_bytes(a.B, a.H, a.W) / sizeof(int)),
+    hipLaunchKernelGGL(feature_stats_kernel, dim3(a.C < STATS_VAR ? a.C : STATS_VAR, a.B), dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, 1,
+                       (const float*)nullptr, 0ll, a.C, a.H, a.W, stats, 1, reinterpret_cast<int*>(workspace), (int)(flag_bytes(a.B, a.H, a.W) / sizeof(int)),
                        sweep_ws_pack_counters(a, workspace), 2 * a.B);
     return hipGetLastError();
 }

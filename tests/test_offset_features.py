@@ -125,6 +125,17 @@ def test_centred_features_do_not_raise_the_guard(dev):
     assert _native.noncentred_guard(2, 64, 128) is False
 
 
+def _same_answer(algo, packed, nchw):
+    """The packed entry against the NCHW entry of the same kernel.  Bit for bit for the float4 layouts; the distance-form
+    kernel's NCHW entry (round 6) takes its channel statistics over the source views AND the reference view, which
+    pdepth_pack_source_f32 does not have: another centring constant and scale, the same costs to rounding."""
+    for p_, n_ in zip(packed, nchw):
+        if algo in ("auto", "dist"):
+            assert torch.allclose(p_, n_, rtol=2e-5, atol=5e-5), algo
+        else:
+            assert torch.equal(p_, n_), algo
+
+
 def test_packed_source_is_tied_to_the_kernel_family(dev):
     """The centred layout (ALGO_AUTO / 'corr', L2) and the plain one (the tiled kernel: L1, forced selectors) differ, and
     the library cannot tell them apart from the host: the binding refuses to sweep a packed source with a descriptor that
@@ -145,7 +156,7 @@ def test_packed_source_is_tied_to_the_kernel_family(dev):
     for ps, algo in ((centred, "auto"), (plain, "tiled1"), (corr, "corr")):
         cp, lp, dp = ops.sweep_dpv(d["ref"], ps, *args, algo=algo, want_cost=True)
         ca, la, da = ops.sweep_dpv(d["ref"], d["src"], *args, algo=algo, want_cost=True)
-        assert torch.equal(cp, ca) and torch.equal(lp, la) and torch.equal(dp, da), algo
+        _same_answer(algo, (cp, lp, dp), (ca, la, da))
         first[algo] = cp
     # a second and a third sweep of the same packed source (the kernel leaves the workspace ready for the next call)
     for _ in range(2):
@@ -174,7 +185,7 @@ def test_a_foreign_packed_layout_is_detected_on_the_device(dev):
         ps.layout = honest
         cp, _, dp = ops.sweep_dpv(d["ref"], ps, *args, algo=pack_algo, want_cost=True)
         ca, _, da = ops.sweep_dpv(d["ref"], d["src"], *args, algo=pack_algo, want_cost=True)
-        assert torch.equal(cp, ca) and torch.equal(dp, da), pack_algo
+        _same_answer(pack_algo, (cp, dp), (ca, da))
 
 
 def test_passes_that_do_not_fit_are_evaluated_directly(dev):
