@@ -105,10 +105,16 @@ bool uses_dist(const pdepth_sweep_desc* d) {
     return pdepth::sweep_dist_supports(shape_args(d));
 }
 //   correlation form on mean-centred features (sweep_corr.hip; centred channel-group-planar layout): on request
+//   (round 4's default; since round 6 in lab builds only -- make LAB=1 --, like the cell-list and first matrix-pipe kernels)
 bool uses_corr(const pdepth_sweep_desc* d) {
+#ifndef PDEPTH_LAB
+    (void)d;
+    return false;
+#else
     if (!uses_packed_source(d) || d->metric != PDEPTH_METRIC_L2) return false;
     if (d->algo != PDEPTH_ALGO_CORR && !(d->algo == PDEPTH_ALGO_AUTO && sweep_impl() == IMPL_CORR)) return false;
     return pdepth::sweep_corr_supports(shape_args(d));
+#endif
 }
 int source_layout(const pdepth_sweep_desc* d) {
     if (!uses_packed_source(d)) return PDEPTH_LAYOUT_NONE;
@@ -138,8 +144,8 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
             return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_MFMA needs the L2 metric, D <= 128 and C <= 72", who);
     }
 #else
-    if (d->algo == PDEPTH_ALGO_CELLS || d->algo == PDEPTH_ALGO_MFMA)
-        return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_CELLS / PDEPTH_ALGO_MFMA exist in lab builds only (make LAB=1)", who);
+    if (d->algo == PDEPTH_ALGO_CELLS || d->algo == PDEPTH_ALGO_MFMA || d->algo == PDEPTH_ALGO_CORR)
+        return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_CELLS / PDEPTH_ALGO_MFMA / PDEPTH_ALGO_CORR exist in lab builds only (make LAB=1)", who);
 #endif
     if (d->algo == PDEPTH_ALGO_CORR && !uses_corr(d))
         return fail(PDEPTH_E_ARG, "%s: PDEPTH_ALGO_CORR needs the L2 metric, D <= 128 and C <= 72", who);
@@ -170,8 +176,8 @@ int sweep_common(const pdepth_sweep_desc* d, const pdepth_camera* cam, const flo
         if (d->algo == PDEPTH_ALGO_TILED_2)
             return launched(pdepth::launch_sweep_tiled_n2(a, workspace, (hipStream_t)stream, packed_ready), who);
         if (uses_dist(d)) return launched(pdepth::launch_sweep_dist(a, workspace, (hipStream_t)stream, packed_ready), who);
-        if (uses_corr(d)) return launched(pdepth::launch_sweep_corr(a, workspace, (hipStream_t)stream, packed_ready), who);
 #ifdef PDEPTH_LAB
+        if (uses_corr(d)) return launched(pdepth::launch_sweep_corr(a, workspace, (hipStream_t)stream, packed_ready), who);
         if (d->algo == PDEPTH_ALGO_MFMA || (d->algo == PDEPTH_ALGO_AUTO && sweep_impl() == IMPL_MFMA && pdepth::sweep_mfma_supports(a)))
             return launched(pdepth::launch_sweep_mfma(a, workspace, (hipStream_t)stream, packed_ready), who);
         if (d->algo == PDEPTH_ALGO_CELLS || (d->algo == PDEPTH_ALGO_AUTO && d->metric == PDEPTH_METRIC_L2 &&

@@ -46,10 +46,10 @@
 
 #include <climits>
 
-#include "geometry.hpp"
-#include "kernels.hpp"
-#include "pack_body.hpp"
-#include "pick.hpp"
+#include "../geometry.hpp"
+#include "../kernels.hpp"
+#include "../pack_body.hpp"
+#include "../pick.hpp"
 #include "sweep_corr_knobs.hpp"
 
 namespace pdepth {

@@ -34,7 +34,7 @@ def test_bench_workload_against_the_oracle(dev, pose):
     one = {k: (v[item:item + 1] if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
     ocost, ologp, odepth = oracle_batch(one)
     cd, ld, dd = _sweep(d, "direct")
-    for algo in ("auto", "corr", "tiled1", "tiled2", "direct"):
+    for algo in ("auto", "tiled1", "direct"):
         cost, logp, depth = _sweep(d, algo)
         np.testing.assert_allclose(cost[item].cpu().numpy(), ocost[0].numpy(), rtol=COST_RTOL, atol=COST_ATOL, err_msg=algo)
         np.testing.assert_allclose(logp[item].cpu().numpy(), ologp[0].numpy(), rtol=0, atol=2e-4, err_msg=algo)
@@ -56,7 +56,7 @@ def test_config5_reduced_area_against_the_oracle(dev):
     b = synth.make_batch(5, 2, C=67, D=128, H=64, W=128, V=4, pose="mono")
     ocost, ologp, odepth = oracle_batch(b)
     d = to_dev(b, dev)
-    for algo in ("auto", "corr", "tiled1", "direct"):
+    for algo in ("auto", "tiled1", "direct"):
         cost, logp, depth = _sweep(d, algo)
         np.testing.assert_allclose(cost.cpu().numpy(), ocost.numpy(), rtol=COST_RTOL, atol=COST_ATOL, err_msg=algo)
         np.testing.assert_allclose(logp.cpu().numpy(), ologp.numpy(), rtol=0, atol=2e-4, err_msg=algo)
@@ -71,7 +71,7 @@ def test_config5_full_size_properties(dev):
     d = to_dev(b, dev)
     cd, ld, dd = _sweep(d, "direct")
     assert torch.isfinite(cd).all() and (cd >= 0).all()
-    for algo in ("auto", "corr", "tiled1"):
+    for algo in ("auto", "tiled1"):
         cost, logp, depth = _sweep(d, algo)
         assert torch.isfinite(cost).all() and (cost >= 0).all()
         assert (torch.exp(logp).sum(1) - 1).abs().max().item() < 2e-5              # a distribution over D
@@ -108,7 +108,7 @@ def test_config5_full_size_against_the_oracle_at_sampled_pixels(dev):
     ologp = O.log_dpv(ocost.reshape(1, D, 1, -1))
     odepth = O.dpv_to_depthmap(ologp, b["d_candi"], BV_log=True).reshape(-1)
     d = to_dev(b, dev)
-    for algo in ("auto", "corr", "tiled1", "direct"):
+    for algo in ("auto", "tiled1", "direct"):
         cost, logp, depth = _sweep(d, algo)
         c_at = cost.reshape(1, D, H * W)[:, :, idx.to(dev)].cpu()
         l_at = logp.reshape(1, D, H * W)[:, :, idx.to(dev)].cpu()
@@ -144,7 +144,7 @@ def test_band_mode_on_encoder_features(dev):
     mean_abs = float(b["ref"].mean(dim=(0, 2, 3)).abs().mean())
     ocost, ologp, odepth = oracle_batch(b)
     d = to_dev(b, dev)
-    for algo in ("auto", "corr", "tiled1", "direct"):
+    for algo in ("auto", "tiled1", "direct"):
         cost, logp, depth = _sweep(d, algo)
         err = (depth.cpu() - odepth).abs().max().item()
         assert err <= DEPTH_ATOL, f"{algo}: depth differs by {err:.3e} on encoder features (mean |channel mean| {mean_abs:.2f})"

@@ -129,7 +129,7 @@ def test_product_library_carries_no_lab_bench():
     csrc = os.path.join(REPO, "probabilistic-depth_amd", "csrc")
     mk = open(os.path.join(csrc, "Makefile")).read()
     srcs = re.search(r"^SRCS = (.*)$", mk, re.M).group(1).split()
-    assert not any(s.startswith("lab/") for s in srcs) and "sweep_corr.hip" in srcs and "ifdef LAB" in mk
+    assert not any(s.startswith("lab/") for s in srcs) and "sweep_dist.hip" in srcs and "sweep_corr.hip" not in srcs and "ifdef LAB" in mk
     for f in srcs:
         if f.startswith("sweep_"):
             n = len(re.findall(r"^\s*#\s*if", open(os.path.join(csrc, f)).read(), re.M))
@@ -139,9 +139,10 @@ def test_product_library_carries_no_lab_bench():
     for n in names:
         assert hasattr(lib, n)
     assert (_native.ALGO_CORR, _native.ALGO_DIST) == (6, 7)
-    # the lab selectors (the cell-list and fp32-matrix kernels of rounds 2 / 3) are refused by the product library, by name
+    # the lab selectors (the cell-list, fp32-matrix and correlation-form kernels of rounds 2 / 3 / 4) are refused by the product
+    # library, by name
     cam = _native.Camera(1, 1, 1, 1, 1)
-    for algo in (_native.ALGO_CELLS, _native.ALGO_MFMA):
+    for algo in (_native.ALGO_CELLS, _native.ALGO_MFMA, _native.ALGO_CORR):
         desc = _native.SweepDesc(1, 1, 4, 8, 8, 16, 0, algo, 0, 1.0, 512, 512, 512)
         rc = lib.pdepth_sweep_dpv_f32(ctypes.byref(desc), ctypes.byref(cam), 1, 1, 1, None, 1, 1, 256, 1 << 20, None)
         assert rc == 1 and b"lab builds only" in lib.pdepth_last_error()

@@ -388,9 +388,9 @@ def test_fuzz_large_tiled_against_gather(dev):
     print(f"large fuzz: worst relative difference {worst:.2e}, {fallback} tiles through the gather kernel")
 
 
-@pytest.mark.parametrize("variant", ["tiled1", "tiled2", "corr"])
+@pytest.mark.parametrize("variant", ["tiled1", "tiled2", "dist"])
 def test_every_sweep_implementation_on_small_ragged_shapes(dev, variant):
-    """The library holds the correlation-form kernel (what ALGO_AUTO runs for the L2 metric) and two builds of the LDS-tiled
+    """The library holds the distance-form kernel (what ALGO_AUTO runs for the L2 metric) and two builds of the LDS-tiled
     kernel (one / two 16x4 tiles per block); the implementation selectors force one, so that each meets the ragged sizes,
     odd tile counts, multi-view and D > 64 cases whatever ALGO_AUTO would choose."""
     rng = np.random.default_rng(7)
@@ -431,13 +431,13 @@ def test_soak_regressions(dev):
         assert err < 2e-6, f"{algo}: {err:.3e}"
     b = synth.make_batch(5480, 1, C=22, D=83, H=195, W=286, V=3, pose="mono", cx_off=1.999560470167534, cy_off=-0.5343920453361704)
     b["t"][0, 0] = torch.tensor([18.91592254, 18.98302991, -11.80695313])
-    for algo in ("auto", "tiled1", "corr"):
+    for algo in ("auto", "tiled1", "dist"):
         agree(b, algo)
     rng = np.random.default_rng(1301)
     for D in (64, 128):
         b = synth.make_batch(6301, 1, C=33, D=D, H=150, W=302, V=1, pose="stereo")
         b["d_candi"] = rng.uniform(0.5, 60.0, size=D)
-        for algo in ("corr", "auto", "tiled2" if D == 64 else "tiled1"):
+        for algo in ("dist", "auto", "tiled2" if D == 64 else "tiled1"):
             agree(b, algo)
 
 

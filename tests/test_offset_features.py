@@ -3,7 +3,7 @@
 The L2 cost sum_c (sum_t w_t s_t - r)^2 (warping/homography.py:80-82,129) does not change when the same constant is added
 to every reference and source value of a channel -- wherever the four taps lie inside the image.  The correlation form
 w^T G w - 2 w.X + |r|^2 that the fast kernels evaluate does: its three terms grow with (mean/std)^2 and cancel.  Round 3's
-kernels lost the 1e-4 depth bound at mean/std = 3.  ALGO_AUTO now centres the features (csrc/sweep_corr.hip,
+kernels lost the 1e-4 depth bound at mean/std = 3.  ALGO_AUTO now centres the features (csrc/sweep_dist.hip,
 csrc/sweep_pack.hip); the LDS-tiled kernel, which is left for the L1 metric and wide features, switches its correlation-form
 plane group off when the pre-pass finds offsets larger than the spread.  Everything here is against the CPU oracle, at the
 north-star tolerance: depth 1e-4 m, cost 2e-4 abs + 2e-5 rel."""
@@ -67,7 +67,7 @@ def test_offset_features_against_the_oracle(dev, kind, pose):
     """64x128, C=67, D=64: every implementation ALGO_AUTO can run, on features with per-channel means of up to 8 standard
     deviations."""
     b = _offset_batch(kind, pose)
-    for algo in ("auto", "dist", "corr", "tiled1", "tiled2", "direct"):
+    for algo in ("auto", "dist", "tiled1", "tiled2", "direct"):
         _check(b, dev, algo)
         # the tiled kernel only gets there because the pre-pass switches its correlation-form plane group off
         if kind == "uniform8" and algo.startswith("tiled"):
@@ -108,7 +108,7 @@ def test_offset_features_border_cells_and_views(dev):
         b["src"] = b["src"] + mu[None, None, :, None, None]
         ocost, ologp, odepth = oracle_batch(b)
         d = to_dev(b, dev)
-        for algo in ("auto", "corr"):
+        for algo in ("auto",):
             cost, logp, depth = ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0,
                                               algo=algo, want_cost=True)
             fin = torch.isfinite(ocost)
@@ -137,7 +137,7 @@ def _same_answer(algo, packed, nchw):
 
 
 def test_packed_source_is_tied_to_the_kernel_family(dev):
-    """The centred layout (ALGO_AUTO / 'corr', L2) and the plain one (the tiled kernel: L1, forced selectors) differ, and
+    """The centred layout (ALGO_AUTO, L2) and the plain one (the tiled kernel: L1, forced selectors) differ, and
     the library cannot tell them apart from the host: the binding refuses to sweep a packed source with a descriptor that
     selects the other family (pdepth_sweep_centres_source), and both families give the NCHW entry's answer bit for bit."""
     b = _offset_batch("uniform8", "mono", B=1)
@@ -145,15 +145,15 @@ def test_packed_source_is_tied_to_the_kernel_family(dev):
     args = (d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0)
     centred = ops.pack_source(d["src"], 64)                      # auto, L2: the distance-form kernel's fp16 planes
     plain = ops.pack_source(d["src"], 64, algo="tiled1")
-    corr = ops.pack_source(d["src"], 64, algo="corr")            # centred float4 planes
-    assert centred.centred and corr.centred and not plain.centred
-    assert (centred.layout, corr.layout, plain.layout) == (_native.LAYOUT_DIST16, _native.LAYOUT_C4_CENTRED, _native.LAYOUT_C4)
-    for ps, kw in ((centred, dict(algo="tiled1")), (plain, dict(algo="auto")), (centred, dict(feat_dist="L1")), (corr, dict(algo="auto")),
-                   (centred, dict(algo="corr"))):
+    assert centred.centred and not plain.centred
+    assert (centred.layout, plain.layout) == (_native.LAYOUT_DIST16, _native.LAYOUT_C4)
+    for ps, kw in ((centred, dict(algo="tiled1")), (plain, dict(algo="auto")), (centred, dict(feat_dist="L1"))):
         with pytest.raises(RuntimeError, match="another kernel family"):
             ops.sweep_dpv(d["ref"], ps, *args, **kw)
+    with pytest.raises(RuntimeError, match="lab builds only"):   # (round 4's correlation-form kernel: make LAB=1)
+        ops.sweep_dpv(d["ref"], d["src"], *args, algo="corr")
     first = {}
-    for ps, algo in ((centred, "auto"), (plain, "tiled1"), (corr, "corr")):
+    for ps, algo in ((centred, "auto"), (plain, "tiled1")):
         cp, lp, dp = ops.sweep_dpv(d["ref"], ps, *args, algo=algo, want_cost=True)
         ca, la, da = ops.sweep_dpv(d["ref"], d["src"], *args, algo=algo, want_cost=True)
         _same_answer(algo, (cp, lp, dp), (ca, la, da))
@@ -172,8 +172,7 @@ def test_a_foreign_packed_layout_is_detected_on_the_device(dev):
     b = synth.make_batch(5, 1, C=67, D=64, H=64, W=128, V=1, pose="mono")
     d = to_dev(b, dev)
     args = (d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0)
-    for pack_algo, sweep_algo in (("corr", "auto"), ("tiled1", "auto"), ("auto", "corr"), ("auto", "tiled1"), ("corr", "tiled1"),
-                                  ("tiled1", "corr")):
+    for pack_algo, sweep_algo in (("tiled1", "auto"), ("auto", "tiled1")):
         ps = ops.pack_source(d["src"], 64, algo=pack_algo)
         honest = ps.layout
         ps.layout = ops.pack_source(d["src"], 64, algo=sweep_algo).layout      # what the sweep's descriptor expects
@@ -192,7 +191,7 @@ def test_passes_that_do_not_fit_are_evaluated_directly(dev):
     """A wide-baseline pose: epipolar segments of hundreds of texels, more blocks of X than the kernel's LDS holds -- those
     passes take the direct evaluation inside the same launch (no tile flags, no second kernel) and meet the same bounds;
     the diagnostics counter says that it happened."""
-    total = {"auto": 0, "corr": 0}
+    total = {"auto": 0}
     for seed, (H, W, D, V) in enumerate(((192, 400, 64, 1), (120, 260, 128, 2))):
         b = synth.make_batch(900 + seed, 1, C=35, D=D, H=H, W=W, V=V, pose="wide")
         g = torch.Generator().manual_seed(seed)
@@ -201,7 +200,7 @@ def test_passes_that_do_not_fit_are_evaluated_directly(dev):
         b["src"] = b["src"] + mu[None, None, :, None, None]
         ocost, ologp, odepth = oracle_batch(b)
         d = to_dev(b, dev)
-        for algo in ("auto", "corr"):
+        for algo in ("auto",):
             cost, logp, depth = ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0,
                                               algo=algo, want_cost=True)
             total[algo] += _native.fallback_tiles(1, H, W)
@@ -217,7 +216,7 @@ def test_passes_that_do_not_fit_are_evaluated_directly(dev):
 
 
 def test_extremes_of_the_default_kernel(dev):
-    """The corners of the shape range sweep_dist_supports() / sweep_corr_supports() admit -- one channel, one plane, images smaller than a tile, the
+    """The corners of the shape range sweep_dist_supports() admits -- one channel, one plane, images smaller than a tile, the
     widest features (C = 72: 18 packed planes), D = 65 (a second plane group with one plane in it), 8 source views, more than
     64 batch items (the per-item block-shape table holds 64) -- against the oracle, with offset features; and just beyond
     them (9 views, C = 73, D = 129) `auto` still answers (the LDS-tiled kernel) while the forced selector says no."""
@@ -231,7 +230,7 @@ def test_extremes_of_the_default_kernel(dev):
         b["src"] = b["src"] + mu[None, None, :, None, None]
         ocost, ologp, odepth = oracle_batch(b)
         d = to_dev(b, dev)
-        for algo in ("auto", "dist", "corr"):
+        for algo in ("auto", "dist"):
             cost, logp, depth = ops.sweep_dpv(d["ref"], d["src"], d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0,
                                               algo=algo, want_cost=True)
             fin = torch.isfinite(ocost)
@@ -250,6 +249,6 @@ def test_extremes_of_the_default_kernel(dev):
         cost = ops.sweep_dpv(*args, algo="auto", want_cost=True)[0]
         fin = torch.isfinite(ocost)
         np.testing.assert_allclose(cost.cpu()[fin].numpy(), ocost[fin].numpy(), rtol=COST_RTOL, atol=COST_ATOL, err_msg=str(c))
-        for algo in ("corr", "dist"):
+        for algo in ("dist",):
             with pytest.raises(RuntimeError):
                 ops.sweep_dpv(*args, algo=algo)

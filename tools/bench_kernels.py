@@ -65,11 +65,10 @@ def main():
     sweep_case("cfg5 D=128 512x1024 V=4 B=2 (per-GPU share of B=16)", 2, 67, 128, 512, 1024, 4, "mono", steps=5)
     sweep_case("cfg2 mono 256x512 B=4 gather kernel", 4, 67, 64, 256, 512, 1, "mono", algo="direct", steps=5)
     # the implementations behind "auto", forced (A/B): the correlation-form kernel, one-tile and two-tile builds of the tiled kernel
-    for algo in ("corr", "tiled1", "tiled2"):
+    for algo in ("tiled1", "tiled2"):
         sweep_case("cfg2 mono 256x512 B=4", 4, 67, 64, 256, 512, 1, "mono", algo=algo)
         sweep_case("cfg3 stereo 256x512 B=4", 4, 67, 64, 256, 512, 1, "stereo", algo=algo)
         sweep_case("model-real 64x128 B=4", 4, 67, 64, 64, 128, 1, "mono", algo=algo, steps=50)
-    sweep_case("cfg5 D=128 512x1024 V=4 B=2", 2, 67, 128, 512, 1024, 4, "mono", algo="corr", steps=5)
     sweep_case("cfg5 D=128 512x1024 V=4 B=2", 2, 67, 128, 512, 1024, 4, "mono", algo="tiled1", steps=5)
     # BASELINE config 1 as the reference runs it (train.py:64-73: eval is B = 1; models.py:518: the sweep at 1/4 resolution):
     # one frame pair, 64x128 (256x512 image) and 64x96 (the default 256x384 crop).  Wall time of back-to-back calls here;

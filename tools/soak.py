@@ -169,7 +169,7 @@ def main():
             continue
         d = {kk: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for kk, v in b.items()}
         metric = "L1" if case % 7 == 3 else "L2"
-        algo = ("tiled1", "dist", "corr", "auto", "tiled2")[case % 5]   # (period 5: every kernel meets offsets -- even cases -- and the oracle leg -- every third)
+        algo = ("tiled1", "dist", "direct", "auto", "tiled2")[case % 5]   # (period 5: every kernel meets offsets -- even cases -- and the oracle leg -- every third)
         if algo in ("corr", "dist") and (metric == "L1" or s["D"] > 128 or s["C"] > 72):
             algo = "tiled1"
         if algo == "tiled2" and s["D"] > 64:
