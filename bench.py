@@ -93,12 +93,13 @@ def main():
     ap.add_argument("--views", type=int, default=1)
     ap.add_argument("--pose", default="mono", choices=["mono", "stereo"])
     ap.add_argument("--algo", default="auto", choices=["auto", "direct", "dist", "corr", "tiled1", "tiled2", "cells", "mfma"],
-                    help="cells / mfma: lab builds of the library only (make LAB=1)")
+                    help="corr / cells / mfma: lab builds of the library only (make LAB=1)")
     ap.add_argument("--peaked", action="store_true", help="SURVEY 8(d)'s correlated feature variant (src = 0.7 shift(ref) + 0.3 noise: a peaked DPV)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-start measurement in front of the headline")
     ap.add_argument("--preheat-ms", type=float, default=60.0, help="untimed headline steps in front of the W warm-up steps (clock ramp), ms of wall time")
     ap.add_argument("--no-secondary", action="store_true", help="skip the model_real / peaked measurements in front of the headline")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the `workloads` object (BASELINE configs[2] and [4] at their per-GPU shard, behind the headline)")
     ap.add_argument("--config", default=None, help="an experiment file in the reference's JSON schema (configs/*.json): "
                     "planes, depth range, sigma, channels and the pose family come from it; the sweep resolution stays "
                     "--height x --width (BASELINE quotes the metric at 256x512)")
@@ -218,7 +219,7 @@ def main():
             secondary["model_real"] = {"shape": "C=%d D=%d 64x128 V=%d pose=%s (the reference sweeps a 256x512 frame at 1/4 resolution: "
                                                 "models/models.py:518)" % (cfg["C"], cfg["D"], cfg["V"], a.pose),
                                        "what": "us_per_call = HIP events around 50 back-to-back calls of the Python binding, best of three rounds (at B=1 the host's call, ~26 us, is "
-                                               "longer than the kernel: profiles/r05_small_sweeps.rocprofv3.txt has the kernels' own durations); "
+                                               "longer than the kernel: profiles/r06_small_sweeps.rocprofv3.txt has the kernels' own durations); "
                                                "frac = algorithmic bytes / us_per_call / 8 TB/s",
                                        "B1_nchw": small(1, "nchw"), "B1_packed": small(1, "packed"),
                                        "B4_nchw": small(4, "nchw"), "B4_packed": small(4, "packed")}
@@ -267,6 +268,42 @@ def main():
             del dp
         except RuntimeError as e:
             secondary["error"] = str(e)
+    # BASELINE configs[2] (default_stereo, batch 32 over 8 GPUs) and configs[4] (D = 128, 512x1024, 4 views, batch 16 over 8
+    # GPUs) at the shard ONE GPU gets (B = 4 / B = 2): the driver runs one command, so their numbers ride in this line.  NCHW
+    # entry (statistics + pack + sweep), HIP events around W + K calls; each checked against the gather kernel (the
+    # reference's op order) on the same batch.
+    workloads = {}
+    if not a.no_workloads and not a.no_secondary and a.algo in ("auto", "dist") and rank == 0 and not a.config:
+        def shard(name, Bs, D, H, W, V, pose, steps):
+            bs = synth.make_batch(2, Bs, C=cfg["C"], D=D, H=H, W=W, V=V, pose=pose)
+            ds = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in bs.items()}
+            dcs = ops.d_candi_tensor(ds["d_candi"], dev)
+            f = lambda algo: ops.sweep_dpv(ds["ref"], ds["src"], ds["K"], ds["R"], ds["t"], ds["rays"], ds["cxcy"], dcs, sigma, algo=algo)
+            for _ in range(a.warmup):
+                o = f(a.algo)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                o = f(a.algo)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1) / steps
+            direct_passes = pdepth_amd._native.fallback_tiles(Bs, H, W)
+            impl_s = a.algo if a.algo != "auto" else pdepth_amd._native.selected_kernel(Bs, V, cfg["C"], D, H, W)
+            ref_depth = f("direct")[2]
+            by = algorithmic_bytes_per_volume(cfg["C"], V, D, H, W) * Bs
+            del ds
+            return {"workload": name, "B": Bs, "ms_per_call": ms, "volumes_per_s": Bs / (ms * 1e-3), "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "sweep_kernel": impl_s, "direct_passes": direct_passes,
+                    "max_abs_depth_diff_vs_gather": float((o[2] - ref_depth).abs().max())}
+        try:
+            workloads["cfg3_shard"] = shard("BASELINE configs[2] at one GPU's shard: default_stereo eval, D=64, 256x512, V=1, B=4 (of 32 over 8 GPUs)",
+                                            4, 64, 256, 512, 1, "stereo", a.steps)
+            workloads["cfg5_share"] = shard("BASELINE configs[4] at one GPU's share: D=128, 512x1024, 4 source views, B=2 (of 16 over 8 GPUs)",
+                                            2, 128, 512, 1024, 4, "mono", max(3, a.steps // 4))
+        except RuntimeError as e:
+            workloads["error"] = str(e)
     depth = out[2]
     metrics = torch.tensor([hi - lo, kern_ms, float(depth.mean()), float(torch.isfinite(depth).all())],
                            dtype=torch.float32, device=dev)
@@ -327,6 +364,8 @@ def main():
         for k in ("model_real", "peaked"):
             if k in secondary:
                 extras[k] = secondary[k]
+        if workloads:
+            extras["workloads"] = workloads
         if "error" in secondary:
             extras["secondary_error"] = secondary["error"]
         if cold is not None:
@@ -344,9 +383,13 @@ def main():
         line = pdist.assemble_bench_line(
             allm, wall, steps=a.steps, warmup=a.warmup, batch_per_gpu=a.batch, world=world,
             metric="depth-volumes/sec (D=64, 256x512)", unit="depth-volumes/s",
-            workload=f"BASELINE configs[1]: default_mono eval, fused sweep+DPV, B={a.batch}/GPU, V={cfg['V']}, "
+            workload=("BASELINE configs[1]: default_mono eval" if a.pose == "mono" else "BASELINE configs[2] (one GPU's shard of the batch): default_stereo eval") +
+                     f", fused sweep+DPV, B={a.batch}/GPU, V={cfg['V']}, "
                      f"C={cfg['C']}, D={cfg['D']}, {cfg['H']}x{cfg['W']}, pose={a.pose}, algo={a.algo}" + (", peaked features" if a.peaked else ""),
-            bytes_per_volume=bpv, hbm_peak_gbs=HBM_PEAK_GBS, extras=extras)
+            bytes_per_volume=bpv, hbm_peak_gbs=HBM_PEAK_GBS, extras=extras,
+            # I/O and every sum in fp32; the default kernel forms the channel contraction from fp16 high / low pairs of the
+            # centred features on the matrix pipe (22 bits per feature, products exact, fp32 accumulation: DESIGN.md section 1)
+            dtype="f32 (fp16-pair products on MFMA, fp32 accumulate)" if impl == "dist" else "f32")
         if world == 1 and not a.no_cpu_baseline:
             # (with --config the depth candidates / sigma come from the file, the port's sample keeps the defaults: timing only)
             line["cpu_baseline"] = cpu_baseline(cfg, gpu_depth0=None if a.config else depth[0].cpu())
