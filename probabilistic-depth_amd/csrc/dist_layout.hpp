@@ -20,10 +20,11 @@
 // Planes of 16 bytes (8 fp16 = one lane's share of a K = 32 matrix operand) per texel, image (H + 2) x (W + 2):
 //     [hi: 4 NCHK planes]  channels 8 p .. 8 p + 7 of the first 32 NCHK channels, high parts
 //     [lo: 4 NCHK planes]  ... low parts
-//     [tail: 4 planes]     K slots 0..7: high parts of the T = C - 32 NCHK left-over channels; 8..15: their low parts;
-//                          16..23: their high parts again (multiplied by the pixel's low parts); 24..31: the specials
+//     [tail: 3 planes]     high parts of the T = C - 32 NCHK left-over channels; their low parts; the specials
 //                          (n1, n2, n3, 2^15, 2^4, 2^-7, 0, 0): N = |x'|^2 as three fp16 pieces N = n1 2^15 + n2 2^4 + n3 2^-7,
-//                          and the constants that multiply the pixel's pieces of |r'|^2
+//                          and the constants that multiply the pixel's pieces of |r'|^2.  As a K = 32 matrix operand the tail is
+//                          (high | low | high AGAIN, against the pixel's low parts | specials): the lanes of K slice 2 load
+//                          the plane of the high parts a second time (round 5 stored it twice: 16 of 336 bytes per texel)
 //     [Q: 1 plane, fp32]   (Dx0, Dy0, Dd, Dx1) of the cell whose top-left texel this is: Dx0 = |s00 - s01|^2,
 //                          Dy0 = |s00 - s10|^2, Dd = |s00 - s11|^2 + |s01 - s10|^2, Dx1 = |s10 - s11|^2
 //                          (Dy1 = |s01 - s11|^2 is the right neighbour's Dy0)
@@ -43,7 +44,7 @@ constexpr float PIECE_I1 = 1.0f / 32768.0f, PIECE_I2 = 1.0f / 16.0f, PIECE_I3 = 
 constexpr float F16_MAX = 65504.0f;
 
 __host__ __device__ inline int nchk(int C) { return C <= 8 ? 0 : (C <= 40 ? 1 : 2); }
-__host__ __device__ inline int nplanes(int C) { return 8 * nchk(C) + 4 + 1; }
+__host__ __device__ inline int nplanes(int C) { return 8 * nchk(C) + 3 + 1; }
 // (rows padded to a multiple of 4 texels: a block of 16 texels that starts at a multiple of 4 is read as whole 64-byte pieces)
 __host__ __device__ inline int wp(int W) { return (W + 2 * RING + 3) & ~3; }
 __host__ __device__ inline int hp(int H) { return H + 2 * RING; }

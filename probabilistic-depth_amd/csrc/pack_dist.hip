@@ -180,7 +180,6 @@ __device__ __forceinline__ void pack_dist_strip(const Source& src, int C, int H,
                 } else {
                     PACK_ST(h8, out + (size_t)(8 * NCHK + 0) * PB + toff, hh[r]);
                     PACK_ST(h8, out + (size_t)(8 * NCHK + 1) * PB + toff, ll[r]);
-                    PACK_ST(h8, out + (size_t)(8 * NCHK + 2) * PB + toff, hh[r]);
                 }
             }
         }
@@ -234,8 +233,8 @@ __device__ __forceinline__ void pack_dist_strip(const Source& src, int C, int H,
         sp[0] = pn.p1; sp[1] = pn.p2; sp[2] = pn.p3;
         sp[3] = (_Float16)dist::PIECE_C1; sp[4] = (_Float16)dist::PIECE_C2; sp[5] = (_Float16)dist::PIECE_C3;
         sp[6] = (_Float16)0.f; sp[7] = (_Float16)0.f;
-        PACK_ST(h8, out + (size_t)(8 * NCHK + 3) * PB + toff, sp);
-        PACK_ST(v4f, out + (size_t)(8 * NCHK + 4) * PB + toff, (v4f{dx[r], dy0[r], dd[r], dx[r + 1]}));
+        PACK_ST(h8, out + (size_t)(8 * NCHK + 2) * PB + toff, sp);
+        PACK_ST(v4f, out + (size_t)(8 * NCHK + 3) * PB + toff, (v4f{dx[r], dy0[r], dd[r], dx[r + 1]}));
     }
     if (ovf) atomicOr(item_flags, 1);
 }

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     constexpr int MP = NCHK + 1;                   // rounds of the cooperative reference load: 16 channel PAIRS per round (the last: the tail's 4)
     constexpr int MAXB = NH == 1 ? DIST_MAXB1 : DIST_MAXB2;
     constexpr int NC = 4 * NH;                     // planes (costs) per thread
-    constexpr int QPL = 8 * NCHK + 4;              // the Q plane
+    constexpr int QPL = 8 * NCHK + 3;              // the Q plane
     constexpr int NS = NH == 1 ? DIST_SETS1 : DIST_SETS2;   // texel operand register sets = blocks of a wave in flight
     typedef DistLds<MAXB, NAC> Lds;
     constexpr int XSTRIDE = Lds::XSTRIDE;
@@ -560,9 +560,11 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                             const int xs = __builtin_amdgcn_ds_bpermute(4 * rho, lo) + 16 * (lane - __builtin_amdgcn_ds_bpermute(4 * rho, fb));
                             boff = lane < nb ? ((yb + rho + dist::RING) * Wp + xs + dist::RING) * 16 : OOB;
                         }
+                        // (the tail chunk: planes high | low | high again | specials = the tail's planes 0, 1, 0, 2 for K slices 0 .. 3)
                         auto fetch = [&](int set, int i, int soff) {   // chunk i: planes 4 i .. 4 i + 3 (the lane's: + kq, in voffA)
                             if (DIST_ABL & 2) { S[set][i] = *reinterpret_cast<const h8*>(bsl + i * 512); return; }   // timing only: no texel loads
-                            S[set][i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffA, soff + i * 4 * PB, 0));
+                            const int voff = i == NAC - 1 ? voffA - (kq == 2 ? 2 * PB : (kq == 3 ? PB : 0)) : voffA;
+                            S[set][i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + i * 4 * PB, 0));
                         };
                         auto fetch_block = [&](int set, int soff) {
 #pragma unroll

@@ -62,7 +62,8 @@ __device__ __forceinline__ void channel_stats(const float* __restrict__ plane, l
                                               int W, int rate, int IW, float* __restrict__ mu_out, float* __restrict__ var_out, int centre) {
     __shared__ float scratch[4];
     const int nvw = nv + (extra ? 1 : 0);
-    const int nrows = min(H, nvw == 1 ? STATS_ROWS : max(2, min(STATS_ROWS, 16 / nvw))), per_view = nrows * W, total = nvw * per_view;
+    // (STATS_ROWS rows in all, at least two per view: the kernel is a round of loads and four block reductions -- latency, 8 us)
+    const int nrows = min(H, max(2, STATS_ROWS / nvw)), per_view = nrows * W, total = nvw * per_view;
     // the partner of a sample for the lagged spread: STATS_LAG_PX texels to the right (to the left in the last columns)
     const int lag = W > 2 * STATS_LAG_PX ? STATS_LAG_PX : (W > 1 ? W / 2 : 0);
     float s = 0.0f, s2 = 0.0f, am = 0.0f, dl = 0.0f;

@@ -12,7 +12,7 @@ for name, kw in (("headline B=4 256x512 V=1", dict(B=4, C=67, D=64, H=256, W=512
     b = synth.make_batch(2, B, pose="mono", **kw)
     d = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
     dc = ops.d_candi_tensor(d["d_candi"], "cuda")
-    for algo in (("dist", "corr") if not os.environ.get("PDEPTH_LIB") else ("dist",)):
+    for algo in ("dist",):
         pk = lambda: ops.pack_source(d["src"], kw["D"], algo)
         ps = pk()
         sw = lambda: ops.sweep_dpv(d["ref"], ps, d["K"], d["R"], d["t"], d["rays"], d["cxcy"], dc, 10.0, algo=algo)
