@@ -20,8 +20,19 @@
  *   - the sweep kernels order their tiles per XCD assuming the SPX partition mode of the MI355X
  *     (workgroup i is dispatched to XCD i mod 8, each XCD with its own L2); under another
  *     partition mode the results are the same and only L2 locality is lost;
- *   - arithmetic type is fp32 throughout (d_candi is float64 on the
- *     host and cast to fp32 at use, warping/homography.py:115, utils/img_utils.py:58).
+ *   - arithmetic: inputs, outputs, sample positions, bilinear weights and every sum are fp32 (SURVEY.md section 8:
+ *     d_candi is float64 on the host and cast to fp32 at use, warping/homography.py:115, utils/img_utils.py:58).
+ *     ONE step of the default sweep kernel (PDEPTH_ALGO_AUTO / _DIST, L2 metric) is not an fp32 instruction: the channel
+ *     contraction <s, r> of the centred features runs on the matrix pipe as products of fp16 high / low PAIRS
+ *     (h = fp16(x'), l = fp16(x' - h): 22 bits per feature, products exact, fp32 accumulation;
+ *     v_mfma_f32_16x16x32_f16) -- measured as accurate as the fp32 matrix instruction.
+ *     BASELINE.json's north star describes the path as "no MFMA (a gather/reduce)": the gather and the reductions are
+ *     vector code here too, the contraction over the channels is not (DESIGN.md section 1 says why).  A caller who
+ *     wants the reference's own operation order end to end selects PDEPTH_ALGO_DIRECT.
+ *   - values that are not numbers propagate as in the reference: a NaN / inf feature or depth candidate makes the costs
+ *     it enters, and with them the pixel's log-DPV and depth, non-finite; a finite feature beyond the fp16 range of the
+ *     default kernel's scaled layout (several thousand times the sampled maximum of its batch item) makes that item's
+ *     outputs NaN -- never a clamped number.
  */
 #ifndef PDEPTH_H_
 #define PDEPTH_H_
@@ -33,7 +44,9 @@
 extern "C" {
 #endif
 
-#define PDEPTH_ABI_VERSION 5   /* 5: PDEPTH_ALGO_DIST (what AUTO runs), pdepth_sweep_source_layout, layout tag in the workspace */
+#define PDEPTH_ABI_VERSION 6   /* 5: PDEPTH_ALGO_DIST (what AUTO runs), pdepth_sweep_source_layout, layout tag in the workspace;
+                                * 6: the distance-form layout is 320 bytes per texel at C = 67 (336 in v5): a workspace packed by a v5
+                                *    library must be re-packed; PDEPTH_ALGO_CORR answers in lab builds only */
 
 enum {
     PDEPTH_OK = 0,
@@ -66,7 +79,7 @@ enum {
     PDEPTH_ALGO_TILED_2 = 3, /* LDS-tiled band kernel, two tiles per block (D <= 64)                    */
     PDEPTH_ALGO_CELLS = 4,   /* lab builds only (make LAB=1): cell-list kernels of round 2 (L2, D <= 128)           */
     PDEPTH_ALGO_MFMA = 5,    /* lab builds only: matrix-pipe kernel of round 3 (L2, D <= 128, C <= 72)              */
-    PDEPTH_ALGO_CORR = 6,    /* correlation form on mean-centred features, fp32 matrix instructions (L2 metric, D <= 128,
+    PDEPTH_ALGO_CORR = 6,    /* LAB BUILDS ONLY since ABI 6 (PDEPTH_E_ARG otherwise): correlation form on mean-centred features, fp32 matrix instructions (L2 metric, D <= 128,
                                 C <= 72; other inputs: PDEPTH_E_ARG): the default of ABI 4, kept as an independent check */
     PDEPTH_ALGO_DIST = 7     /* distance form sum_t w_t |s_t - r|^2 - Q on fp16 high / low parts, matrix pipe (L2 metric,
                                 D <= 128, C <= 72, V <= 8; other inputs: PDEPTH_E_ARG): what AUTO runs on those shapes  */
@@ -139,14 +152,27 @@ int pdepth_sweep_dpv_f32(const pdepth_sweep_desc *desc, const pdepth_camera *cam
 /*
  * The same fused sweep for a caller that keeps its source features in the kernels' staging layout -- e.g. the epilogue
  * of the feature encoder (models/models.py:518-534 is where the reference concatenates the 64 learned channels with
- * the RGB thumbnail) -- so that the NCHW -> channel-group-planar re-layout is paid once per frame instead of once per
- * sweep call (it is 10 % of the time and 30 % of the memory traffic of pdepth_sweep_dpv_f32):
- *   pdepth_pack_source_f32      : src [B,V,C,H,W] (strides from desc) -> workspace (the pre-pass of the entry above:
- *                                 float4 texels of 4 channels, planes [ceil(C/4)][H][W], + 2 Gram planes);
- *   pdepth_sweep_dpv_packed_f32 : the sweep on a workspace packed by that call for the same desc (B, V, C, H, W and
- *                                 algo = PDEPTH_ALGO_AUTO; any cameras, depth candidates, sigma, metric, reference
- *                                 features).  Outputs as pdepth_sweep_dpv_f32.
+ * the RGB thumbnail) -- so that the re-layout is paid once per frame instead of once per sweep call (it is a fifth of the
+ * time of pdepth_sweep_dpv_f32 on the headline shape):
+ *   pdepth_pack_source_f32      : src [B,V,C,H,W] (strides from desc) -> workspace, in the layout the sweep kernel that
+ *                                 `desc` selects reads (pdepth_sweep_source_layout(desc)):
+ *                                   PDEPTH_LAYOUT_DIST16 (L2, C <= 72, D <= 128, V <= 8: what AUTO runs): per view an
+ *                                     (H + 2) x (W + 2) image (a ring of zero-feature texels), planes of 16 bytes per texel:
+ *                                     the centred, power-of-two scaled features as fp16 high and low parts in matrix-operand
+ *                                     order, |x'|^2 as three fp16 pieces, and an fp32 record of the five squared neighbour
+ *                                     differences of the cell (20 planes = 320 bytes per texel at C = 67; csrc/dist_layout.hpp);
+ *                                   PDEPTH_LAYOUT_C4 (L1 metric, C > 72, D > 128: the LDS-tiled kernel): float4 texels of 4
+ *                                     channels, planes [ceil(C/4)][H][W], + 2 Gram planes;
+ *   pdepth_sweep_dpv_packed_f32 : the sweep on a workspace packed by that call for a desc with the same B, V, C, H, W and
+ *                                 the SAME pdepth_sweep_source_layout() -- a layout is tied to its kernel family: the
+ *                                 metric and the algo selector may only change within it (any cameras, depth candidates,
+ *                                 sigma, reference features).  Outputs as pdepth_sweep_dpv_f32.  A foreign layout is
+ *                                 detected on the device (tag in the workspace): every output is filled with NaN.
+ *                                 The packed entry of the default kernel is ONE launch.
  * PDEPTH_E_ARG if the shape does not run on a packed source (then use pdepth_sweep_dpv_f32).
+ * Statistics.  The default kernel centres and scales with per-channel constants of the batch item, estimated from sampled
+ * rows: pdepth_sweep_dpv_f32 and pdepth_pack_views_f32 sample every source view AND the reference view,
+ * pdepth_pack_source_f32 (which is not given the reference) the source views.
  */
 int pdepth_pack_source_f32(const pdepth_sweep_desc *desc, const float *src, void *workspace,
                            size_t workspace_bytes, void *stream);
@@ -168,15 +194,18 @@ int pdepth_sweep_dpv_packed_f32(const pdepth_sweep_desc *desc, const pdepth_came
                                 void *workspace, size_t workspace_bytes, void *stream);
 
 /* Bytes of scratch the two sweep entry points need for `desc` (0 for ALGO_DIRECT); the workspace
- * must be 256-byte aligned.  ALGO_AUTO without it returns PDEPTH_E_WORKSPACE.  For ALGO_AUTO it holds
- * one flag per 16x4 tile, 8 work-queue counters and a channel-group-planar copy of the source views
- * plus their Gram planes (B*V*(ceil(C/4)+2)*H*W*16 bytes, written by a pre-pass of every call) -- size it once per shape and reuse it.  A call
- * rewrites all of it: do not share one workspace between calls that may run concurrently (different streams). */
+ * must be 256-byte aligned.  ALGO_AUTO without it returns PDEPTH_E_WORKSPACE.  It holds one int per 16x4 tile (tile flags
+ * of the LDS-tiled kernel; the default kernel keeps its eight per-XCD queue counters there, 256 bytes apart), 64 counter /
+ * tag ints, the packed source views -- sized for the LARGEST of the layouts of the shape, so any pack fits any sweep:
+ * max(B*V*(8*nchk(C)+4)*(H+2)*wp(W)*16 + 256*B*V, B*V*(ceil(C/4)+2)*H*W*16) bytes with nchk(C) = 0 | 1 | 2 chunks of 32
+ * channels and wp(W) = W + 2 rounded up to a multiple of 4 -- and 416 floats of channel statistics per batch item.  Size it
+ * once per shape and reuse it.  A call rewrites all of it: do not share one workspace between calls that may run
+ * concurrently (different streams). */
 size_t pdepth_sweep_workspace_bytes(const pdepth_sweep_desc *desc);
 
 /* 1 if the packing entry points (pdepth_pack_source_f32, pdepth_pack_views_f32) subtract the channel means from the
- * packed source for `desc` -- i.e. the sweep it selects is PDEPTH_ALGO_CORR, directly or through PDEPTH_ALGO_AUTO --,
- * else 0.  A packed workspace must be swept with a descriptor for which this answer is the same (the centred and the
+ * packed source for `desc` -- i.e. the sweep it selects is the distance-form kernel (PDEPTH_ALGO_DIST, directly or through
+ * PDEPTH_ALGO_AUTO; lab builds: also PDEPTH_ALGO_CORR) --, else 0.  A packed workspace must be swept with a descriptor for which this answer is the same (the centred and the
  * plain layout differ; the library cannot tell them apart from the host).  No reference counterpart: the reference
  * never re-lays its features (warping/homography.py:123-129 works on the NCHW tensors). */
 int pdepth_sweep_centres_source(const pdepth_sweep_desc *desc);

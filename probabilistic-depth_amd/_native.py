@@ -151,7 +151,7 @@ def load():
     lib.pdepth_sweep_centres_source.argtypes = [POINTER(SweepDesc)]
     lib.pdepth_sweep_source_layout.restype = c_int
     lib.pdepth_sweep_source_layout.argtypes = [POINTER(SweepDesc)]
-    if lib.pdepth_abi_version() != 5:
+    if lib.pdepth_abi_version() != 6:
         raise RuntimeError("libpdepth_hip.so ABI version mismatch")
     _lib = lib
     return lib

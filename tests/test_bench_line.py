@@ -76,3 +76,39 @@ def test_self_launch_starts_ranks_before_touching_the_gpu():
     assert p.returncode != 0
     if not torch.cuda.is_available():
         assert "bench.py needs a GPU" in p.stderr
+
+
+def _rank8(rank, world, port, out_path, global_batch, tag):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = pdist.init_from_env(backend="gloo")
+    lo, hi = pdist.shard_range(global_batch, r, w)          # the slice of the global batch this rank owns
+    pdist.barrier()
+    wall = pdist.max_over_ranks(0.004 + 0.0001 * r, torch.device("cpu"))
+    vec = torch.tensor([hi - lo, 0.40 + 0.01 * r, float(lo), 1.0], dtype=torch.float32)
+    allm = pdist.gather_metrics(vec)
+    if r == 0:
+        line = pdist.assemble_bench_line(allm, wall, steps=10, warmup=5, batch_per_gpu=global_batch // w, world=w, metric="m", unit="u",
+                                         workload=tag, bytes_per_volume=104333312, hbm_peak_gbs=8000.0)
+        line["first_items"] = [float(x) for x in allm[:, 2]]
+        json.dump(line, open(out_path, "w"))
+    pdist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("global_batch,tag", [(32, "configs[2]: default_stereo, batch 32 over 8 GPUs"),
+                                               (16, "configs[4]: D=128 512x1024 V=4, batch 16 over 8 GPUs")])
+def test_eight_rank_shards_of_configs_3_and_5(tmp_path, global_batch, tag):
+    """the partition and the arithmetic of the line at the world size the driver's scaling run uses
+    (`python bench.py --gpus 8 --batch 4 --pose stereo`, `--gpus 8 --batch 2 --planes 128 --height 512 --width 1024 --views 4`;
+    train.py:88-95 is the reference's one-process-per-GPU spawn).  gloo on the CPU: 8 ranks, contiguous slices, one all_gather."""
+    out = str(tmp_path / "line8.json")
+    mp.spawn(_rank8, args=(8, _free_port(), out, global_batch, tag), nprocs=8, join=True)
+    line = json.load(open(out))
+    per = global_batch // 8
+    assert line["n_gpus"] == 8 and line["config"]["global_batch"] == global_batch and line["config"]["per_gpu_batch"] == per
+    assert line["config"]["parallelism"] == "dp8" and line["scaling"] == "weak"
+    assert len(line["per_rank_kernel_ms"]) == 8 and line["per_rank_kernel_ms"][7] == pytest.approx(0.47)
+    assert line["first_items"] == [float(per * r) for r in range(8)]          # contiguous, disjoint, covering
+    assert line["value"] == pytest.approx(global_batch * 10 / 0.0047)         # every rank's volumes / the slowest rank's wall
+    assert line["roofline"]["achieved"] == pytest.approx(per * 104333312 / 0.40e-3 / 1e9)   # rank 0's own launch

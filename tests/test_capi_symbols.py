@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = _native.load()
     for sym in _declared_symbols():
         assert hasattr(lib, sym), f"{sym} declared in include/pdepth.h but not exported"
-    assert lib.pdepth_abi_version() == 5
+    assert lib.pdepth_abi_version() == 6
 
 
 def test_argument_validation_without_gpu():
@@ -158,3 +158,14 @@ def test_product_library_carries_no_lab_bench():
                 head = body[:m.start()]
                 opened = len(re.findall(r"^\s*#\s*ifdef PDEPTH_LAB", head, re.M)) + len(re.findall(r"^\s*#\s*if defined\(PDEPTH_LAB\)", head, re.M))
                 assert opened > 0 and head.rfind("PDEPTH_LAB") > head.rfind("#endif"), f"{f}: getenv outside a lab-only block"
+
+
+def test_header_says_what_the_code_does():
+    """the boundary's prose is checked against the stale statements it once made."""
+    h = open(os.path.join(REPO, "include", "pdepth.h")).read()
+    for stale in ("arithmetic type is fp32 throughout", "(ceil(C/4)+2)*H*W*16 bytes, written by a pre-pass of every call",
+                  "any cameras, depth candidates, sigma, metric, reference"):
+        assert stale not in h, stale
+    for needed in ("v_mfma_f32_16x16x32_f16", "320 bytes per texel", "PDEPTH_LAYOUT_DIST16", "never a clamped number", "ONE launch"):
+        assert needed in h, needed
+    assert "#define PDEPTH_ABI_VERSION 6" in h
