@@ -259,63 +259,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
         int b, tx, ty, sub;
         decode(item, b, tx, ty, sub);
         const int H = KARG(int, a.H), W = KARG(int, a.W), V = KARG(int, a.V), C = KARG(int, a.C), D = KARG(int, a.D);
-        // per BATCH item, for every wave: scaled channel means, the views' homography terms, the camera constants, the item's
-        // flags (visible behind the barrier in front of the first block's centring).  Items come out of the queues batch item
-        // by batch item: the tables are rebuilt a few times per launch, not once per tile.
-        const bool new_b = b + 1 != state >> 2;
-        if (new_b) {
-            state = (state & 3) | ((b + 1) << 2);
-            // (the lane's roles re-derived here: hoisted out of the item loop, the invariants of this rarely run block were
-            //  spilled registers of the whole kernel)
-            const int tid = opaque_v((int)threadIdx.x), lane = tid & 63;
-            const float* st = KARG(const float*, stats) + (size_t)b * STATS_STRIDE;
-            if (wave == 0) {
-                // the scale (dist_layout.hpp: the same function of the same numbers as in the pack kernel) and the guard
-                float am = st[STATS_AMAX + lane], sv = st[STATS_VAR + lane], sl_ = st[STATS_LAG + lane];
-                if (lane + 64 < STATS_VAR) {
-                    am = fmaxf(am, st[STATS_AMAX + lane + 64]); sv += st[STATS_VAR + lane + 64]; sl_ += st[STATS_LAG + lane + 64];
-                }
-#pragma unroll
-                for (int sh = 32; sh >= 1; sh >>= 1) {
-                    am = fmaxf(am, __shfl_xor(am, sh)); sv += __shfl_xor(sv, sh); sl_ += __shfl_xor(sl_, sh);
-                }
-                const int e = dist::scale_exponent(am);
-                const float sc = ldexpf(1.0f, e);
-                // Guard.  The rounding error of Y = N - 2 X + |r'|^2 is 2^-23 of the ENERGY of the centred features (sum_c var_c,
-                // trends across the image included: a constant per channel does not remove them), that of the reference's own
-                // form 2^-23 of the cost, i.e. of their spread at the distance of a sweep (sum_c lag_c).  Measured on features
-                // with trends (tools/dbg/dist_guard.py, depth against the CPU oracle): ratio 1.34 -> 3.6e-5 m, ratio 2.1 ..
-                // 2.4 -> 1.0e-4 .. 1.4e-4 m, where the reference's form keeps 3e-5.  An item is evaluated directly where the
-                // ratio exceeds DIST_GUARD_RATIO AND the energy is large enough against sigma for the difference to show
-                // (unit-variance features: 67; features whose energy is all spread gain nothing from the direct form).
-                const float sg = KARG(float, a.sigma);
-                const bool outside = sv > DIST_GUARD_RATIO * sl_ && sv * 10.0f > DIST_GUARD_ENERGY * fabsf(sg);
-                if (lane == 0) {
-                    L.cst[6] = sc; L.cst[7] = ldexpf(refined_rcp(sg), -2 * e);
-                    const int pf = reinterpret_cast<const int*>(st + STATS_FLAGS)[0];
-                    L.iflag = (pf != 0 ? 1 : 0) | (outside ? 2 : 0);
-                }
-                for (int c = lane; c < dist::MAX_C + 8; c += 64) L.mus[c] = st[c] * sc;
-            }
-            if (tid >= 128 && tid < 128 + V) {
-                const int v = tid - 128;
-                ViewXform xf;
-                make_view_xform(KARG(const float*, a.K) + b * 9, KARG(const float*, a.R) + ((size_t)b * V + v) * 9,
-                                KARG(const float*, a.t) + ((size_t)b * V + v) * 3, KARG(int, a.blas_mode), xf);
-#pragma unroll
-                for (int i = 0; i < 9; ++i) L.xf[v * 12 + i] = xf.kr[i];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) L.xf[v * 12 + 9 + i] = xf.kt[i];
-            }
-            if (tid == 255) {
-                const float* const cxcy_ = KARG(const float*, a.cxcy);
-                const float cx = cxcy_[b * 2 + 0], cy = cxcy_[b * 2 + 1];
-                L.cst[0] = cx; L.cst[1] = cy; L.cst[2] = refined_rcp(cx); L.cst[3] = refined_rcp(cy);
-                L.cst[4] = (float)W / 2.0f; L.cst[5] = (float)H / 2.0f;
-            }
-        }
         const bool wide = b < 64 ? L.wide[b] != 0 : false;
-        bool item_ready = !new_b;
 
         {
             if ((wide ? ty * 4 + sub : ty * 4 + 2 * (sub >> 1)) >= H) {   // the block lies below the image (uniform)
@@ -360,6 +304,72 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 }
             }
             DSTAMP(1)   // item set-up, pixel loads issued
+            // (the pixel loads above are in flight while the tables of a new batch item are built: where every workgroup runs ONE
+            //  item -- the model-real shapes -- that is a memory round trip off a 13 us launch)
+            // per BATCH item, for every wave: scaled channel means, the views' homography terms, the camera constants, the item's
+            // flags (visible behind the barrier in front of the first block's centring).  Items come out of the queues batch item
+            // by batch item: the tables are rebuilt a few times per launch, not once per tile.
+            const bool new_b = b + 1 != state >> 2;
+            if (new_b) {
+                state = (state & 3) | ((b + 1) << 2);
+                // (the lane's roles re-derived here: hoisted out of the item loop, the invariants of this rarely run block were
+                //  spilled registers of the whole kernel)
+                const int tid = opaque_v((int)threadIdx.x), lane = tid & 63;
+                const float* st = KARG(const float*, stats) + (size_t)b * STATS_STRIDE;
+                if (wave == 0) {
+                    // the scale (dist_layout.hpp: the same function of the same numbers as in the pack kernel) and the guard
+                    float am = st[STATS_AMAX + lane], sv = st[STATS_VAR + lane], sl_ = st[STATS_LAG + lane];
+                    if (lane + 64 < STATS_VAR) {
+                        am = fmaxf(am, st[STATS_AMAX + lane + 64]); sv += st[STATS_VAR + lane + 64]; sl_ += st[STATS_LAG + lane + 64];
+                    }
+                        // (xor shuffles whose lane arithmetic is part of the instruction -- ds_swizzle -- or hangs on the opaque lane
+                    //  above: __shfl_xor's own, hoisted out of the item loop, was a spilled register of the kernel)
+                    {
+                        const int x32 = (lane ^ 32) << 2;
+                        am = fmaxf(am, bperm_f(x32, am)); sv += bperm_f(x32, sv); sl_ += bperm_f(x32, sl_);
+#define PDEPTH_XOR_STEP(M) { const int pat = ((M) << 10) | 0x1f; \
+                             am = fmaxf(am, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, am), pat))); \
+                             sv += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sv), pat)); \
+                             sl_ += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sl_), pat)); }
+                        PDEPTH_XOR_STEP(16) PDEPTH_XOR_STEP(8) PDEPTH_XOR_STEP(4) PDEPTH_XOR_STEP(2) PDEPTH_XOR_STEP(1)
+#undef PDEPTH_XOR_STEP
+                    }
+                    const int e = dist::scale_exponent(am);
+                    const float sc = ldexpf(1.0f, e);
+                    // Guard.  The rounding error of Y = N - 2 X + |r'|^2 is 2^-23 of the ENERGY of the centred features (sum_c var_c,
+                    // trends across the image included: a constant per channel does not remove them), that of the reference's own
+                    // form 2^-23 of the cost, i.e. of their spread at the distance of a sweep (sum_c lag_c).  Measured on features
+                    // with trends (tools/dbg/dist_guard.py, depth against the CPU oracle): ratio 1.34 -> 3.6e-5 m, ratio 2.1 ..
+                    // 2.4 -> 1.0e-4 .. 1.4e-4 m, where the reference's form keeps 3e-5.  An item is evaluated directly where the
+                    // ratio exceeds DIST_GUARD_RATIO AND the energy is large enough against sigma for the difference to show
+                    // (unit-variance features: 67; features whose energy is all spread gain nothing from the direct form).
+                    const float sg = KARG(float, a.sigma);
+                    const bool outside = sv > DIST_GUARD_RATIO * sl_ && sv * 10.0f > DIST_GUARD_ENERGY * fabsf(sg);
+                    if (lane == 0) {
+                        L.cst[6] = sc; L.cst[7] = ldexpf(refined_rcp(sg), -2 * e);
+                        const int pf = reinterpret_cast<const int*>(st + STATS_FLAGS)[0];
+                        L.iflag = (pf != 0 ? 1 : 0) | (outside ? 2 : 0);
+                    }
+                    for (int c = lane; c < dist::MAX_C + 8; c += 64) L.mus[c] = st[c] * sc;
+                }
+                if (tid >= 128 && tid < 128 + V) {
+                    const int v = tid - 128;
+                    ViewXform xf;
+                    make_view_xform(KARG(const float*, a.K) + b * 9, KARG(const float*, a.R) + ((size_t)b * V + v) * 9,
+                                    KARG(const float*, a.t) + ((size_t)b * V + v) * 3, KARG(int, a.blas_mode), xf);
+    #pragma unroll
+                    for (int i = 0; i < 9; ++i) L.xf[v * 12 + i] = xf.kr[i];
+    #pragma unroll
+                    for (int i = 0; i < 3; ++i) L.xf[v * 12 + 9 + i] = xf.kt[i];
+                }
+                if (tid == 255) {
+                    const float* const cxcy_ = KARG(const float*, a.cxcy);
+                    const float cx = cxcy_[b * 2 + 0], cy = cxcy_[b * 2 + 1];
+                    L.cst[0] = cx; L.cst[1] = cy; L.cst[2] = refined_rcp(cx); L.cst[3] = refined_rcp(cy);
+                    L.cst[4] = (float)W / 2.0f; L.cst[5] = (float)H / 2.0f;
+                }
+            }
+            bool item_ready = !new_b;
             float rr = 0.0f, zc = 0.0f;    // |r'|^2 and |r|^2 of the pixel, scaled (set with the first pass)
             bool centred = false;
             unsigned failmask = 0;         // uniform over the workgroup: passes (view v, plane group h) left to the direct evaluation
