@@ -47,7 +47,9 @@ def test_bench_workload_against_the_oracle(dev, pose):
     ps = ops.pack_source(d["src"], 64)
     cp, lp, dp = ops.sweep_dpv(d["ref"], ps, d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0, want_cost=True)
     ca, la, da = _sweep(d, "auto")
-    assert torch.equal(cp, ca) and torch.equal(lp, la) and torch.equal(dp, da)
+    # (round 6: the NCHW entry's channel statistics also see the reference view, which pdepth_pack_source_f32 is not given:
+    #  another centring constant and scale, the same costs to rounding -- was bit for bit through round 5)
+    assert torch.allclose(cp, ca, rtol=2e-5, atol=5e-5) and torch.allclose(lp, la, rtol=0, atol=1e-4) and torch.allclose(dp, da, rtol=0, atol=1e-4)
 
 
 def test_config5_reduced_area_against_the_oracle(dev):

@@ -463,7 +463,10 @@ def test_packed_entry_with_gather_fallback(dev):
                 continue
             fb_total += pdepth_amd._native.fallback_tiles(2, H, W)
             ca, la, da = ops.sweep_dpv(d["ref"], d["src"], *args, feat_dist=metric, want_cost=True)
-            assert torch.equal(cp.nan_to_num(nan=-7.0), ca.nan_to_num(nan=-7.0)), (pose, metric)
-            assert torch.equal(dp.nan_to_num(nan=-7.0), da.nan_to_num(nan=-7.0)), (pose, metric)
-            assert torch.equal(lp.nan_to_num(nan=-7.0), la.nan_to_num(nan=-7.0)), (pose, metric)
+            # (L1: the float4 layout, bit for bit.  L2: the distance-form kernel's NCHW entry takes its channel statistics over
+            #  the source views AND the reference view -- round 6 --, the packed entry over the source views: equal to rounding)
+            same = torch.equal if metric == "L1" else (lambda x, y: torch.allclose(x, y, rtol=2e-5, atol=1e-4))
+            assert same(cp.nan_to_num(nan=-7.0), ca.nan_to_num(nan=-7.0)), (pose, metric)
+            assert same(dp.nan_to_num(nan=-7.0), da.nan_to_num(nan=-7.0)), (pose, metric)
+            assert same(lp.nan_to_num(nan=-7.0), la.nan_to_num(nan=-7.0)), (pose, metric)
     assert fb_total > 0, "these cases are meant to exercise the gather fallback"
