@@ -200,7 +200,10 @@ def main():
                     ps = ops.pack_source(d["src"], s["D"], "auto", metric)
                     cp, _, dp = ops.sweep_dpv(d["ref"], ps, *args[2:], feat_dist=metric, algo="auto", want_cost=True)
                     ca2, _, da2 = ops.sweep_dpv(*args, feat_dist=metric, algo="auto", want_cost=True)
-                    if not (torch.equal(cp.nan_to_num(), ca2.nan_to_num()) and torch.equal(dp.nan_to_num(), da2.nan_to_num())):
+                    # (round 6: the NCHW entry of the distance-form kernel takes its statistics over the source views and the
+                    #  reference view, the packed entry over the source views: the two agree to rounding, not bit for bit)
+                    close = lambda x, y: torch.allclose(x.nan_to_num(), y.nan_to_num(), rtol=3e-5, atol=3e-4 * max(1.0, float(np.max(np.abs(b["d_candi"]))) / 40.0))
+                    if not (close(cp, ca2) and close(dp, da2) and torch.equal(torch.isnan(cp), torch.isnan(ca2))):
                         print(tag, "packed entry differs from the plain entry")
                 except RuntimeError as e:   # shapes the packed entry declines
                     if "packed" not in str(e):
