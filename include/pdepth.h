@@ -198,7 +198,7 @@ int pdepth_sweep_dpv_packed_f32(const pdepth_sweep_desc *desc, const pdepth_came
  * of the LDS-tiled kernel; the default kernel keeps its eight per-XCD queue counters there, 256 bytes apart), 64 counter /
  * tag ints, the packed source views -- sized for the LARGEST of the layouts of the shape, so any pack fits any sweep:
  * max(B*V*(8*nchk(C)+4)*(H+2)*wp(W)*16 + 256*B*V, B*V*(ceil(C/4)+2)*H*W*16) bytes with nchk(C) = 0 | 1 | 2 chunks of 32
- * channels and wp(W) = W + 2 rounded up to a multiple of 4 -- and 416 floats of channel statistics per batch item.  Size it
+ * channels and wp(W) = W + 2 rounded up to a multiple of 4 -- and 496 floats of channel statistics per batch item.  Size it
  * once per shape and reuse it.  A call rewrites all of it: do not share one workspace between calls that may run
  * concurrently (different streams). */
 size_t pdepth_sweep_workspace_bytes(const pdepth_sweep_desc *desc);

@@ -46,7 +46,9 @@ constexpr int CORR_PACK_TIMEOUT_SLOT = 55;   // ... workgroups that gave up wait
 // difference of samples STATS_LAG_PX texels apart at +STATS_LAG (the spread of a channel at the distance of a plane sweep:
 // equal to var[c] for white features, smaller for smooth ones), and STATS_NFLAG ints at +STATS_FLAGS: [0] != 0 = a feature
 // of the item did not fit the fp16 range of the distance-form layout (pack_dist.hip)
-constexpr int STATS_VAR = 80, STATS_OFF = 160, STATS_AMAX = 240, STATS_LAG = 320, STATS_FLAGS = 400, STATS_NFLAG = 16, STATS_STRIDE = 416;
+constexpr int STATS_VAR = 80, STATS_OFF = 160, STATS_AMAX = 240, STATS_LAG = 320, STATS_FLAGS = 400, STATS_NFLAG = 16, STATS_READY = 416, STATS_STRIDE = 496;
+// STATS_READY: one int per channel = the tag of the launch whose statistics the row holds (pack_dist.hip: the pack kernel computes the
+// statistics in its first workgroups and every workgroup waits for its batch item's tags -- one pre-pass launch)
 constexpr int STATS_LAG_PX = 16;
 // which staging layout the packed-source region holds (written by the pack kernels, checked by the sweep kernels: a sweep on
 // another family's layout fills its outputs with NaN instead of returning numbers computed from the wrong bytes)
@@ -114,9 +116,11 @@ size_t sweep_ws_stats_offset(int B, int V, int C, int H, int W);
 
 // sweep_pack.hip: the channel statistics alone (mean-centring on), for the pack kernels of pack_dist.hip
 hipError_t launch_feature_stats(const SweepArgs& a, float* stats, hipStream_t stream);
+int sweep_resident_workgroups();   // 256-thread workgroups the device certainly holds at once (conservative)
 hipError_t launch_view_stats(const SweepArgs& a, const float* feat, const float* rgb, int rate, int img_h, int img_w, float* stats, hipStream_t stream);
 // pack_dist.hip: statistics + the source views in the distance-form kernel's layout (dist_layout.hpp)
-hipError_t launch_pack_dist(const SweepArgs& a, void* workspace, hipStream_t stream);
+// fuse_stats: the statistics inside the pack kernel (one launch) -- only where the sweep kernel follows in the same call: it clears the tags
+hipError_t launch_pack_dist(const SweepArgs& a, void* workspace, hipStream_t stream, bool fuse_stats = false);
 hipError_t launch_pack_views_dist(const SweepArgs& a, const float* feat, const float* rgb, int rate, int img_h, int img_w, float* ref_out,
                                   void* workspace, hipStream_t stream);
 // sweep_dist.hip (L2 only): distance form sum_t w_t |s_t - r|^2 - Q on the matrix pipe (fp16 high / low parts), C <= 72, D <= 128

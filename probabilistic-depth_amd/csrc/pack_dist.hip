@@ -10,12 +10,17 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "dist_layout.hpp"
 #include "kernels.hpp"
+#include "stats_body.hpp"
 
 #ifndef PDEPTH_PACK_NT_LOAD
 #define PDEPTH_PACK_NT_LOAD 0
+#endif
+#ifndef PDEPTH_PACK_FUSE_STATS
+#define PDEPTH_PACK_FUSE_STATS 1   // the channel statistics in the first workgroups of the pack kernel (one pre-pass launch instead of two)
 #endif
 #ifndef PDEPTH_PACK_NT_STORE
 #define PDEPTH_PACK_NT_STORE 0
@@ -260,10 +265,12 @@ __host__ __device__ inline int pack_dist_waves(int H, int W, int ROWS) {
 __device__ __forceinline__ float load_item_scale(const float* __restrict__ stats, int b, float* mus, float* scratch) {
     const float* st = stats + (size_t)b * STATS_STRIDE;
     const int t = threadIdx.x;
-    float am = t < STATS_VAR ? st[STATS_AMAX + t] : 0.0f;
-    const float mean_t = t < dist::MAX_C + 8 ? st[t] : 0.0f;   // (asked for with the maxima: one round trip, not two)
+    // (agent-scope loads: in the fused pre-pass the rows were written by other workgroups of this launch, on other XCDs)
+    auto ld = [&](int i) { return __hip_atomic_load(st + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    float am = t < STATS_VAR ? ld(STATS_AMAX + t) : 0.0f;
+    const float mean_t = t < dist::MAX_C + 8 ? ld(t) : 0.0f;   // (asked for with the maxima: one round trip, not two)
     if (t < 64) {
-        if (t + 64 < STATS_VAR) am = fmaxf(am, st[STATS_AMAX + t + 64]);
+        if (t + 64 < STATS_VAR) am = fmaxf(am, ld(STATS_AMAX + t + 64));
 #pragma unroll
         for (int sh = 32; sh >= 1; sh >>= 1) am = fmaxf(am, __shfl_xor(am, sh));
         if (t == 0) scratch[0] = am;
@@ -285,13 +292,69 @@ __device__ __forceinline__ void reset_queue(int* __restrict__ queue) {
     if (threadIdx.x < 64) queue[threadIdx.x] = threadIdx.x == LAYOUT_SLOT ? LAYOUT_DIST16 : 0;
 }
 
+// FUSED STATISTICS (tag != 0).  The channel statistics of the call are computed by the first C x B workgroups of this very launch
+// (one channel of one batch item each: stats_body.hpp), which publish them with the launch's tag; every workgroup then waits
+// for the tags of its batch item before it reads the means and the scale.  Workgroups are dispatched in the order of their
+// linear index, so the producers are resident -- and depend on nobody -- before any consumer can occupy their place: the
+// launcher fuses only where C x B is a fraction of what the device holds at once.  One lane of a workgroup polls (agent-scope
+// acquire loads, s_sleep in between), the others wait at the barrier behind it; a poll that does not come true in ~50 ms
+// gives up (the statistics of an earlier call, or zeros, are used: a wrong scale is loud -- NaN items -- and never a hang).
+// The tag is a kernel argument: a captured graph replays it.  So the sweep kernel that follows in the same call clears the tags
+// (sweep_dist.hip), and only the NCHW sweep entry fuses -- pdepth_pack_source_f32, which no sweep needs to follow, keeps the
+// statistics kernel in front.
+__device__ __forceinline__ void fused_stats(const float* __restrict__ src, long long bstride, long long vstride, int V, const float* __restrict__ ref,
+                                            long long ref_bstride, int B, int C, int H, int W, float* __restrict__ stats, int tag, int b_mine) {
+    const int Cs = C < STATS_VAR ? C : STATS_VAR;
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (lin < Cs * B) {
+        const int b = lin / Cs, c = lin - b * Cs;
+        float* st = stats + (size_t)b * STATS_STRIDE;
+        if (c == 0) {
+            if (threadIdx.x < STATS_VAR - C && C + (int)threadIdx.x < STATS_VAR) {   // channels beyond C
+                st[C + threadIdx.x] = 0.0f; st[STATS_VAR + C + threadIdx.x] = 0.0f; st[STATS_OFF + C + threadIdx.x] = 0.0f;
+                st[STATS_AMAX + C + threadIdx.x] = 0.0f; st[STATS_LAG + C + threadIdx.x] = 0.0f;
+            }
+            if (threadIdx.x < STATS_NFLAG) reinterpret_cast<int*>(st + STATS_FLAGS)[threadIdx.x] = 0;
+        }
+        stats_body::channel_stats<false>(src + (size_t)b * bstride + (size_t)c * H * W, vstride, V,
+                                         ref ? ref + (size_t)b * ref_bstride + (size_t)c * H * W : nullptr, H, W, 1, W, st + c, st + STATS_VAR + c, 1);
+        __syncthreads();   // (thread 0 wrote the channel's row, every thread its share of the zeros above)
+        // release without a fence (an agent-scope fence writes back / invalidates a whole L2 -- per workgroup that cost twice what
+        // the fusion saves): every thread pushes the words it wrote to the memory side with agent-scope stores, waits for their
+        // acknowledgements, and behind a barrier thread 0 publishes the tag -- the guide's "payload, vmcnt(0), flag" hand-off
+        if (threadIdx.x == 0) {
+            for (int o = 0; o < STATS_FLAGS; o += STATS_VAR) __hip_atomic_store(st + o + c, st[o + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (c == 0) {
+            if (threadIdx.x < STATS_VAR - C && C + (int)threadIdx.x < STATS_VAR)
+                for (int o = 0; o < STATS_FLAGS; o += STATS_VAR) __hip_atomic_store(st + o + C + threadIdx.x, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x < STATS_NFLAG) __hip_atomic_store(reinterpret_cast<int*>(st + STATS_FLAGS) + threadIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<int*>(st + STATS_READY) + c, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x < 64) {
+        const int* rdy = reinterpret_cast<const int*>(stats + (size_t)b_mine * STATS_STRIDE + STATS_READY);
+        for (int spin = 0; spin < (1 << 16); ++spin) {
+            bool ok = true;
+            for (int c = threadIdx.x; c < Cs; c += 64) ok = ok && __hip_atomic_load(rdy + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag;
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+            __builtin_amdgcn_s_sleep(20);
+        }
+    }
+    __syncthreads();   // (the rows behind the tags are read with agent-scope loads: load_item_scale)
+}
+
 template <int NCHK, int ROWS, bool SPLIT>
 __global__ __launch_bounds__(256) void pack_dist_kernel(const float* __restrict__ src, long long bstride, long long vstride, int V, int C,
                                                         int H, int W, char* __restrict__ out, int* __restrict__ flags, int nflags,
-                                                        int* queue, float* __restrict__ stats) {
+                                                        int* queue, float* __restrict__ stats, const float* __restrict__ ref, long long ref_bstride,
+                                                        int B, int tag) {
     for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < nflags; i += gridDim.x * gridDim.y * 256) flags[i] = 0;
     if (blockIdx.x == 0 && blockIdx.y == 0) reset_queue(queue);
     const int bv = blockIdx.y, b = bv / V;
+    if (tag != 0) fused_stats(src, bstride, vstride, V, ref, ref_bstride, B, C, H, W, stats, tag, b);
     __shared__ float mus[dist::MAX_C + 8];
     __shared__ float scratch[4];
     const float sc = load_item_scale(stats, b, mus, scratch);
@@ -343,21 +406,48 @@ __global__ __launch_bounds__(256) void pack_views_dist_kernel(const float* __res
                                        reinterpret_cast<int*>(stats + (size_t)b * STATS_STRIDE + STATS_FLAGS), part);
 }
 
+// workgroups of pack_dist_kernel<nck, PACK_ROWS, split> the device holds at once (occupancy query, cached)
+int pack_dist_resident(int nck, bool split) {
+    static int cache[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    int& c = cache[nck][split ? 1 : 0];
+    if (c == 0) {
+        int per_cu = 0;
+        hipError_t e = hipErrorUnknown;
+#define PDEPTH_OCC(N, S) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pack_dist_kernel<N, PACK_ROWS, S>, 256, 0)
+        if (nck == 0) { if (split) PDEPTH_OCC(0, true); else PDEPTH_OCC(0, false); }
+        else if (nck == 1) { if (split) PDEPTH_OCC(1, true); else PDEPTH_OCC(1, false); }
+        else { if (split) PDEPTH_OCC(2, true); else PDEPTH_OCC(2, false); }
+#undef PDEPTH_OCC
+        c = (e == hipSuccess && per_cu > 0 ? per_cu : 1) * sweep_device_cus();
+    }
+    return c;
+}
+
 }  // namespace
 
 // statistics + packed source of the distance-form kernel (what launch_pack_c4 is for the other two)
-hipError_t launch_pack_dist(const SweepArgs& a, void* workspace, hipStream_t stream) {
+hipError_t launch_pack_dist(const SweepArgs& a, void* workspace, hipStream_t stream, bool fuse_stats) {
     int* flags = reinterpret_cast<int*>(workspace);
     char* packed = static_cast<char*>(workspace) + sweep_ws_flag_bytes(a.B, a.H, a.W);
     float* stats = reinterpret_cast<float*>(static_cast<char*>(workspace) + sweep_ws_stats_offset(a.B, a.V, a.C, a.H, a.W));
     int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + sweep_ws_flag_only_bytes(a.B, a.H, a.W));
-    hipError_t e = launch_feature_stats(a, stats, stream);
-    if (e != hipSuccess) return e;
     const int nflags = (int)(sweep_ws_flag_only_bytes(a.B, a.H, a.W) / sizeof(int));
     const bool split = pack_dist_split(a.H, a.W);
     dim3 grid(split ? pack_dist_waves(a.H, a.W, PACK_ROWS) : (pack_dist_waves(a.H, a.W, PACK_ROWS) + 3) / 4, a.B * a.V);
+    // one launch where the statistics' producers (C x B workgroups) are a fraction of what the device holds at once and of the
+    // grid; else the statistics kernel in front, as through round 5
+    const long long nstat = (long long)(a.C < STATS_VAR ? a.C : STATS_VAR) * a.B;
+    static std::atomic<unsigned> launches{0};
+    int tag = 0;
+    // (half of what the occupancy query says the chip holds of this kernel: C x B = 268 at the headline shape, of 1 536)
+    if (PDEPTH_PACK_FUSE_STATS && fuse_stats && nstat * 2 <= pack_dist_resident(dist::nchk(a.C), split) && nstat <= (long long)grid.x * grid.y)
+        tag = (int)(launches.fetch_add(1) % 0x7fffffffu) + 1;   // (never 0; another one per launch of the process)
+    if (tag == 0) {
+        hipError_t e = launch_feature_stats(a, stats, stream);
+        if (e != hipSuccess) return e;
+    }
 #define PDEPTH_PACK_DIST(N, R) hipLaunchKernelGGL((pack_dist_kernel<N, R, SPLIT_>), grid, dim3(256), 0, stream, a.src, a.src_bstride, a.src_vstride, a.V, a.C, \
-                                                  a.H, a.W, packed, flags, nflags, queue, stats)
+                                                  a.H, a.W, packed, flags, nflags, queue, stats, a.ref, a.ref_bstride, a.B, tag)
 #define PDEPTH_PACK_DIST_R(N) do { if (split) { constexpr bool SPLIT_ = true; PDEPTH_PACK_DIST(N, PACK_ROWS); } else { constexpr bool SPLIT_ = false; PDEPTH_PACK_DIST(N, PACK_ROWS); } } while (0)
     switch (dist::nchk(a.C)) {
         case 0: PDEPTH_PACK_DIST_R(0); break;

@@ -141,6 +141,12 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
     // items of the others.
     const int xcd = blockIdx.x & 7;
     if (blockIdx.x == 0 && tid == 0) KARG(int*, queue)[DIST_NONCE_SLOT] = KARG(int, nonce);   // (diagnostics: whose count DIST_DIRECT_LAST_SLOT holds)
+    // the tags of the fused statistics (pack_dist.hip: fused_stats) are cleared for the next call on this workspace: a captured graph
+    // replays the pack kernel with the same tag (workgroup 1; nobody reads the tags during a sweep)
+    if (blockIdx.x == 1 % gridDim.x) {
+        float* st = const_cast<float*>(KARG(const float*, stats));
+        for (int i = tid; i < KARG(int, a.B) * STATS_VAR; i += 256) reinterpret_cast<int*>(st + (size_t)(i / STATS_VAR) * STATS_STRIDE + STATS_READY)[i % STATS_VAR] = 0;
+    }
     auto band_tiles_of = [&](int q) { const int nt = KARG(int, ntile); return (nt >> 3) + (q < (nt & 7) ? 1 : 0); };
     auto band_first_of = [&](int q) {
         const int nt = KARG(int, ntile), qq = nt >> 3, rr8 = nt & 7;
@@ -928,7 +934,7 @@ hipError_t launch_sweep_dist(const SweepArgs& a, void* workspace, hipStream_t st
     int* queue = reinterpret_cast<int*>(static_cast<char*>(workspace) + sweep_ws_flag_only_bytes(a.B, a.H, a.W));
     const float* stats = reinterpret_cast<const float*>(static_cast<char*>(workspace) + sweep_ws_stats_offset(a.B, a.V, a.C, a.H, a.W));
     if (!packed_ready) {
-        hipError_t e = launch_pack_dist(a, workspace, stream);
+        hipError_t e = launch_pack_dist(a, workspace, stream, /*fuse_stats=*/true);
         if (e != hipSuccess) return e;
     }
     const int nck = dist::nchk(a.C);

@@ -126,3 +126,35 @@ def test_a_nan_candidate_plane(dev):
         assert torch.equal(torch.isnan(depth), torch.isnan(odepth)), algo
         fin = torch.isfinite(ocost)
         np.testing.assert_allclose(cost[fin].numpy(), ocost[fin].numpy(), rtol=COST_RTOL, atol=COST_ATOL, err_msg=algo)
+
+
+def test_nchw_entry_is_two_capturable_launches(dev):
+    """the NCHW call of the default kernel is a pack kernel (which computes the channel statistics in its
+    first workgroups: csrc/pack_dist.hip fused_stats) and the sweep kernel.  Captured into a graph and replayed on NEW features
+    in the captured buffers it gives the eager call's answer bit for bit -- the statistics' tags are a kernel argument a replay
+    repeats, the sweep kernel clears them."""
+    b = synth.make_batch(41, 2, C=67, D=64, H=64, W=128, V=1, pose="mono")
+    d = to_dev(b, dev)
+    ref, src = d["ref"].clone(), d["src"].clone()
+    run = lambda: ops.sweep_dpv(ref, src, d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0)
+    want0 = [x.clone() for x in run()[1:]]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = run()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[1], want0[0]) and torch.equal(out[2], want0[1])
+    for seed, scale in ((42, 1.0), (43, 30.0), (44, 0.02)):     # other frames, other magnitudes: another scale exponent every time
+        b2 = synth.make_batch(seed, 2, C=67, D=64, H=64, W=128, V=1, pose="mono")
+        ref.copy_(b2["ref"].to(dev) * scale); src.copy_(b2["src"].to(dev) * scale)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [out[1].clone(), out[2].clone()]
+        want = run()
+        assert torch.equal(got[0], want[1]) and torch.equal(got[1], want[2]), (seed, scale)
