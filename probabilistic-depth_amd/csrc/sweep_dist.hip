@@ -81,7 +81,8 @@ __device__ __forceinline__ float dist_exp(float x) {
 template <int MAXB, int NAC>
 struct __attribute__((aligned(16))) DistLds {
     static constexpr int XSTRIDE = MAXB * 16 + 4;   // floats per pixel of the Y buffer (stride / 4 odd: conflict-free b128 stores)
-    float Ys[16 * XSTRIDE];      // Y[pixel][slot]
+    float Ys[16 * XSTRIDE + DIST_YSKEW];   // Y[pixel][slot]; the rows of pixels 8 .. 15 begin DIST_YSKEW floats later (their slots differ from
+                                           // those of pixels 0 .. 7 by a source row = a multiple of 16: the same LDS banks without the skew)
     float Qs[(MAXB + 3) / 4 * 256 + 8];   // Q record (Dx0, Dy0, Dd, Dx1) per slot (moved in groups of four blocks: whole groups)
     _Float16 Bs[NAC * 4 * 16 * 8];   // pixel-side operands of the block's 16 pixels: [chunk][kq][pixel][8], -2 x (high | low) parts
     float rp[4 * 16 * 2];        // per wave and pixel: partial |r'|^2, |r|^2 (scaled)
@@ -591,6 +592,22 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                         const int q = (nb + 3) >> 2, b0 = wave * q, b1 = min(nb, b0 + q);
                         if (DIST_XPRIO) __builtin_amdgcn_s_setprio(DIST_XPRIO);
                         if (go) {
+#if DIST_Q_LAST
+#pragma unroll
+                            for (int u = 0; u < NS; ++u)
+                                if (b0 + u < b1) fetch_block(u, __builtin_amdgcn_readlane(boff, b0 + u));
+                            // the Q records of the pass's cells, from memory straight to LDS: blocks 4 g .. 4 g + 3 per instruction
+                            // (lane = (block, texel)); wave w moves groups w and w + 4
+#pragma unroll
+                            for (int gq = 0; gq < (MAXB + 15) / 16; ++gq) {
+                                const int g = wave + 4 * gq;
+                                if (4 * g < nb) {   // uniform
+                                    const int bo = __builtin_amdgcn_ds_bpermute(4 * (4 * g + kq), boff);
+                                    const int vq = 4 * g + kq < nb ? bo + n * 16 : OOB;
+                                    dma_b128(rsrc, lds_addr_of(&L.Qs[g * 256]), vq, QPL * PB);
+                                }
+                            }
+#else
                             // the Q records of the pass's cells, from memory straight to LDS: blocks 4 g .. 4 g + 3 per instruction
                             // (lane = (block, texel)); wave w moves groups w and w + 4
 #pragma unroll
@@ -605,6 +622,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
 #pragma unroll
                             for (int u = 0; u < NS; ++u)
                                 if (b0 + u < b1) fetch_block(u, __builtin_amdgcn_readlane(boff, b0 + u));
+#endif
                         }
                         // the slots of this thread's cells (under the first blocks' loads)
 #pragma unroll
@@ -653,7 +671,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                                         if (more) fetch(u, NAC - 1, soff);
                                     }
                                     // Y[texel 4 kq ..][pixel n] of the block
-                                    *reinterpret_cast<v4f*>(&L.Ys[n * XSTRIDE + 16 * bj + 4 * kq]) = acc;
+                                    *reinterpret_cast<v4f*>(&L.Ys[n * XSTRIDE + (n >> 3) * DIST_YSKEW + 16 * bj + 4 * kq]) = acc;
                                 }
                             }
                             DSTAMP(6)   // slots, loads + multiplications
@@ -675,7 +693,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                         failmask |= 1u << (v * NH + h);
                     } else {
                         const float cinv = L.cst[7];
-                        const float* yr = &L.Ys[n * XSTRIDE];
+                        const float* yr = &L.Ys[n * XSTRIDE + (n >> 3) * DIST_YSKEW];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             // (no tap inside the image: the taps read zero, cost = |r|^2 -- and NaN where the position itself
