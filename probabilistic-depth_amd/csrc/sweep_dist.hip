@@ -793,11 +793,11 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
             // (the planes' scalar offsets are formed here, from a value the optimiser cannot trace back: hoisted to the top of
             //  the item they were four spilled scalars, read back lane by lane with five wait states each in front of a store)
             resolve_next();
-            const int HW4 = opaque_s(HW * 4);
+            const int HW4 = KARG(int, a.H) * KARG(int, a.W) * 4;   // (re-read: HW * 4 kept from the top of the block was a spilled scalar)
             const int ovoff = xlive ? 4 * kq * HW4 + p * 4 : OOB;
             const int pl0 = 16 * wave * HW4;
             if (float* const cost_out = KARG(float*, a.cost_out)) {
-                const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(cost_out + (size_t)b * D * HW), 0, D * HW * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(cost_out + (size_t)b * D * (HW4 >> 2)), 0, D * HW4, 0x00020000);
 #pragma unroll
                 for (int j = 0; j < NC; ++j)   // (planes beyond D lie beyond the descriptor: dropped)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cost[j]), rc, ovoff, pl0 + (64 * (j >> 2) + (j & 3)) * HW4, DIST_STORE_AUX);
@@ -843,13 +843,13 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                     }
                     const float ls = logf(S_);
                     if (logp_out) {
-                        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(logp_out + (size_t)b * D * HW), 0, D * HW * 4, 0x00020000);
+                        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(logp_out + (size_t)b * D * (HW4 >> 2)), 0, D * HW4, 0x00020000);
 #pragma unroll
                         for (int j = 0; j < NC; ++j)
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (cost[j] - M) - ls), rl, ovoff,
                                                                   pl0 + (64 * (j >> 2) + (j & 3)) * HW4, DIST_STORE_AUX);
                     }
-                    if (depth_out && xlive && tq == 0) depth_out[(size_t)b * HW + p] = E / S_;
+                    if (depth_out && xlive && tq == 0) depth_out[(size_t)b * (HW4 >> 2) + p] = E / S_;
                 }
             } else {
                 publish_next();
