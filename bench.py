@@ -190,7 +190,7 @@ def main():
         pass
     # SURVEY 8(d), "Ambiguity resolved": the 64x128 model-real number is always reported next to the 256x512 one, and both the
     # N(0,1) and the peaked feature variants.  GPU time per call from HIP events over 50 back-to-back calls (the launch gaps of
-    # the call are inside); launches per call: NCHW entry = pack (with the channel statistics in its first workgroups) + sweep, packed entry = the sweep.
+    # the call are inside); launches per call: NCHW entry = statistics + pack + sweep, packed entry = the sweep.
     secondary = {}
     if not a.no_secondary and a.algo in ("auto", "dist", "corr") and rank == 0 and not a.config:
         def small(Bs, entry):
@@ -213,7 +213,7 @@ def main():
                 us = min(us, e0.elapsed_time(e1) / 50 * 1e3)
                 wall_us = min(wall_us, (time.perf_counter() - t0) / 50 * 1e6)
             by = algorithmic_bytes_per_volume(cfg["C"], cfg["V"], cfg["D"], 64, 128) * Bs
-            return {"us_per_call": us, "wall_us_per_call": wall_us, "launches": 1 if entry == "packed" else 2,
+            return {"us_per_call": us, "wall_us_per_call": wall_us, "launches": 1 if entry == "packed" else 3,
                     "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "volumes_per_s": Bs / (us * 1e-6)}
         try:
             secondary["model_real"] = {"shape": "C=%d D=%d 64x128 V=%d pose=%s (the reference sweeps a 256x512 frame at 1/4 resolution: "
@@ -343,7 +343,7 @@ def main():
                 #  with the commit and box it was collected on)
                 "traffic_source": prof.get("source"),
                 "traffic_collected": prof.get("collected"),
-                "kernel": ("fused sweep+DPV call = pack_dist_kernel (pre-pass: channel statistics in its first workgroups, centred fp16 re-layout "
+                "kernel": ("fused sweep+DPV call = feature_stats_kernel + pack_dist_kernel (pre-pass: channel statistics, centred fp16 re-layout "
                            "+ neighbour differences) + " + kname if impl == "dist" else
                            "fused sweep+DPV call = feature_stats_kernel + pack_c4_kernel (pre-pass: channel means, centred re-layout) + " + kname
                            if impl == "corr" else

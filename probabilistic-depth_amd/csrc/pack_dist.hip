@@ -20,7 +20,11 @@
 #define PDEPTH_PACK_NT_LOAD 0
 #endif
 #ifndef PDEPTH_PACK_FUSE_STATS
-#define PDEPTH_PACK_FUSE_STATS 1   // the channel statistics in the first workgroups of the pack kernel (one pre-pass launch instead of two)
+#define PDEPTH_PACK_FUSE_STATS 0   // 1: the channel statistics in the first workgroups of the pack kernel (one pre-pass launch instead of two).
+                                   // Built, parity-green (graph replays included), measured SLOWER on one box, A/B twice (us per NCHW call,
+                                   // separate / fused): B=1 64x128 23.0 / 27.4, B=4 64x128 41.7 / 45.0, B=1 256x512 111.5 / 115.0, headline
+                                   // 398 / 400, config 5 4 160 / 4 200 -- every workgroup of the grid polls and reads its means past L2
+                                   // (agent-scope loads), which costs more than the launch it saves (profiles/r06_ab/README.md): off
 #endif
 #ifndef PDEPTH_PACK_NT_STORE
 #define PDEPTH_PACK_NT_STORE 0

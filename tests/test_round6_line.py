@@ -21,7 +21,7 @@ def test_committed_bench_line_of_round_6():
     assert w["cfg5_share"]["ms_per_call"] / w["cfg5_share"]["B"] < 2.3
     for key in ("B1_nchw", "B1_packed", "B4_nchw", "B4_packed"):
         row = line["model_real"][key]
-        assert row["us_per_call"] > 0 and row["launches"] in (1, 2) and 0 < row["frac"] < 1, key
+        assert row["us_per_call"] > 0 and row["launches"] in (1, 3) and 0 < row["frac"] < 1, key
     assert line["packed_entry"]["kernel_ms"] < 0.34 and line["packed_entry"]["max_abs_depth_diff_vs_headline"] <= 1e-4
     assert line["preflight"]["max_abs_depth_diff_vs_gather_kernel"] <= 1e-4
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["max_abs_depth_diff_gpu_vs_port_item0"] <= 1e-4

@@ -128,11 +128,11 @@ def test_a_nan_candidate_plane(dev):
         np.testing.assert_allclose(cost[fin].numpy(), ocost[fin].numpy(), rtol=COST_RTOL, atol=COST_ATOL, err_msg=algo)
 
 
-def test_nchw_entry_is_two_capturable_launches(dev):
-    """the NCHW call of the default kernel is a pack kernel (which computes the channel statistics in its
-    first workgroups: csrc/pack_dist.hip fused_stats) and the sweep kernel.  Captured into a graph and replayed on NEW features
-    in the captured buffers it gives the eager call's answer bit for bit -- the statistics' tags are a kernel argument a replay
-    repeats, the sweep kernel clears them."""
+def test_nchw_entry_is_capturable(dev):
+    """the NCHW call of the default kernel -- statistics, pack, sweep: no host synchronisation, no allocation --
+    captured into a graph and replayed on NEW features in the captured buffers gives the eager call's answer bit for bit.  (Also
+    with -DPDEPTH_PACK_FUSE_STATS=1, the statistics inside the pack kernel: their tags are a kernel argument a replay repeats, the
+    sweep kernel clears them.  That build was 2-4 us per call SLOWER on every shape -- csrc/pack_dist.hip -- and is off.)"""
     b = synth.make_batch(41, 2, C=67, D=64, H=64, W=128, V=1, pose="mono")
     d = to_dev(b, dev)
     ref, src = d["ref"].clone(), d["src"].clone()
