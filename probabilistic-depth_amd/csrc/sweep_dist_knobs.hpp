@@ -32,7 +32,7 @@
 #define DIST_XPRIO 1       // wave priority in the matrix phase
 #endif
 #ifndef DIST_STORE_AUX
-#define DIST_STORE_AUX 2   // nt: the outputs are written once and not read by this kernel (0, 1, 3: no difference measured)
+#define DIST_STORE_AUX 0   // cache policy of the output stores: default (write-back: the two 32-byte halves of a 64-byte piece, written by the workgroups of neighbouring pixel blocks, merge in L2 -- WRITE_SIZE 145 MB per launch = the output; nt, round 5: 245 MB; same time)
 #endif
 #ifndef DIST_BANDS
 #define DIST_BANDS 16      // bands of tile rows per image in the XCD partition: 16 (XCD q: half-bands q and 8 + q) | 8 (band q: 7 % fewer L2 misses, 5 % slower -- the XCDs' loads differ; profiles/r05_ab/xcd_bands_8_vs_16.txt)
