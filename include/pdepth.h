@@ -157,10 +157,12 @@ int pdepth_sweep_dpv_f32(const pdepth_sweep_desc *desc, const pdepth_camera *cam
  *   pdepth_pack_source_f32      : src [B,V,C,H,W] (strides from desc) -> workspace, in the layout the sweep kernel that
  *                                 `desc` selects reads (pdepth_sweep_source_layout(desc)):
  *                                   PDEPTH_LAYOUT_DIST16 (L2, C <= 72, D <= 128, V <= 8: what AUTO runs): per view an
- *                                     (H + 2) x (W + 2) image (a ring of zero-feature texels), planes of 16 bytes per texel:
- *                                     the centred, power-of-two scaled features as fp16 high and low parts in matrix-operand
- *                                     order, |x'|^2 as three fp16 pieces, and an fp32 record of the five squared neighbour
- *                                     differences of the cell (20 planes = 320 bytes per texel at C = 67; csrc/dist_layout.hpp);
+ *                                     (H + 2) x wp(W) image (a ring of zero-feature texels; rows padded to a multiple of 8
+ *                                     texels), planes of 16 bytes per texel: the centred, power-of-two scaled features as
+ *                                     fp16 high and low parts in matrix-operand order, |x'|^2 as three fp16 pieces, and an
+ *                                     fp32 record of the five squared neighbour differences of the cell (20 planes = 320
+ *                                     bytes per texel at C = 67), stored texel-group-major: the planes of four consecutive
+ *                                     texels of a row lie together (1 280 bytes at C = 67; csrc/dist_layout.hpp);
  *                                   PDEPTH_LAYOUT_C4 (L1 metric, C > 72, D > 128: the LDS-tiled kernel): float4 texels of 4
  *                                     channels, planes [ceil(C/4)][H][W], + 2 Gram planes;
  *   pdepth_sweep_dpv_packed_f32 : the sweep on a workspace packed by that call for a desc with the same B, V, C, H, W and
@@ -194,11 +196,11 @@ int pdepth_sweep_dpv_packed_f32(const pdepth_sweep_desc *desc, const pdepth_came
                                 void *workspace, size_t workspace_bytes, void *stream);
 
 /* Bytes of scratch the two sweep entry points need for `desc` (0 for ALGO_DIRECT); the workspace
- * must be 256-byte aligned.  ALGO_AUTO without it returns PDEPTH_E_WORKSPACE.  It holds one int per 16x4 tile (tile flags
- * of the LDS-tiled kernel; the default kernel keeps its eight per-XCD queue counters there, 256 bytes apart), 64 counter /
- * tag ints, the packed source views -- sized for the LARGEST of the layouts of the shape, so any pack fits any sweep:
+ * must be 256-byte aligned.  ALGO_AUTO without it returns PDEPTH_E_WORKSPACE.  It holds two ints per 16x4 tile (tile flags
+ * and the list of left-over tiles of the LDS-tiled kernel; the default kernel keeps its eight per-XCD queue counters in the
+ * first, 256 bytes apart), 64 counter / tag ints, the packed source views -- sized for the LARGEST of the layouts of the shape, so any pack fits any sweep:
  * max(B*V*(8*nchk(C)+4)*(H+2)*wp(W)*16 + 256*B*V, B*V*(ceil(C/4)+2)*H*W*16) bytes with nchk(C) = 0 | 1 | 2 chunks of 32
- * channels and wp(W) = W + 2 rounded up to a multiple of 4 -- and 496 floats of channel statistics per batch item.  Size it
+ * channels and wp(W) = W + 2 rounded up to a multiple of 8 -- and 496 floats of channel statistics per batch item.  Size it
  * once per shape and reuse it.  A call rewrites all of it: do not share one workspace between calls that may run
  * concurrently (different streams). */
 size_t pdepth_sweep_workspace_bytes(const pdepth_sweep_desc *desc);

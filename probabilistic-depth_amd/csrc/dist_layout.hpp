@@ -17,7 +17,8 @@
 // The kernel multiplies h_s h_r + h_s l_r + l_s h_r with v_mfma_f32_16x16x32_f16 (fp32 accumulation): measured as accurate
 // as the fp32 matrix instruction (tools/mb_split16.hip), 4.9 times fewer matrix cycles.
 //
-// Planes of 16 bytes (8 fp16 = one lane's share of a K = 32 matrix operand) per texel, image (H + 2) x (W + 2):
+// Planes of 16 bytes (8 fp16 = one lane's share of a K = 32 matrix operand) per texel, image (H + 2) x wp(W) (W + 2 rounded up
+// to a multiple of 8), stored group-major (below: texel_offset):
 //     [hi: 4 NCHK planes]  channels 8 p .. 8 p + 7 of the first 32 NCHK channels, high parts
 //     [lo: 4 NCHK planes]  ... low parts
 //     [tail: 3 planes]     high parts of the T = C - 32 NCHK left-over channels; their low parts; the specials
@@ -45,13 +46,26 @@ constexpr float F16_MAX = 65504.0f;
 
 __host__ __device__ inline int nchk(int C) { return C <= 8 ? 0 : (C <= 40 ? 1 : 2); }
 __host__ __device__ inline int nplanes(int C) { return 8 * nchk(C) + 3 + 1; }
-// (rows padded to a multiple of 4 texels: a block of 16 texels that starts at a multiple of 4 is read as whole 64-byte pieces)
-__host__ __device__ inline int wp(int W) { return (W + 2 * RING + 3) & ~3; }
+// Texel-group-major (round 6): the planes of GROUP = 4 consecutive texels of a row are contiguous -- nplanes x 64 bytes = 1 280
+// at C = 67 --, so the 16 texels x 20 planes of an operand block of the sweep (which starts at a group) are 5 KB in ONE piece
+// (one DRAM page, one TLB entry) instead of twenty 256-byte pieces 2 MB apart (plane-major, rounds 4-5), and a load instruction
+// of the sweep (4 planes of 16 texels) reads four runs of 256 bytes.  Measured against plane-major on one box (profiles/r06_ab/):
+// packed sweep -3 % (config 2), -2 % (config 3), -5 % (config 5); with groups of 8 texels (whole 128-byte lines per plane) the
+// blocks that start in the middle of a group read half lines: +1 .. +5 % against groups of 4.
+constexpr int GROUP = 4;
+constexpr int GROUP_PLANE_BYTES = GROUP * 16;
+// (rows of whole octets of texels: eight lanes of the pack kernel write two groups -- pack_dist.hip: pack_store_pair)
+__host__ __device__ inline int wp(int W) { return (W + 2 * RING + 7) & ~7; }
 __host__ __device__ inline int hp(int H) { return H + 2 * RING; }
-// bytes of one plane / one view; a view's planes are followed by 256 bytes that a block of 16 texels starting at the
-// last texels of the image may read (never used)
+// bytes of one plane of a view / of one view; a view is followed by 256 bytes that a block of 16 texels starting at the last
+// texels of the image may read (never used)
 __host__ __device__ inline long long plane_bytes(int H, int W) { return (long long)hp(H) * wp(W) * 16; }
 __host__ __device__ inline long long view_bytes(int C, int H, int W) { return (long long)nplanes(C) * plane_bytes(H, W) + 256; }
+__host__ __device__ inline int group_bytes(int C) { return nplanes(C) * GROUP_PLANE_BYTES; }
+// where the 16 bytes of (plane p, padded texel (yp, xp)) of a view lie
+__host__ __device__ inline long long texel_offset(int C, int H, int W, int p, int yp, int xp) {
+    return ((long long)yp * (wp(W) / GROUP) + xp / GROUP) * group_bytes(C) + p * GROUP_PLANE_BYTES + (xp % GROUP) * 16;
+}
 
 // value = p1 2^15 + p2 2^4 + p3 2^-7 with fp16 pieces (value >= 0, < 2^31)
 struct Pieces { _Float16 p1, p2, p3; };

@@ -36,6 +36,7 @@ namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 
 // source accessors: raw feature c of texel (y, x) of view (b, v); the caller only asks for texels inside the image
 struct NchwSource {
@@ -89,6 +90,31 @@ struct ViewSource {
 #define PACK_ST(T, p, v) (*reinterpret_cast<T*>(p) = (v))
 #endif
 
+// Two planes P (even), P + 1 of a lane's texel into the layout of groups of four texels (dist_layout.hpp), in whole 128-byte
+// lines.  Lane by lane the two stores would write 64-byte halves of lines (a group's plane is 64 bytes) -- measured 20 % slower
+// for the whole kernel than the plane-major layout.  Instead the two quads of every eight lanes trade values (lane ^ 4): the
+// first store writes both planes of the EVEN group (lanes 0-3 their own X, lanes 4-7 the Y of lanes 0-3), the second both
+// planes of the odd group.  row8 = where plane P of the even group's first texel lies; the eight lanes' texels are in one row.
+__device__ __forceinline__ void pack_store_pair(char* row8, int group_bytes, v4i X, v4i Y) {
+    const int lane = threadIdx.x & 63;
+    const bool odd = lane & 4;
+    v4i send, recv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        send[k] = odd ? X[k] : Y[k];
+        recv[k] = __builtin_amdgcn_ds_swizzle(send[k], 0x101f);   // lane ^ 4
+    }
+    char* p = row8 + (lane & 7) * 16;
+    v4i first, second;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        first[k] = odd ? recv[k] : X[k];
+        second[k] = odd ? Y[k] : recv[k];
+    }
+    PACK_ST(v4i, p, first);
+    PACK_ST(v4i, p + group_bytes, second);
+}
+
 __device__ __forceinline__ float wave_shl1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
@@ -103,7 +129,6 @@ __device__ __forceinline__ void pack_dist_strip(const Source& src, int C, int H,
     static_assert(!SPLIT || ROWS == 1, "the split mode is written for one row per strip");
     const int lane = threadIdx.x & 63;
     const int Wp = dist::wp(W), Hp = dist::hp(H);
-    const long long PB = dist::plane_bytes(H, W);
     const long long nelem = (long long)((Hp + ROWS - 1) / ROWS) * Wp;
     // this lane's column, and the column whose texels lane 63 needs as right-hand neighbours (the "halo": element e0 + 64)
     const long long e = e0 + lane;
@@ -144,6 +169,10 @@ __device__ __forceinline__ void pack_dist_strip(const Source& src, int C, int H,
         }
         v[NV - 1] = src.at(min(8 * g + hj, C - 1), yha, xha);
     };
+    constexpr bool PAIRED = !SPLIT;   // (pack_store_pair)
+    auto row8 = [&](int pl, int r) { return out + dist::texel_offset(C, H, W, pl, yp0 + r, xp & ~7); };
+    const int GB = dist::group_bytes(C);
+    h8 hk[ROWS], lk[ROWS];   // (PAIRED: the planes of the even round, kept for the odd one)
     auto finish = [&](int g, const float(&v)[NV]) {
         h8 hh[ROWS], ll[ROWS];
         // x' = (x - mu) 2^e in one rounding (the scaling is exact); outside the image, and beyond C: x = 0
@@ -182,13 +211,22 @@ __device__ __forceinline__ void pack_dist_strip(const Source& src, int C, int H,
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
                 if (yp0 + r >= Hp) break;
-                const size_t toff = ((size_t)(yp0 + r) * Wp + xp) * 16;
-                if (g < 4 * NCHK) {
-                    PACK_ST(h8, out + (size_t)g * PB + toff, hh[r]);
-                    PACK_ST(h8, out + (size_t)(4 * NCHK + g) * PB + toff, ll[r]);
+                auto at = [&](int pl) { return out + dist::texel_offset(C, H, W, pl, yp0 + r, xp); };
+                if (PAIRED) {
+                    if (g == 4 * NCHK) {   // the tail: high and low parts are neighbours
+                        pack_store_pair(row8(8 * NCHK, r), GB, __builtin_bit_cast(v4i, hh[r]), __builtin_bit_cast(v4i, ll[r]));
+                    } else if (g & 1) {
+                        pack_store_pair(row8(g - 1, r), GB, __builtin_bit_cast(v4i, hk[r]), __builtin_bit_cast(v4i, hh[r]));
+                        pack_store_pair(row8(4 * NCHK + g - 1, r), GB, __builtin_bit_cast(v4i, lk[r]), __builtin_bit_cast(v4i, ll[r]));
+                    } else {
+                        hk[r] = hh[r]; lk[r] = ll[r];
+                    }
+                } else if (g < 4 * NCHK) {
+                    PACK_ST(h8, at(g), hh[r]);
+                    PACK_ST(h8, at(4 * NCHK + g), ll[r]);
                 } else {
-                    PACK_ST(h8, out + (size_t)(8 * NCHK + 0) * PB + toff, hh[r]);
-                    PACK_ST(h8, out + (size_t)(8 * NCHK + 1) * PB + toff, ll[r]);
+                    PACK_ST(h8, at(8 * NCHK + 0), hh[r]);
+                    PACK_ST(h8, at(8 * NCHK + 1), ll[r]);
                 }
             }
         }
@@ -235,15 +273,19 @@ __device__ __forceinline__ void pack_dist_strip(const Source& src, int C, int H,
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         if (yp0 + r >= Hp) break;
-        const size_t toff = ((size_t)(yp0 + r) * Wp + xp) * 16;
+        auto at = [&](int pl) { return out + dist::texel_offset(C, H, W, pl, yp0 + r, xp); };
         ovf = ovf || !(n[r] < 2.0e9f);
         const dist::Pieces pn = dist::split_pieces(fminf(n[r], 2.0e9f));
         h8 sp;
         sp[0] = pn.p1; sp[1] = pn.p2; sp[2] = pn.p3;
         sp[3] = (_Float16)dist::PIECE_C1; sp[4] = (_Float16)dist::PIECE_C2; sp[5] = (_Float16)dist::PIECE_C3;
         sp[6] = (_Float16)0.f; sp[7] = (_Float16)0.f;
-        PACK_ST(h8, out + (size_t)(8 * NCHK + 2) * PB + toff, sp);
-        PACK_ST(v4f, out + (size_t)(8 * NCHK + 3) * PB + toff, (v4f{dx[r], dy0[r], dd[r], dx[r + 1]}));
+        if (PAIRED) {
+            pack_store_pair(row8(8 * NCHK + 2, r), GB, __builtin_bit_cast(v4i, sp), __builtin_bit_cast(v4i, v4f{dx[r], dy0[r], dd[r], dx[r + 1]}));
+        } else {
+            PACK_ST(h8, at(8 * NCHK + 2), sp);
+            PACK_ST(v4f, at(8 * NCHK + 3), (v4f{dx[r], dy0[r], dd[r], dx[r + 1]}));
+        }
     }
     if (ovf) atomicOr(item_flags, 1);
 }
@@ -351,7 +393,7 @@ __device__ __forceinline__ void fused_stats(const float* __restrict__ src, long 
 }
 
 template <int NCHK, int ROWS, bool SPLIT>
-__global__ __launch_bounds__(256) void pack_dist_kernel(const float* __restrict__ src, long long bstride, long long vstride, int V, int C,
+__global__ __launch_bounds__(256, 4) void pack_dist_kernel(const float* __restrict__ src, long long bstride, long long vstride, int V, int C,
                                                         int H, int W, char* __restrict__ out, int* __restrict__ flags, int nflags,
                                                         int* queue, float* __restrict__ stats, const float* __restrict__ ref, long long ref_bstride,
                                                         int B, int tag) {

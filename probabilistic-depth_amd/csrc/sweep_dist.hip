@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                             const v2i e0 = *reinterpret_cast<const v2i*>(&L.ctab[par][((yb + lane) & 63) * 2]);
                             const v2i e1 = *reinterpret_cast<const v2i*>(&L.ctab[par][((yb + lane - 1) & 63) * 2]);
                             const int l0 = min(e0.x, e1.x), h0 = max(e0.y, e1.y);
-                            // (blocks start at a multiple of 4 texels of the padded row: 64-byte pieces for the loads of four lanes)
+                            // (blocks start at a multiple of 4 texels of the padded row: whole 64-byte pieces for the loads of four lanes)
                             lo = ((l0 + dist::RING) & ~3) - dist::RING;
                             nblk = l0 <= h0 ? (h0 - lo + 2 + 15) >> 4 : 0;   // texels lo .. hi + 1
                             const int incl = wave_scan_incl(nblk);
@@ -558,9 +558,15 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                     // ---- Y = |s' - r'|^2 for the blocks of the pass, on the matrix pipe ------------------------------------
                     int sl0[4], sl1[4];   // slots of the top / bottom row of this thread's cells
                     {
-                        const int PB = (int)dist::plane_bytes(H, W), Wp = dist::wp(W);
+                        // byte steps of the packed view (dist_layout.hpp: texel_offset): between the planes of a texel (PB), between
+                        // the groups of four texels (GB), and what a lane adds for its texel n of a block.  A block = four whole
+                        // groups: one load instruction (4 planes of 16 texels) reads four runs of 256 bytes, all the operands of
+                        // a block lie within 5 KB.
+                        constexpr int PB = dist::GROUP_PLANE_BYTES, GB = (8 * NCHK + 4) * PB;   // (= dist::group_bytes(C): nchk(C) = NCHK)
+                        const int Wp = dist::wp(W);
+                        const int ntex = (n / dist::GROUP) * GB + (n % dist::GROUP) * 16;
                         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)srcv, 0, (int)dist::view_bytes(C, H, W), 0x00020000);
-                        const int voffA = opaque_v(n * 16 + kq * PB);
+                        const int voffA = opaque_v(ntex + kq * PB);
                         // a block's texel operands in consumption order: (high c, low c) for c < NCHK, tail; NS register sets: NS
                         // blocks of the wave are in flight, every chunk refilled with the operands of the block after the next
                         // right behind its last multiplication.  (One set -- round 5 -- left every block of a wave waiting a whole
@@ -575,7 +581,8 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                             for (int i = 0; i < nblk; ++i) L.brow[fb + i] = lane;
                             const int rho = L.brow[min(lane, MAXB - 1)];
                             const int xs = __builtin_amdgcn_ds_bpermute(4 * rho, lo) + 16 * (lane - __builtin_amdgcn_ds_bpermute(4 * rho, fb));
-                            boff = lane < nb ? ((yb + rho + dist::RING) * Wp + xs + dist::RING) * 16 : OOB;
+                            // (xs + RING is a multiple of 4: the block starts at a texel group)
+                            boff = lane < nb ? ((yb + rho + dist::RING) * (Wp / dist::GROUP) + (xs + dist::RING) / dist::GROUP) * GB : OOB;
                         }
                         // (the tail chunk: planes high | low | high again | specials = the tail's planes 0, 1, 0, 2 for K slices 0 .. 3)
                         auto fetch = [&](int set, int i, int soff) {   // chunk i: planes 4 i .. 4 i + 3 (the lane's: + kq, in voffA)
@@ -592,10 +599,11 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                         const int q = (nb + 3) >> 2, b0 = wave * q, b1 = min(nb, b0 + q);
                         if (DIST_XPRIO) __builtin_amdgcn_s_setprio(DIST_XPRIO);
                         if (go) {
-#if DIST_Q_LAST
 #pragma unroll
                             for (int u = 0; u < NS; ++u)
                                 if (b0 + u < b1) fetch_block(u, __builtin_amdgcn_readlane(boff, b0 + u));
+                            // (the first blocks' operand loads go in front of the Q records', which are needed behind the pass's second barrier only:
+                            // -0.8 % headline, -2.5 % config 5)
                             // the Q records of the pass's cells, from memory straight to LDS: blocks 4 g .. 4 g + 3 per instruction
                             // (lane = (block, texel)); wave w moves groups w and w + 4
 #pragma unroll
@@ -603,26 +611,10 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                                 const int g = wave + 4 * gq;
                                 if (4 * g < nb) {   // uniform
                                     const int bo = __builtin_amdgcn_ds_bpermute(4 * (4 * g + kq), boff);
-                                    const int vq = 4 * g + kq < nb ? bo + n * 16 : OOB;
+                                    const int vq = 4 * g + kq < nb ? bo + ntex : OOB;
                                     dma_b128(rsrc, lds_addr_of(&L.Qs[g * 256]), vq, QPL * PB);
                                 }
                             }
-#else
-                            // the Q records of the pass's cells, from memory straight to LDS: blocks 4 g .. 4 g + 3 per instruction
-                            // (lane = (block, texel)); wave w moves groups w and w + 4
-#pragma unroll
-                            for (int gq = 0; gq < (MAXB + 15) / 16; ++gq) {
-                                const int g = wave + 4 * gq;
-                                if (4 * g < nb) {   // uniform
-                                    const int bo = __builtin_amdgcn_ds_bpermute(4 * (4 * g + kq), boff);
-                                    const int vq = 4 * g + kq < nb ? bo + n * 16 : OOB;
-                                    dma_b128(rsrc, lds_addr_of(&L.Qs[g * 256]), vq, QPL * PB);
-                                }
-                            }
-#pragma unroll
-                            for (int u = 0; u < NS; ++u)
-                                if (b0 + u < b1) fetch_block(u, __builtin_amdgcn_readlane(boff, b0 + u));
-#endif
                         }
                         // the slots of this thread's cells (under the first blocks' loads)
 #pragma unroll
@@ -727,7 +719,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 const int b = opaque_s((state >> 2) - 1);   // (the batch item in work)
                 const v4f c0 = *reinterpret_cast<const v4f*>(&L.cst[0]), c1 = *reinterpret_cast<const v4f*>(&L.cst[4]);
                 const bool ovf = (L.iflag & 1) != 0;
-                const int PB = (int)dist::plane_bytes(H, W), Wp = dist::wp(W);
+                (void)0;
 #pragma unroll 1
                 for (int vh = 0; vh < V * NH; ++vh) {
                     if (!(failmask >> vh & 1u)) continue;
@@ -754,18 +746,21 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                             const int cxx = cell_x(cellj), cyy = cell_y(cellj);
                             const float ex = 1.0f - fwj, ey = 1.0f - fnj;
                             const float w00 = ey * ex, w01 = ey * fwj, w10 = fnj * ex, w11 = fnj * fwj;
-                            const size_t t00 = ((size_t)(cyy + dist::RING) * Wp + cxx + dist::RING) * 16;
+                            // (the four taps' texels: neighbours in a row may lie in two texel groups)
+                            const long long t00 = dist::texel_offset(C, H, W, 0, cyy + dist::RING, cxx + dist::RING), t01 = dist::texel_offset(C, H, W, 0, cyy + dist::RING, cxx + dist::RING + 1);
+                            const long long t10 = dist::texel_offset(C, H, W, 0, cyy + dist::RING + 1, cxx + dist::RING), t11 = dist::texel_offset(C, H, W, 0, cyy + dist::RING + 1, cxx + dist::RING + 1);
+                            const long long pstep = dist::texel_offset(C, H, W, 1, 0, 0);   // from a plane to the next
                             float part = 0.0f;
 #pragma unroll DIST_DIRECT_UNROLL
                             for (int g = 0; g < 4 * NCHK + 1; ++g) {
                                 // planes of the group's high and low parts; the pixel's: chunk g >> 2 (tail: 2 NCHK), K slice g & 3 (tail: 0 | 2)
                                 const bool tail = g == 4 * NCHK;
-                                const char* ph = srcv + (size_t)(tail ? 8 * NCHK : g) * PB + t00;
-                                const char* pl = srcv + (size_t)(tail ? 8 * NCHK + 1 : 4 * NCHK + g) * PB + t00;
-                                const h8 a00 = *reinterpret_cast<const h8*>(ph), a01 = *reinterpret_cast<const h8*>(ph + 16);
-                                const h8 a10 = *reinterpret_cast<const h8*>(ph + (size_t)Wp * 16), a11 = *reinterpret_cast<const h8*>(ph + (size_t)Wp * 16 + 16);
-                                const h8 l00 = *reinterpret_cast<const h8*>(pl), l01 = *reinterpret_cast<const h8*>(pl + 16);
-                                const h8 l10 = *reinterpret_cast<const h8*>(pl + (size_t)Wp * 16), l11 = *reinterpret_cast<const h8*>(pl + (size_t)Wp * 16 + 16);
+                                const char* ph = srcv + (tail ? 8 * NCHK : g) * pstep;
+                                const char* pl = srcv + (tail ? 8 * NCHK + 1 : 4 * NCHK + g) * pstep;
+                                const h8 a00 = *reinterpret_cast<const h8*>(ph + t00), a01 = *reinterpret_cast<const h8*>(ph + t01);
+                                const h8 a10 = *reinterpret_cast<const h8*>(ph + t10), a11 = *reinterpret_cast<const h8*>(ph + t11);
+                                const h8 l00 = *reinterpret_cast<const h8*>(pl + t00), l01 = *reinterpret_cast<const h8*>(pl + t01);
+                                const h8 l10 = *reinterpret_cast<const h8*>(pl + t10), l11 = *reinterpret_cast<const h8*>(pl + t11);
                                 const h8 rh = *reinterpret_cast<const h8*>(&L.Bs[(((tail ? 2 * NCHK : (g >> 2)) * 4 + (tail ? 0 : (g & 3))) * 16 + n) * 8]);
                                 const h8 rl = *reinterpret_cast<const h8*>(&L.Bs[(((tail ? 2 * NCHK : NCHK + (g >> 2)) * 4 + (tail ? 2 : (g & 3))) * 16 + n) * 8]);
 #pragma unroll

@@ -25,9 +25,6 @@
 #ifndef DIST_YSKEW
 #define DIST_YSKEW 0       // floats by which the Y rows of pixels 8 .. 15 are shifted (a multiple of 4; 8 = a quarter of the banks)
 #endif
-#ifndef DIST_Q_LAST
-#define DIST_Q_LAST 1      // 1: the first blocks' operand loads are issued in front of the Q records' (needed behind the pass's second barrier only): -0.8 % headline, -2.5 % config 5
-#endif
 #ifndef DIST_XPRIO
 #define DIST_XPRIO 1       // wave priority in the matrix phase
 #endif

@@ -169,3 +169,22 @@ def test_header_says_what_the_code_does():
     for needed in ("v_mfma_f32_16x16x32_f16", "320 bytes per texel", "PDEPTH_LAYOUT_DIST16", "never a clamped number", "ONE launch"):
         assert needed in h, needed
     assert "#define PDEPTH_ABI_VERSION 6" in h
+
+
+def test_workspace_size_is_the_one_the_header_states():
+    """include/pdepth.h gives the workspace of a sweep as a formula (the packed views in the larger of the two layouts, one
+    ints per 16x4 tile + the counters, 496 floats of statistics per batch item): the library's answer is that, up to the
+    256-byte roundings of its parts."""
+    lib = _native.load()
+    h = open(os.path.join(REPO, "include", "pdepth.h")).read()
+    assert "rounded up to a multiple of 8" in h and "texel-group-major" in h
+    for B, V, C, D, H, W in ((4, 1, 67, 64, 256, 512), (2, 4, 67, 128, 512, 1024), (1, 2, 22, 48, 37, 53), (3, 1, 8, 16, 20, 31), (1, 1, 40, 64, 64, 128)):
+        desc = _native.SweepDesc(B, V, C, D, H, W, 0, 0, 0, 10.0, C * H * W, V * C * H * W, C * H * W)
+        got = lib.pdepth_sweep_workspace_bytes(ctypes.byref(desc))
+        nchk = 0 if C <= 8 else (1 if C <= 40 else 2)
+        wp = (W + 2 + 7) // 8 * 8
+        packed = max(B * V * (8 * nchk + 4) * (H + 2) * wp * 16 + 256 * B * V, B * V * ((C + 3) // 4 + 2) * H * W * 16)
+        flags = 4 * (2 * B * ((H + 3) // 4) * ((W + 15) // 16) + 64)
+        stats = 496 * 4 * B
+        want = packed + flags + stats
+        assert want <= got <= want + 4 * 256, (B, V, C, D, H, W, got, want)
