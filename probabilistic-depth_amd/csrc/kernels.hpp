@@ -44,7 +44,7 @@ constexpr int CORR_PACK_TIMEOUT_SLOT = 55;   // ... workgroups that gave up wait
 // channel statistics of the source (workspace tail, sweep_pack.hip): per batch item mu[c] at +0, var[c] at +STATS_VAR, the
 // squared offset that was NOT subtracted at +STATS_OFF, the largest sampled |x| at +STATS_AMAX, half the mean squared
 // difference of samples STATS_LAG_PX texels apart at +STATS_LAG (the spread of a channel at the distance of a plane sweep:
-// equal to var[c] for white features, smaller for smooth ones), and STATS_NFLAG ints at +STATS_FLAGS: [0] != 0 = a feature
+// equal to var[c] for white features, smaller for smooth ones), and STATS_NFLAG ints at +STATS_FLAGS: [1] != 0 = the item was left to the gather kernel (sweep_dist.hip: routing); [0] != 0 = a feature
 // of the item did not fit the fp16 range of the distance-form layout (pack_dist.hip)
 constexpr int STATS_VAR = 80, STATS_OFF = 160, STATS_AMAX = 240, STATS_LAG = 320, STATS_FLAGS = 400, STATS_NFLAG = 16, STATS_READY = 416, STATS_STRIDE = 496;
 // STATS_READY: one int per channel = the tag of the launch whose statistics the row holds (pack_dist.hip: the pack kernel computes the
@@ -86,7 +86,9 @@ hipError_t launch_sweep_direct(const SweepArgs& a, hipStream_t stream);
 // every writer of a gather flag increments it, the gather kernel's blocks leave at once while it is zero.
 constexpr int GATHER_COUNT_SLOT = 48;
 hipError_t launch_sweep_direct_flagged(const SweepArgs& a, const int* tile_flags, const int* gather_count, int tiles_x,
-                                       int tiles, hipStream_t stream, int flag_value = 1);  // runs the tiles whose flag == flag_value
+                                       int tiles, hipStream_t stream, int flag_value = 1);
+// ... the whole batch items b with item_flags[b * item_stride] != 0 (the distance-form kernel's routed items: STATS_FLAGS + 1)
+hipError_t launch_sweep_direct_items(const SweepArgs& a, const int* item_flags, int item_stride, hipStream_t stream);  // runs the tiles whose flag == flag_value
 int sweep_direct_max_planes(int C);
 
 // sweep_tiled.hip

@@ -24,9 +24,13 @@ namespace pdepth {
 template <int METRIC, int CCH, bool MULTI_CHUNK, bool PACKED = false>
 __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int* __restrict__ tile_flags,
                                                           const int* __restrict__ gather_count, int tiles_x, int tiles,
-                                                          int flag_value) {
+                                                          int flag_value, int item_stride) {
     // the usual case -- no tile was handed over -- costs one scalar load per block
     if (gather_count && *gather_count == 0) return;
+    // per-ITEM mode (item_stride != 0: the distance-form kernel's routing, sweep_dist.hip): tile_flags[b * item_stride] != 0 = this
+    // batch item is this kernel's, whole; the blocks stride over its groups of 64 pixels
+    const bool per_item = item_stride != 0;
+    if (per_item && tile_flags[(size_t)blockIdx.y * item_stride] == 0) return;
     extern __shared__ float lds[];
     const int tid = threadIdx.x;
     const int HW = a.H * a.W;
@@ -36,14 +40,14 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int
     for (int tile = blockIdx.x; tile < (tile_flags ? tiles : (int)gridDim.x); tile += gridDim.x) {
     int pix;
     bool live;
-    if (tile_flags) {
+    if (tile_flags && !per_item) {
         if (tile_flags[b * tiles + tile] != flag_value) continue;  // block-uniform
         const int x = (tile % tiles_x) * 16 + (tid & 15);
         const int y = (tile / tiles_x) * 4 + (tid >> 4);
         live = x < a.W && y < a.H;
         pix = y * a.W + x;
     } else {
-        pix = blockIdx.x * 64 + tid;
+        pix = tile * 64 + tid;
         live = pix < HW;
     }
     const int p = live ? pix : HW - 1;  // dead lanes shadow the last pixel, never store
@@ -169,9 +173,10 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int
 
 template <int METRIC>
 static hipError_t launch_metric(const SweepArgs& a, const int* tile_flags, const int* gather_count, int tiles_x, int tiles,
-                                hipStream_t stream, int flag_value = 1) {
+                                hipStream_t stream, int flag_value = 1, int item_stride = 0) {
     const int HW = a.H * a.W;
-    dim3 grid(tile_flags ? (tiles < 256 ? tiles : 256) : (HW + 63) / 64, a.B);
+    if (item_stride) tiles = (HW + 63) / 64;
+    dim3 grid(item_stride ? (tiles < 1024 ? tiles : 1024) : tile_flags ? (tiles < 256 ? tiles : 256) : (HW + 63) / 64, a.B);
     // no NCHW source (packed-source entry): the taps come from the packed copy
     const bool packed = a.src == nullptr;
     if (packed && a.packed_src == nullptr) return hipErrorInvalidValue;
@@ -180,7 +185,7 @@ static hipError_t launch_metric(const SweepArgs& a, const int* tile_flags, const
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, a, tile_flags, gather_count, tiles_x, tiles, flag_value);
+        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, a, tile_flags, gather_count, tiles_x, tiles, flag_value, item_stride);
         return hipGetLastError();
     };
     if (a.C <= 68) {
@@ -200,6 +205,12 @@ hipError_t launch_sweep_direct_flagged(const SweepArgs& a, const int* tile_flags
                                        int tiles, hipStream_t stream, int flag_value) {
     return a.metric == 0 ? launch_metric<0>(a, tile_flags, gather_count, tiles_x, tiles, stream, flag_value)
                          : launch_metric<1>(a, tile_flags, gather_count, tiles_x, tiles, stream, flag_value);
+}
+
+// the batch items with item_flags[b * item_stride] != 0, whole (the other items' blocks leave at once)
+hipError_t launch_sweep_direct_items(const SweepArgs& a, const int* item_flags, int item_stride, hipStream_t stream) {
+    return a.metric == 0 ? launch_metric<0>(a, item_flags, nullptr, 0, 0, stream, 1, item_stride)
+                         : launch_metric<1>(a, item_flags, nullptr, 0, 0, stream, 1, item_stride);
 }
 
 // Largest D the direct kernel can hold in LDS (two arrays in the chunked variant, three from 256 channels on).

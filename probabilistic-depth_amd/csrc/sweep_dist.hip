@@ -325,19 +325,27 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 const float* st = KARG(const float*, stats) + (size_t)b * STATS_STRIDE;
                 if (wave == 0) {
                     // the scale (dist_layout.hpp: the same function of the same numbers as in the pack kernel) and the guard
-                    float am = st[STATS_AMAX + lane], sv = st[STATS_VAR + lane], sl_ = st[STATS_LAG + lane];
+                    float am = st[STATS_AMAX + lane], sv = st[STATS_VAR + lane], sl_ = st[STATS_LAG + lane], m2 = st[lane] * st[lane];
                     if (lane + 64 < STATS_VAR) {
                         am = fmaxf(am, st[STATS_AMAX + lane + 64]); sv += st[STATS_VAR + lane + 64]; sl_ += st[STATS_LAG + lane + 64];
+                        m2 += st[lane + 64] * st[lane + 64];
                     }
+                    // (the largest and the smallest |depth candidate|: L.dcl repeats the last one beyond D)
+                    float dhi = fabsf(L.dcl[lane]), dlo = -dhi;
+                    if (NH == 2) { const float d2 = fabsf(L.dcl[lane + 64]); dhi = fmaxf(dhi, d2); dlo = fmaxf(dlo, -d2); }
                         // (xor shuffles whose lane arithmetic is part of the instruction -- ds_swizzle -- or hangs on the opaque lane
                     //  above: __shfl_xor's own, hoisted out of the item loop, was a spilled register of the kernel)
                     {
                         const int x32 = (lane ^ 32) << 2;
-                        am = fmaxf(am, bperm_f(x32, am)); sv += bperm_f(x32, sv); sl_ += bperm_f(x32, sl_);
+                        am = fmaxf(am, bperm_f(x32, am)); sv += bperm_f(x32, sv); sl_ += bperm_f(x32, sl_); m2 += bperm_f(x32, m2);
+                        dhi = fmaxf(dhi, bperm_f(x32, dhi)); dlo = fmaxf(dlo, bperm_f(x32, dlo));
 #define PDEPTH_XOR_STEP(M) { const int pat = ((M) << 10) | 0x1f; \
                              am = fmaxf(am, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, am), pat))); \
                              sv += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sv), pat)); \
-                             sl_ += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sl_), pat)); }
+                             sl_ += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, sl_), pat)); \
+                             m2 += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, m2), pat)); \
+                             dhi = fmaxf(dhi, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, dhi), pat))); \
+                             dlo = fmaxf(dlo, __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, dlo), pat))); }
                         PDEPTH_XOR_STEP(16) PDEPTH_XOR_STEP(8) PDEPTH_XOR_STEP(4) PDEPTH_XOR_STEP(2) PDEPTH_XOR_STEP(1)
 #undef PDEPTH_XOR_STEP
                     }
@@ -352,10 +360,18 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                     // (unit-variance features: 67; features whose energy is all spread gain nothing from the direct form).
                     const float sg = KARG(float, a.sigma);
                     const bool outside = sv > DIST_GUARD_RATIO * sl_ && sv * 10.0f > DIST_GUARD_ENERGY * fabsf(sg);
+                    // Conditioning.  Whatever the form, an fp32 cost carries 2^-23 of its own size, and the expected depth moves by
+                    // up to the candidates' range times that: where V (2 sum var + |mu|^2) / sigma -- the cost of a sample, inside
+                    // the image and outside it -- times the range times 2^-23 exceeds DIST_COND_LIMIT, two fp32 evaluations agree
+                    // to 1e-4 m only if they round alike (the float32 reference itself is then up to 3e-4 m from the exact value:
+                    // tests/test_soak_regressions.py).  Headline workload: 5.6e-5, config 5: 2.2e-4; the six soak cases: 5.8e-4
+                    // .. 3.5e-3.  Such an item is left to the gather kernel, which rounds like the reference -- where the caller
+                    // gave the NCHW source (below); a packed source has nothing to fall back to and takes the fast form.
+                    const bool illcond = (float)KARG(int, a.V) * (2.0f * sv + m2) * (dhi + dlo) * 1.1920929e-7f > DIST_COND_LIMIT * fabsf(sg);
                     if (lane == 0) {
                         L.cst[6] = sc; L.cst[7] = ldexpf(refined_rcp(sg), -2 * e);
                         const int pf = reinterpret_cast<const int*>(st + STATS_FLAGS)[0];
-                        L.iflag = (pf != 0 ? 1 : 0) | (outside ? 2 : 0);
+                        L.iflag = (pf != 0 ? 1 : 0) | (outside ? 2 : 0) | (illcond ? 4 : 0);
                     }
                     for (int c = lane; c < dist::MAX_C + 8; c += 64) L.mus[c] = st[c] * sc;
                 }
@@ -377,6 +393,21 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 }
             }
             bool item_ready = !new_b;
+            // Routing (NCHW entry: the raw source is at hand): an item the guard or the conditioning flags is the gather kernel's,
+            // launched behind this one for the items marked here (capi.hip); its pixel blocks are skipped.
+            if (KARG(const float*, a.src) != nullptr) {
+                if (!item_ready) { PDEPTH_LDS_BARRIER(); item_ready = true; }
+                if ((__builtin_amdgcn_readfirstlane(L.iflag) & 7) != 0) {   // uniform (overflow of the fp16 range, guard, conditioning)
+                    if (opaque_v((int)threadIdx.x) == 0) {
+                        reinterpret_cast<int*>(const_cast<float*>(KARG(const float*, stats)) + (size_t)b * STATS_STRIDE + STATS_FLAGS)[1] = 1;
+                        ++n_direct;
+                    }
+                    resolve_next();
+                    publish_next();
+                    PDEPTH_LDS_BARRIER();
+                    continue;
+                }
+            }
             float rr = 0.0f, zc = 0.0f;    // |r'|^2 and |r|^2 of the pixel, scaled (set with the first pass)
             bool centred = false;
             unsigned failmask = 0;         // uniform over the workgroup: passes (view v, plane group h) left to the direct evaluation
@@ -549,7 +580,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                         }
                     }
                     const int iflag = __builtin_amdgcn_readfirstlane(L.iflag);
-                    if (iflag != 0) fits = false;   // (the item is evaluated directly)
+                    if ((iflag & 3) != 0) fits = false;   // (the item is evaluated directly; an ill-conditioned one -- bit 2 -- on a packed source is not: nothing to gain)
                     if (DIST_FORCE_DIRECT == -1 || DIST_FORCE_DIRECT == v) fits = false;   // (test builds)
                     state ^= 2;
                     const int rowoff = 16 * fb - lo;    // slot of texel x of this lane's row = x + rowoff
@@ -951,14 +982,18 @@ hipError_t launch_sweep_dist(const SweepArgs& a, void* workspace, hipStream_t st
         if (e != hipSuccess) return e;
     }
     const int nck = dist::nchk(a.C);
-    if (a.D <= 64) {
-        if (nck == 0) return launch_inst<0, 1>(a, packed, stats, queue, tiles_x, tiles, stream);
-        if (nck == 1) return launch_inst<1, 1>(a, packed, stats, queue, tiles_x, tiles, stream);
-        return launch_inst<2, 1>(a, packed, stats, queue, tiles_x, tiles, stream);
-    }
-    if (nck == 0) return launch_inst<0, 2>(a, packed, stats, queue, tiles_x, tiles, stream);
-    if (nck == 1) return launch_inst<1, 2>(a, packed, stats, queue, tiles_x, tiles, stream);
-    return launch_inst<2, 2>(a, packed, stats, queue, tiles_x, tiles, stream);
+    hipError_t e;
+    if (a.D <= 64)
+        e = nck == 0 ? launch_inst<0, 1>(a, packed, stats, queue, tiles_x, tiles, stream)
+                     : (nck == 1 ? launch_inst<1, 1>(a, packed, stats, queue, tiles_x, tiles, stream) : launch_inst<2, 1>(a, packed, stats, queue, tiles_x, tiles, stream));
+    else
+        e = nck == 0 ? launch_inst<0, 2>(a, packed, stats, queue, tiles_x, tiles, stream)
+                     : (nck == 1 ? launch_inst<1, 2>(a, packed, stats, queue, tiles_x, tiles, stream) : launch_inst<2, 2>(a, packed, stats, queue, tiles_x, tiles, stream));
+    if (e != hipSuccess || a.src == nullptr) return e;
+    // NCHW entry: the items the kernel left alone (fp16 overflow, guard, conditioning: flag 1 of their statistics row) are
+    // evaluated by the gather kernel on the caller's tensor, in the reference's own rounding; on the usual input every block
+    // of this launch reads one flag and leaves
+    return launch_sweep_direct_items(a, reinterpret_cast<const int*>(stats + STATS_FLAGS) + 1, STATS_STRIDE, stream);
 }
 
 }  // namespace pdepth

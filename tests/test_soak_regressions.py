@@ -14,8 +14,8 @@ What round 5 found (profiles/r05_soak_summary.txt):
     3.5e-5 m on all six cases -- asserted below at the north star's 1e-4 m, unscaled, also where candidates reach 60 m.
   * the float32 oracle is itself up to 3.2e-4 m from the exact value on these inputs (soak51 case 12: 68 pixels beyond
     1e-4 m): the depth is ill-conditioned there, and within 1e-4 m of the reference means rounding like the reference.
-    `auto` is held to: cost no noisier than the reference's own (tests/util.py: NOISE_MAX / NOISE_RMS), depth within
-    1e-4 m plus what the measured cost errors of the two volumes explain at that pixel (noise_and_explained()).
+    Round 5 held `auto` to "no noisier than the reference + explained" here; since round 6 the default kernel measures the
+    conditioning of an item itself and hands such items to the gather kernel (NCHW entry): `auto` is held to the plain 1e-4 m.
 The measured numbers are written to gpurun_out/soak_regressions.json (tools/soak_summary.py formats them)."""
 import importlib.util
 import json
@@ -26,8 +26,8 @@ import pytest
 import torch
 
 import pdepth_amd  # noqa: F401
-from pdepth_amd import ops
-from util import DEPTH_ATOL, NOISE_MAX, NOISE_RMS, exact_batch, noise_and_explained, oracle_batch, to_dev
+from pdepth_amd import _native, ops
+from util import DEPTH_ATOL, exact_batch, noise_and_explained, oracle_batch, to_dev
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -85,6 +85,8 @@ def test_soak_worst_case_against_the_whole_image_oracle(dev, soak, log, seed, sp
     for algo in ("auto", "direct"):
         cost, _, depth = ops.sweep_dpv(*args, feat_dist="L2", algo=algo, want_cost=True)
         cost, depth = cost.cpu(), depth.cpu()
+        if algo == "auto":
+            row["auto_blocks_off_the_fast_path"] = _native.fallback_tiles(shape["B"], shape["H"], shape["W"])
         assert torch.equal(torch.isfinite(depth), fin), f"{algo}: finiteness of the depth differs from the oracle"
         e = (depth - odepth)[fin].abs()
         res[algo] = dict(max_m=float(e.max()) if e.numel() else 0.0, p999_m=float(torch.quantile(e.double(), 0.999)) if e.numel() else 0.0,
@@ -94,7 +96,8 @@ def test_soak_worst_case_against_the_whole_image_oracle(dev, soak, log, seed, sp
     tag = f"{log} case {case} {shape}"
     # the gather kernel rounds like the reference: the north star as it stands
     assert res["direct"]["max_m"] <= DEPTH_ATOL, f"{tag}: direct is {res['direct']['max_m']:.3e} m from the whole-image oracle"
-    # the default kernel: no noisier than the reference, and its depth differs by what the cost noise explains
+    # the default kernel (NCHW entry): these items are ill-conditioned by its own measure (csrc/sweep_dist.hip: "Conditioning") and
+    # go to the gather kernel -- the north star as it stands, for every selector
     a = res["auto"]
-    assert a["noise_max_ratio"] <= NOISE_MAX and a["noise_rms_ratio"] <= NOISE_RMS, f"{tag}: auto's cost noise {a}"
-    assert a["unexplained_m"] == 0.0, f"{tag}: auto's depth differs from the oracle by {a['unexplained_m']:.3e} m more than the cost noise explains"
+    assert a["max_m"] <= DEPTH_ATOL, f"{tag}: auto is {a['max_m']:.3e} m from the whole-image oracle"
+    assert row["auto_blocks_off_the_fast_path"] > 0, f"{tag}: not routed"
