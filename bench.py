@@ -190,7 +190,8 @@ def main():
         pass
     # SURVEY 8(d), "Ambiguity resolved": the 64x128 model-real number is always reported next to the 256x512 one, and both the
     # N(0,1) and the peaked feature variants.  GPU time per call from HIP events over 50 back-to-back calls (the launch gaps of
-    # the call are inside); launches per call: NCHW entry = statistics + pack + sweep, packed entry = the sweep.
+    # the call are inside); launches per call: NCHW entry = statistics + pack + sweep + the gather kernel for routed items (its
+    # blocks leave at once when none is), packed entry = the sweep.
     secondary = {}
     if not a.no_secondary and a.algo in ("auto", "dist", "corr") and rank == 0 and not a.config:
         def small(Bs, entry):
@@ -213,7 +214,7 @@ def main():
                 us = min(us, e0.elapsed_time(e1) / 50 * 1e3)
                 wall_us = min(wall_us, (time.perf_counter() - t0) / 50 * 1e6)
             by = algorithmic_bytes_per_volume(cfg["C"], cfg["V"], cfg["D"], 64, 128) * Bs
-            return {"us_per_call": us, "wall_us_per_call": wall_us, "launches": 1 if entry == "packed" else 3,
+            return {"us_per_call": us, "wall_us_per_call": wall_us, "launches": 1 if entry == "packed" else 4,
                     "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "volumes_per_s": Bs / (us * 1e-6)}
         try:
             secondary["model_real"] = {"shape": "C=%d D=%d 64x128 V=%d pose=%s (the reference sweeps a 256x512 frame at 1/4 resolution: "
@@ -274,8 +275,12 @@ def main():
     # reference's op order) on the same batch.
     workloads = {}
     if not a.no_workloads and not a.no_secondary and a.algo in ("auto", "dist") and rank == 0 and not a.config:
-        def shard(name, Bs, D, H, W, V, pose, steps):
+        def shard(name, Bs, D, H, W, V, pose, steps, offset=0.0):
             bs = synth.make_batch(2, Bs, C=cfg["C"], D=D, H=H, W=W, V=V, pose=pose)
+            if offset:   # per-channel offsets, the same in every view: costs of hundreds where a tap leaves the image
+                mu = (torch.rand(cfg["C"], generator=torch.Generator().manual_seed(5)) * 2 - 1) * offset
+                bs["ref"] += mu[None, :, None, None]
+                bs["src"] += mu[None, None, :, None, None]
             ds = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in bs.items()}
             dcs = ops.d_candi_tensor(ds["d_candi"], dev)
             f = lambda algo: ops.sweep_dpv(ds["ref"], ds["src"], ds["K"], ds["R"], ds["t"], ds["rays"], ds["cxcy"], dcs, sigma, algo=algo)
@@ -302,6 +307,11 @@ def main():
                                             4, 64, 256, 512, 1, "stereo", a.steps)
             workloads["cfg5_share"] = shard("BASELINE configs[4] at one GPU's share: D=128, 512x1024, 4 source views, B=2 (of 16 over 8 GPUs)",
                                             2, 128, 512, 1024, 4, "mono", max(3, a.steps // 4))
+            # the perf cliff of the default selector, in the open: features whose channel means are 6 sigma off zero make an
+            # item ill-conditioned by the kernel's measure (csrc/sweep_dist.hip: "Conditioning"); every item is then the gather kernel's
+            workloads["cfg2_routed"] = shard("the headline shape with per-channel offsets of up to 6 sigma: every item routed to the gather kernel "
+                                             "(direct_passes = pixel blocks routed)", hi - lo, cfg["D"], cfg["H"], cfg["W"], cfg["V"], a.pose,
+                                             max(3, a.steps // 4), offset=6.0)
         except RuntimeError as e:
             workloads["error"] = str(e)
     depth = out[2]

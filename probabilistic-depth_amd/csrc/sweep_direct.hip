@@ -171,12 +171,18 @@ __global__ __launch_bounds__(64) void sweep_direct_kernel(SweepArgs a, const int
     }  // tiles
 }
 
+// per-item mode: blocks per batch item (each leaves after one flag read where its item is not routed: the usual case, paid by
+// every NCHW call of the default kernel)
+#ifndef PDEPTH_ROUTE_GRID
+#define PDEPTH_ROUTE_GRID 2048
+#endif
+
 template <int METRIC>
 static hipError_t launch_metric(const SweepArgs& a, const int* tile_flags, const int* gather_count, int tiles_x, int tiles,
                                 hipStream_t stream, int flag_value = 1, int item_stride = 0) {
     const int HW = a.H * a.W;
     if (item_stride) tiles = (HW + 63) / 64;
-    dim3 grid(item_stride ? (tiles < 1024 ? tiles : 1024) : tile_flags ? (tiles < 256 ? tiles : 256) : (HW + 63) / 64, a.B);
+    dim3 grid(item_stride ? (tiles < PDEPTH_ROUTE_GRID ? tiles : PDEPTH_ROUTE_GRID) : tile_flags ? (tiles < 256 ? tiles : 256) : (HW + 63) / 64, a.B);
     // no NCHW source (packed-source entry): the taps come from the packed copy
     const bool packed = a.src == nullptr;
     if (packed && a.packed_src == nullptr) return hipErrorInvalidValue;

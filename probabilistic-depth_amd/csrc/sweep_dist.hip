@@ -398,9 +398,12 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
             if (KARG(const float*, a.src) != nullptr) {
                 if (!item_ready) { PDEPTH_LDS_BARRIER(); item_ready = true; }
                 if ((__builtin_amdgcn_readfirstlane(L.iflag) & 7) != 0) {   // uniform (overflow of the fp16 range, guard, conditioning)
-                    if (opaque_v((int)threadIdx.x) == 0) {
+                    // (the item's first block marks it and counts ALL its blocks for the diagnostics: the count is merged into
+                    //  the workspace by a compare-and-swap chain per workgroup at the end of the kernel -- one per pixel block was
+                    //  0.9 ms of serialised atomics on a routed launch)
+                    if (opaque_v((int)threadIdx.x) == 0 && tx == 0 && ty == 0 && sub == 0) {
                         reinterpret_cast<int*>(const_cast<float*>(KARG(const float*, stats)) + (size_t)b * STATS_STRIDE + STATS_FLAGS)[1] = 1;
-                        ++n_direct;
+                        n_direct += KARG(int, tiles_x) * (wide ? H : 2 * ((H + 1) >> 1));
                     }
                     resolve_next();
                     publish_next();

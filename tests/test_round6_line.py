@@ -19,9 +19,12 @@ def test_committed_bench_line_of_round_6():
         assert row["max_abs_depth_diff_vs_gather"] <= 1.5e-4, key      # (two GPU kernels against each other)
     assert "configs[2]" in w["cfg3_shard"]["workload"] and "configs[4]" in w["cfg5_share"]["workload"]
     assert w["cfg5_share"]["ms_per_call"] / w["cfg5_share"]["B"] < 2.3
+    # the routed workload: every pixel block of every item left to the gather kernel, whose answer it then is
+    r = w["cfg2_routed"]
+    assert r["direct_passes"] == r["B"] * 256 * 512 // 16 and r["max_abs_depth_diff_vs_gather"] == 0.0 and r["ms_per_call"] > line["ms_per_step"]
     for key in ("B1_nchw", "B1_packed", "B4_nchw", "B4_packed"):
         row = line["model_real"][key]
-        assert row["us_per_call"] > 0 and row["launches"] in (1, 3) and 0 < row["frac"] < 1, key
+        assert row["us_per_call"] > 0 and row["launches"] in (1, 4) and 0 < row["frac"] < 1, key
     assert line["packed_entry"]["kernel_ms"] < 0.34 and line["packed_entry"]["max_abs_depth_diff_vs_headline"] <= 1e-4
     assert line["preflight"]["max_abs_depth_diff_vs_gather_kernel"] <= 1e-4
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["max_abs_depth_diff_gpu_vs_port_item0"] <= 1e-4

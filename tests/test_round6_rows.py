@@ -84,8 +84,9 @@ def test_a_source_view_unlike_view_zero(dev):
 
 def test_a_bright_row_the_statistics_do_not_sample(dev):
     """One row of the source at 1e6 where everything else is N(0, 1): the sampled maximum misses it, the pack finds it out of the
-    fp16 range.  Never a wrong number: the item comes out NaN from the default kernel (flag of the pack), correct from
-    `direct`; the other batch item is untouched."""
+    fp16 range.  Never a wrong number: on the NCHW entry the item goes to the gather kernel and comes out RIGHT (round 6 routing;
+    ADVICE r5: "evaluate the item in the fp32 reference form from a.src"), through a packed workspace -- no NCHW source to fall
+    back to -- it comes out NaN; the other batch item is untouched."""
     b = synth.make_batch(33, 2, C=67, D=32, H=64, W=128, V=1, pose="mono")
     rows = {0, 4, 12, 20, 28, 36, 44, 52, 60}   # (any row but the sampled ones: stats_row(i, 8, 64) = 4, 12, .., 60 -- and their pooled variants)
     row = next(r for r in range(1, 63) if r not in rows and r % 4 != 0)
@@ -93,9 +94,12 @@ def test_a_bright_row_the_statistics_do_not_sample(dev):
     ocost, _, odepth = oracle_batch(b)
     cost, _, depth = _run(b, dev, "auto")
     assert torch.isfinite(cost[0]).all() and float((depth[0] - odepth[0]).abs().max()) <= DEPTH_ATOL
-    loud = torch.isnan(cost[1]).all() and torch.isnan(depth[1]).all()
-    right = torch.isfinite(cost[1]).all() and np.allclose(cost[1].numpy(), ocost[1].numpy(), rtol=3e-5, atol=1e-2)
-    assert loud or right, "a feature beyond the fp16 range must be loud (NaN item) or right, never a clamped number"
+    np.testing.assert_allclose(cost[1].numpy(), ocost[1].numpy(), rtol=3e-5, atol=1e-2)
+    assert float((depth[1] - odepth[1]).abs().max()) <= DEPTH_ATOL
+    d = to_dev(b, dev)
+    packed = ops.pack_source(d["src"], 32, "auto")
+    pcost, _, pdepth = ops.sweep_dpv(d["ref"], packed, d["K"], d["R"], d["t"], d["rays"], d["cxcy"], d["d_candi"], 10.0, want_cost=True)
+    assert torch.isfinite(pcost[0]).all() and torch.isnan(pcost[1]).all() and torch.isnan(pdepth[1]).all()
     cost, _, depth = _run(b, dev, "direct")
     np.testing.assert_allclose(cost.numpy(), ocost.numpy(), rtol=3e-5, atol=1e-2)
 
@@ -126,6 +130,29 @@ def test_a_nan_candidate_plane(dev):
         assert torch.equal(torch.isnan(depth), torch.isnan(odepth)), algo
         fin = torch.isfinite(ocost)
         np.testing.assert_allclose(cost[fin].numpy(), ocost[fin].numpy(), rtol=COST_RTOL, atol=COST_ATOL, err_msg=algo)
+
+
+def test_routed_items_are_the_gather_kernels_bit_for_bit(dev):
+    """Round 6 routing (csrc/sweep_dist.hip: "Conditioning"): in a batch of three, item 1 carries per-channel offsets of 6 sigma
+    (costs of hundreds: ill-conditioned by the kernel's measure), items 0 and 2 are the usual N(0, 1).  The default selector gives
+    item 1 the gather kernel's answer bit for bit -- it IS the gather kernel's --, items 0 and 2 the fast form's (what they get in
+    a batch without item 1), and says so in its diagnostics.  Every item within the north star of the oracle."""
+    b = synth.make_batch(52, 3, C=67, D=64, H=48, W=96, V=2, pose="mono")
+    g = torch.Generator().manual_seed(9)
+    mu = (torch.rand(67, generator=g) * 2 - 1) * 6.0
+    b["ref"][1] += mu[:, None, None]
+    b["src"][1] += mu[None, :, None, None]
+    ocost, _, odepth = oracle_batch(b)
+    cost, logp, depth = _run(b, dev, "auto")
+    routed = _native.fallback_tiles(3, 48, 96)
+    dcost, dlogp, ddepth = _run(b, dev, "direct")
+    assert routed == 48 * 96 // 16, routed            # (every pixel block of item 1, none of the others)
+    assert torch.equal(cost[1], dcost[1]) and torch.equal(logp[1], dlogp[1]) and torch.equal(depth[1], ddepth[1])
+    assert not torch.equal(cost[0], dcost[0])         # (the fast form: another rounding)
+    two = {k: (v[[0, 2]] if isinstance(v, torch.Tensor) and v.shape[:1] == (3,) else v) for k, v in b.items()}
+    cost2, _, depth2 = _run(two, dev, "auto")
+    assert torch.equal(cost[[0, 2]], cost2) and torch.equal(depth[[0, 2]], depth2)
+    assert float((depth - odepth).abs().max()) <= DEPTH_ATOL
 
 
 def test_nchw_entry_is_capturable(dev):
