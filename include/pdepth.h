@@ -30,9 +30,16 @@
  *     vector code here too, the contraction over the channels is not (DESIGN.md section 1 says why).  A caller who
  *     wants the reference's own operation order end to end selects PDEPTH_ALGO_DIRECT.
  *   - values that are not numbers propagate as in the reference: a NaN / inf feature or depth candidate makes the costs
- *     it enters, and with them the pixel's log-DPV and depth, non-finite; a finite feature beyond the fp16 range of the
- *     default kernel's scaled layout (several thousand times the sampled maximum of its batch item) makes that item's
- *     outputs NaN -- never a clamped number.
+ *     it enters, and with them the pixel's log-DPV and depth, non-finite.  A finite feature beyond the fp16 range of the
+ *     default kernel's scaled layout (several thousand times the sampled maximum of its batch item): pdepth_sweep_dpv_f32
+ *     evaluates that batch item with the gather kernel on the NCHW tensor (right numbers), the packed entry -- which has
+ *     no NCHW tensor -- makes the item's outputs NaN: never a clamped number.
+ *   - routing (PDEPTH_ALGO_AUTO / _DIST through pdepth_sweep_cost_f32 / pdepth_sweep_dpv_f32): a batch item whose costs are
+ *     so large against the candidates' range that two fp32 evaluations agree to 1e-4 m only if they round alike
+ *     (V (2 sum_c var_c + |mu|^2) / sigma * (d_max - d_min) * 2^-23 > 4e-4; the headline workload: 5.6e-5), or whose
+ *     features carry trends the centring cannot remove, is evaluated by the gather kernel (the reference's operation
+ *     order, PDEPTH_ALGO_DIRECT's kernel) inside the same call: ONE more launch, whose blocks leave at once when no item
+ *     is flagged.  The packed entry evaluates every item in the distance form.
  */
 #ifndef PDEPTH_H_
 #define PDEPTH_H_

@@ -42,7 +42,8 @@ def record(path, pose, chosen, source, collected):
                 kernels[n][extra] = v[extra]
         if "sweep_direct" in n:
             # bench.py's one preflight run of the gather kernel (the cross-check in front of the timed region): not part of a step
-            kernels[n]["note"] = "bench.py's preflight run of the whole gather kernel; not part of a step, not in the totals"
+            kernels[n]["note"] = ("the mean over bench.py's ONE preflight run of the whole gather kernel (the cross-check, not part of a step) and the routed launch "
+                                  "of every NCHW call, whose blocks read one flag and leave (4 us, no traffic) when no item is routed: not in the totals")
             continue
         tot["hbm"] += (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0
         tot["valu"] += v.get("SQ_INSTS_VALU", 0.0)
@@ -58,7 +59,7 @@ if __name__ == "__main__":
     chosen = sys.argv[5] if len(sys.argv) > 5 else "dist"
     doc = {"correction": "gfx950: FETCH_SIZE x2 (calibrated in profiles/r01_fetch_size_calibration.txt), WRITE_SIZE exact; KB = 1024 B",
            "note": "one launch = one pdepth_sweep_dpv_f32 call (NCHW entry) = feature_stats_kernel + pack_dist_kernel (pre-pass: channel means and "
-                   "scale, centred fp16 hi/lo planes + squared neighbour differences) + sweep_dist_kernel. bench.py attaches a record only when its workload AND the kernel "
+                   "scale, centred fp16 hi/lo planes + squared neighbour differences) + sweep_dist_kernel + the gather kernel's launch for routed items (empty on this workload). bench.py attaches a record only when its workload AND the kernel "
                    "that ran match; 'collected' says on which commit and when the counters were taken (another box than any later bench run).",
            "workloads": [
                record(mono, "mono", chosen, "profiles/%s_auto_mono.rocprofv3.txt (tools/prof.sh: rocprofv3 --pmc passes of `python3 bench.py --steps 3 "
