@@ -13,7 +13,7 @@ import torch
 
 import pdepth_amd  # noqa: F401
 from pdepth_amd import _native, ops, synth
-from util import DEPTH_ATOL, assert_depth_parity, oracle_batch, to_dev
+from util import DEPTH_ATOL, oracle_batch, to_dev
 
 pytestmark = pytest.mark.gpu
 COST_ATOL, COST_RTOL = 2e-4, 2e-5
@@ -237,10 +237,11 @@ def test_extremes_of_the_default_kernel(dev):
             assert torch.equal(torch.isfinite(cost.cpu()), fin), (algo, c)
             # (the north-star bounds as they stand, whatever the number of views: no scaling with V)
             np.testing.assert_allclose(cost.cpu()[fin].numpy(), ocost[fin].numpy(), rtol=COST_RTOL, atol=COST_ATOL, err_msg=f"{algo} {c}")
-            # depth: 1e-4 m; the 8-view case (costs of 8 views x 72 channels with means of 4 sigma: ~600) sits at 1.1e-4 m at one
-            # pixel, where the float32 oracle itself is that far from the exact value (util.assert_depth_parity says how
-            # that is checked: no scaling of the bound with V)
-            assert_depth_parity(b, cost.cpu(), depth.cpu(), ocost, odepth, 10.0, (algo, c))
+            # depth: the plain 1e-4 m.  (The 8-view case -- costs of 8 views x 72 channels with means of 4 sigma: ~600 -- sat at
+            # 1.1e-4 m at one pixel in round 5, where the float32 oracle itself is that far from the exact value; the kernel now
+            # finds such an item ill-conditioned and hands it to the gather kernel: csrc/sweep_dist.hip, "Conditioning")
+            dfin = torch.isfinite(odepth)
+            assert float((depth.cpu() - odepth)[dfin].abs().max()) <= DEPTH_ATOL, (algo, c)
     for c in (dict(C=8, D=16, V=9), dict(C=73, D=16, V=1), dict(C=8, D=129, V=1)):
         b = synth.make_batch(400, 1, C=c["C"], D=c["D"], H=12, W=20, V=c["V"], pose="mono")
         ocost, ologp, odepth = oracle_batch(b)

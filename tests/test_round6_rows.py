@@ -12,7 +12,7 @@ import torch
 
 import pdepth_amd  # noqa: F401
 from pdepth_amd import _native, ops, synth
-from util import DEPTH_ATOL, assert_depth_parity, oracle_batch, to_dev
+from util import DEPTH_ATOL, oracle_batch, to_dev
 
 pytestmark = pytest.mark.gpu
 COST_ATOL, COST_RTOL = 2e-4, 2e-5
@@ -58,16 +58,12 @@ def test_reference_and_source_with_different_channel_means(dev, pose):
     g = torch.Generator().manual_seed(77)
     dmu = (torch.rand(67, generator=g) * 2 - 1) * 2.0
     b["ref"] = b["ref"] + dmu[None, :, None, None]
-    # (costs of ~50 per plane: the depth is ill-conditioned, the float32 reference itself is ~1e-4 m from the exact value of
-    #  its formula -- tests/util.py: assert_depth_parity holds the kernels to 1e-4 m plus what the measured cost noise explains)
+    # (costs of ~20 per plane; measured: auto 3.1e-5 / 4.4e-5 m, direct 2.3e-5 / 1.9e-5 m -- the plain north-star bound)
     ocost, _, odepth = oracle_batch(b)
     for algo in ("auto", "direct"):
         cost, _, depth = _run(b, dev, algo)
         np.testing.assert_allclose(cost.numpy(), ocost.numpy(), rtol=COST_RTOL, atol=COST_ATOL, err_msg=algo)
-        err = assert_depth_parity(b, cost, depth, ocost, odepth, who=algo)
-        assert err <= 5e-4, (algo, err)   # (hard cap: nothing hides behind the explained term)
-    cost, _, depth = _run(b, dev, "direct")
-    assert float((depth - odepth).abs().max()) <= DEPTH_ATOL
+        assert float((depth - odepth).abs().max()) <= DEPTH_ATOL, algo
 
 
 def test_a_source_view_unlike_view_zero(dev):

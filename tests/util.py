@@ -63,17 +63,17 @@ def exact_batch(batch, sigma=10.0):
     return tuple(torch.cat([o[i] for o in outs], dim=0) for i in range(3))
 
 
-# How a kernel that does NOT copy the reference's summation order is held to the reference where the depth is
+# (Diagnostics since round 6: no test relaxes the north-star bound any more -- the default kernel routes ill-conditioned items to
+#  the gather kernel, tests/test_soak_regressions.py asserts the plain 1e-4 m and records these figures next to it.)
+# How a kernel that does NOT copy the reference's summation order compares with the reference where the depth is
 # ill-conditioned (features with means of several sigma: costs of hundreds, float32 rounding noise of 1e-4 in them, and a
 # softmax that turns a unit of cost into up to (d_max - d_min) / 2 metres).  Measured on the soak's worst cases
 # (profiles/r05_soak_summary.txt): the float32 reference itself is up to 3.2e-4 m from the exact evaluation of its own
 # formula -- no implementation can be within 1e-4 m of it there unless it rounds like it.  So, with the exact volume X:
-#   noise:      max |cost - X| <= NOISE_MAX x max |oracle - X|  and  rms <= NOISE_RMS x rms of the oracle  (no noisier
-#               than the reference, up to the factor measured for the distance form: 2.2 / 1.5)
+#   noise:      max |cost - X| / max |oracle - X|  and  the ratio of the rms errors (measured for the distance form: 2.2 / 1.5)
 #   explained:  per pixel |depth - oracle depth| <= DEPTH_ATOL + kappa (max_k |cost - X| + max_k |oracle - X|): the
 #               north-star bound plus what the two cost volumes' own errors at that pixel account for, to first order --
 #               nothing is left for the softmax / expectation of the kernel to have added
-NOISE_MAX, NOISE_RMS = 3.0, 2.0
 
 
 def noise_and_explained(cost, depth, ocost, odepth, xcost, xkappa):
@@ -92,16 +92,3 @@ def noise_and_explained(cost, depth, ocost, odepth, xcost, xkappa):
     out["unexplained_m"] = float(over.max().clamp_min(0.0))
     out["kappa_max"] = float(xkappa[dfin].max()) if bool(dfin.any()) else 0.0
     return out
-
-
-def assert_depth_parity(batch, cost, depth, ocost, odepth, sigma=10.0, who=""):
-    """The north-star bound; where a pixel exceeds it, the case must be one where the float32 reference is itself that far
-    from the exact value of its formula, i.e. the excess is explained by the two cost volumes' measured rounding noise
-    (noise_and_explained()).  Returns the plain maximum difference."""
-    dfin = torch.isfinite(odepth)
-    err = float((depth - odepth)[dfin].abs().max()) if bool(dfin.any()) else 0.0
-    if err > DEPTH_ATOL:
-        xcost, _, xkappa = exact_batch(batch, sigma)
-        r = noise_and_explained(cost, depth, ocost, odepth, xcost, xkappa)
-        assert r["noise_max_ratio"] <= NOISE_MAX and r["noise_rms_ratio"] <= NOISE_RMS and r["unexplained_m"] == 0.0, (who, err, r)
-    return err
