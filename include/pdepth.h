@@ -39,7 +39,8 @@
  *     (V (2 sum_c var_c + |mu|^2) / sigma * (d_max - d_min) * 2^-23 > 4e-4; the headline workload: 5.6e-5), or whose
  *     features carry trends the centring cannot remove, is evaluated by the gather kernel (the reference's operation
  *     order, PDEPTH_ALGO_DIRECT's kernel) inside the same call: ONE more launch, whose blocks leave at once when no item
- *     is flagged.  The packed entry evaluates every item in the distance form.
+ *     is flagged.  The packed entry of the default kernel evaluates every item in the distance form (it has no fp32
+ *     features to fall back to); the LDS-tiled kernel (L1, C > 72, D > 128, forced selectors) routes on both entries.
  */
 #ifndef PDEPTH_H_
 #define PDEPTH_H_

@@ -34,6 +34,10 @@ struct SweepArgs {
     // = leave at once if queue[PICK_SLOT] != 0, PICK_RUN_IF_SET = leave at once if it is 0.  In the pre-pass: != 0 = compute it.
     int pick;
 };
+// conditioning above which a batch item is routed to the gather kernel (sweep_dist.hip: "Conditioning"; sweep_pack.hip)
+#ifndef PDEPTH_COND_LIMIT
+#define PDEPTH_COND_LIMIT 4.0e-4f
+#endif
 constexpr int PICK_SLOT = 50, PICK_MFMA = 1;          // workspace int behind the tile flags (cleared with them)
 // more of the 64 workspace ints behind the tile flags:
 constexpr int NONCENTRED_SLOT = 51;        // set by the pre-pass of a NOT centred source whose channel offsets exceed the spread (sweep_pack.hip)

@@ -362,12 +362,12 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                     const bool outside = sv > DIST_GUARD_RATIO * sl_ && sv * 10.0f > DIST_GUARD_ENERGY * fabsf(sg);
                     // Conditioning.  Whatever the form, an fp32 cost carries 2^-23 of its own size, and the expected depth moves by
                     // up to the candidates' range times that: where V (2 sum var + |mu|^2) / sigma -- the cost of a sample, inside
-                    // the image and outside it -- times the range times 2^-23 exceeds DIST_COND_LIMIT, two fp32 evaluations agree
+                    // the image and outside it -- times the range times 2^-23 exceeds PDEPTH_COND_LIMIT, two fp32 evaluations agree
                     // to 1e-4 m only if they round alike (the float32 reference itself is then up to 3e-4 m from the exact value:
                     // tests/test_soak_regressions.py).  Headline workload: 5.6e-5, config 5: 2.2e-4; the six soak cases: 5.8e-4
                     // .. 3.5e-3.  Such an item is left to the gather kernel, which rounds like the reference -- where the caller
                     // gave the NCHW source (below); a packed source has nothing to fall back to and takes the fast form.
-                    const bool illcond = (float)KARG(int, a.V) * (2.0f * sv + m2) * (dhi + dlo) * 1.1920929e-7f > DIST_COND_LIMIT * fabsf(sg);
+                    const bool illcond = (float)KARG(int, a.V) * (2.0f * sv + m2) * (dhi + dlo) * 1.1920929e-7f > PDEPTH_COND_LIMIT * fabsf(sg);
                     if (lane == 0) {
                         L.cst[6] = sc; L.cst[7] = ldexpf(refined_rcp(sg), -2 * e);
                         const int pf = reinterpret_cast<const int*>(st + STATS_FLAGS)[0];

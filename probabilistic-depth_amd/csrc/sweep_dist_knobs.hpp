@@ -66,9 +66,6 @@
 #ifndef DIST_GUARD_ENERGY
 #define DIST_GUARD_ENERGY 110.0f   // ... energy x 10 / sigma beyond which an item is evaluated directly (sweep_dist.hip)
 #endif
-#ifndef DIST_COND_LIMIT
-#define DIST_COND_LIMIT 4.0e-4f   // conditioning above which an item is routed to the gather kernel (sweep_dist.hip: "Conditioning")
-#endif
 #ifndef DIST_EXACT_EXP
 #define DIST_EXACT_EXP 0   // 1: geometry.hpp's exp_nonpos (1.5 ulp, 12 instructions) instead of the hardware 2^x on the rounded product
 #endif

@@ -86,6 +86,25 @@ __device__ __forceinline__ void reset_queue_and_guard(int* __restrict__ queue, c
     if (threadIdx.x == 0) queue[NONCENTRED_SLOT] = off > 0.5f * var ? 1 : 0;
 }
 
+// Routing of the LDS-tiled kernel (L2; both entries -- the gather kernel reads the raw features from the NCHW tensor or from the float4
+// copy alike): the conditioning measure of sweep_dist.hip ("Conditioning") per batch item, from
+// the statistics of the pre-pass (the first 80 channels; scaled to C) and this call's candidates and sigma: flag 1 of the item's
+// statistics row != 0 = the tiled kernel leaves the item's tiles to the gather kernel, which rounds like the reference.
+__device__ __forceinline__ void route_ill_conditioned_items(float* __restrict__ stats, const SweepArgs& pa) {
+    for (int b = threadIdx.x; b < pa.B; b += blockDim.x) {
+        float* st = stats + (size_t)b * STATS_STRIDE;
+        float sv = 0.0f, m2 = 0.0f;
+        const int nc = pa.C < STATS_VAR ? pa.C : STATS_VAR;
+        // (|mu|^2: the mean where the pre-pass centres, the squared offset it did NOT subtract where it does not)
+        for (int c = 0; c < nc; ++c) { sv += st[STATS_VAR + c]; m2 += st[c] * st[c] + st[STATS_OFF + c]; }
+        const float scale = (float)pa.C / (float)nc;
+        float dhi = 0.0f, dlo = INFINITY;
+        for (int k = 0; k < pa.D; ++k) { const float d = fabsf(pa.d_candi[k]); dhi = fmaxf(dhi, d); dlo = fminf(dlo, d); }
+        const bool ill = pa.metric == 0 && (float)pa.V * scale * (2.0f * sv + m2) * (dhi - dlo) * 1.1920929e-7f > PDEPTH_COND_LIMIT * fabsf(pa.sigma);
+        reinterpret_cast<int*>(st + STATS_FLAGS)[1] = ill ? 1 : 0;
+    }
+}
+
 // NCHW -> channel-group-planar [C/4 + 2][H][W] float4: plane g < C/4 holds channels 4g .. 4g+3 of every texel minus mu
 // (channels beyond C are zero), and the last two planes hold, for texel (x, y) and with s'(.) ABSENT (zero) outside the image:
 //     plane C/4     : ( <s'(x,y),s'(x,y)>, <s'(x,y),s'(x+1,y)>, <s'(x,y),s'(x,y+1)>, <s'(x,y),s'(x+1,y+1)> + <s'(x+1,y),s'(x,y+1)> )
@@ -106,6 +125,7 @@ __global__ __launch_bounds__(256) void pack_c4_kernel(const float* __restrict__ 
         if (threadIdx.x == 0) queue[PICK_SLOT] = 0;
         __syncthreads();
         if (pa.pick != 0) pick_for_launch(pa, queue, threadIdx.x, 256);
+        if (pa.d_candi != nullptr) route_ill_conditioned_items(const_cast<float*>(stats), pa);   // (a sweep's pre-pass; pdepth_pack_source_f32 has no candidates)
     }
     // XCD-aware block order (workgroups are dealt round-robin over the 8 XCDs): every XCD packs one contiguous band
     // of rows, so the row below -- which another block of the same band loads as its own row -- hits that XCD's L2
@@ -265,10 +285,11 @@ __global__ __launch_bounds__(256) void clear_and_pick_kernel(SweepArgs pa, int* 
     }
 }
 
-// flag clear that keeps the guard slot the pre-pass wrote
-__global__ __launch_bounds__(256) void clear_flags_kernel(int* flags, int nflags, int* queue) {
+// flag clear that keeps the guard slot the pre-pass wrote; the routing flags of the items for THIS call's candidates and sigma
+__global__ __launch_bounds__(256) void clear_flags_kernel(int* flags, int nflags, int* queue, SweepArgs pa, float* stats) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nflags; i += gridDim.x * 256)
         if (flags + i != queue + NONCENTRED_SLOT && flags + i != queue + LAYOUT_SLOT) flags[i] = 0;
+    if (blockIdx.x == 0 && pa.d_candi != nullptr) route_ill_conditioned_items(stats, pa);
 }
 
 size_t flag_only_bytes(int B, int H, int W) {
@@ -367,7 +388,8 @@ hipError_t clear_sweep_flags(const SweepArgs& a, void* workspace, hipStream_t st
     if (a.pick != 0)
         hipLaunchKernelGGL(clear_and_pick_kernel, dim3((nflags + 2047) / 2048), dim3(256), 0, stream, a, reinterpret_cast<int*>(workspace), nflags, queue);
     else
-        hipLaunchKernelGGL(clear_flags_kernel, dim3((nflags + 2047) / 2048), dim3(256), 0, stream, reinterpret_cast<int*>(workspace), nflags, queue);
+        hipLaunchKernelGGL(clear_flags_kernel, dim3((nflags + 2047) / 2048), dim3(256), 0, stream, reinterpret_cast<int*>(workspace), nflags, queue, a,
+                           reinterpret_cast<float*>(static_cast<char*>(workspace) + sweep_ws_stats_offset(a.B, a.V, a.C, a.H, a.W)));
     return hipGetLastError();
 }
 

@@ -182,7 +182,7 @@ namespace PDEPTH_VARIANT {
 template <int METRIC, bool SPEC>
 __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a, const float4* __restrict__ packed,
                                                               int* __restrict__ tile_flags, int* __restrict__ queue,
-                                                              int tiles_x, int ntile) {
+                                                              int tiles_x, int ntile, const float* __restrict__ route_stats) {
     if (PDEPTH_COLD_ARG(int, pick) == PICK_SKIP_IF_SET && queue[PICK_SLOT] != 0) return;   // (the pre-pass chose the other kernel: pick.hpp)
     if (poison_on_foreign_layout(a, queue, LAYOUT_C4)) return;
     const int aD = SPEC ? 64 : a.D, aC = SPEC ? 67 : a.C, aV = SPEC ? 1 : a.V;
@@ -339,7 +339,14 @@ __global__ __launch_bounds__(NT, PDEPTH_OCC) void sweep_tiled_kernel(SweepArgs a
     const float* refb = PDEPTH_COLD_ARG(const float*, ref) + (size_t)b * PDEPTH_COLD_ARG(long long, ref_bstride);
     const v4i ref_rsrc = make_rsrc(refb, aC * HW * 4);
 
+    // Routing (route_stats = the statistics rows; flag 1 set by the pre-pass / flag clear of the call, sweep_pack.hip): an ill-conditioned item
+    // is the gather kernel's, whole -- every tile of it is handed over as a tile whose windows do not fit is
+    const bool routed = route_stats && reinterpret_cast<const int*>(route_stats + (size_t)b * STATS_STRIDE + STATS_FLAGS)[1] != 0;
     for (int v = 0; v < aV; ++v) {
+        if (routed) {   // block-uniform
+            if (lane == 0 && pgl == 0) flag_subtile();
+            goto tile_done;
+        }
         ViewXform xf;
         make_view_xform(PDEPTH_COLD_ARG(const float*, K) + b * 9, PDEPTH_COLD_ARG(const float*, R) + ((size_t)b * aV + v) * 9,
                         PDEPTH_COLD_ARG(const float*, t) + ((size_t)b * aV + v) * 3, PDEPTH_COLD_ARG(int, blas_mode), xf);
@@ -959,6 +966,8 @@ hipError_t PDEPTH_CAT(launch_sweep_tiled_n, PDEPTH_NSUB)(const SweepArgs& a, voi
     const long long full = 8ll * ((tiles + 7) / 8) * a.B;  // one block per item of the largest XCD band, times 8
     if (full <= nblk) nblk = (int)full;
     dim3 grid(nblk);
+    // (routing: the pre-pass / the flag clear of this call has set flag 1 of the statistics row of every ill-conditioned item)
+    const float* route_stats = reinterpret_cast<const float*>(static_cast<char*>(workspace) + sweep_ws_stats_offset(a.B, a.V, a.C, a.H, a.W));
     // (the dynamic-LDS attribute is per kernel, sticky and the same on every device: set it whenever more than the
     //  default is needed -- no cached state, and a failure is reported instead of surfacing as a launch error)
     if (phases & PH_KERNEL) {
@@ -968,21 +977,21 @@ hipError_t PDEPTH_CAT(launch_sweep_tiled_n, PDEPTH_NSUB)(const SweepArgs& a, voi
             e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles);
+        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles, route_stats);
     } else if (a.metric == 0) {
         auto kern = PDEPTH_VARIANT::sweep_tiled_kernel<0, false>;
         if (lds > 64 * 1024) {
             e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles);
+        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles, route_stats);
     } else {
         auto kern = PDEPTH_VARIANT::sweep_tiled_kernel<1, false>;
         if (lds > 64 * 1024) {
             e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles);
+        hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, a, packed, flags, queue, tiles_x, tiles, route_stats);
     }
     }
     e = hipGetLastError();

@@ -82,7 +82,7 @@ def test_soak_worst_case_against_the_whole_image_oracle(dev, soak, log, seed, sp
                cost_max=float(xcost[torch.isfinite(xcost)].abs().max()),
                oracle_vs_exact=dict(max_m=float(oe.max()), over_1e4=int((oe > DEPTH_ATOL).sum())))
     res = {}
-    for algo in ("auto", "direct"):
+    for algo in ("auto", "tiled1", "direct"):
         cost, _, depth = ops.sweep_dpv(*args, feat_dist="L2", algo=algo, want_cost=True)
         cost, depth = cost.cpu(), depth.cpu()
         if algo == "auto":
@@ -100,4 +100,6 @@ def test_soak_worst_case_against_the_whole_image_oracle(dev, soak, log, seed, sp
     # go to the gather kernel -- the north star as it stands, for every selector
     a = res["auto"]
     assert a["max_m"] <= DEPTH_ATOL, f"{tag}: auto is {a['max_m']:.3e} m from the whole-image oracle"
+    # ... and so does the LDS-tiled kernel (what `auto` runs for the L1 metric, C > 72, D > 128), whose pre-pass applies the same measure
+    assert res["tiled1"]["max_m"] <= DEPTH_ATOL, f"{tag}: tiled1 is {res['tiled1']['max_m']:.3e} m from the whole-image oracle"
     assert row["auto_blocks_off_the_fast_path"] > 0, f"{tag}: not routed"
