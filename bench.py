@@ -275,8 +275,12 @@ def main():
     # reference's op order) on the same batch.
     workloads = {}
     if not a.no_workloads and not a.no_secondary and a.algo in ("auto", "dist") and rank == 0 and not a.config:
-        def shard(name, Bs, D, H, W, V, pose, steps, offset=0.0):
+        def shard(name, Bs, D, H, W, V, pose, steps, offset=0.0, smooth=0):
             bs = synth.make_batch(2, Bs, C=cfg["C"], D=D, H=H, W=W, V=V, pose=pose)
+            if smooth:   # spatially smooth features (box filter, unit variance again): what the trend guard looks at
+                blur = lambda x: torch.nn.functional.avg_pool2d(x, smooth, 1, smooth // 2, count_include_pad=False)
+                r, sr = blur(bs["ref"]), blur(bs["src"].flatten(0, 1)).view_as(bs["src"])
+                bs["ref"], bs["src"] = r / r.std(), sr / sr.std()
             if offset:   # per-channel offsets, the same in every view: costs of hundreds where a tap leaves the image
                 mu = (torch.rand(cfg["C"], generator=torch.Generator().manual_seed(5)) * 2 - 1) * offset
                 bs["ref"] += mu[None, :, None, None]
@@ -309,6 +313,9 @@ def main():
                                             2, 128, 512, 1024, 4, "mono", max(3, a.steps // 4))
             # the perf cliff of the default selector, in the open: features whose channel means are 6 sigma off zero make an
             # item ill-conditioned by the kernel's measure (csrc/sweep_dist.hip: "Conditioning"); every item is then the gather kernel's
+            workloads["cfg2_smooth"] = shard("the headline shape with spatially smooth features (33x33 box filter of N(0,1), unit variance: var / lag-16 spread -- "
+                                             "the trend guard's ratio -- is 2, the energy against sigma is small): the fast form, nothing routed",
+                                             hi - lo, cfg["D"], cfg["H"], cfg["W"], cfg["V"], a.pose, max(3, a.steps // 2), smooth=33)
             workloads["cfg2_routed"] = shard("the headline shape with per-channel offsets of up to 6 sigma: every item routed to the gather kernel "
                                              "(direct_passes = pixel blocks routed)", hi - lo, cfg["D"], cfg["H"], cfg["W"], cfg["V"], a.pose,
                                              max(3, a.steps // 4), offset=6.0)

@@ -84,6 +84,10 @@ struct ViewSource {
 // cell corners loaded separately) issued 4 loads per channel and texel, this one (ROWS + 1) / ROWS.  Where a row of the padded image ends inside a wave, the "neighbour" a lane gets belongs to the
 // next row's first texel: both lie in the ring (x = W + 1 or beyond, x = -1), both hold the zero feature vector.
 
+// waves per SIMD the pack kernel is compiled for (4: 128 VGPRs)
+#ifndef PDEPTH_PACK_OCC
+#define PDEPTH_PACK_OCC 4
+#endif
 #if PDEPTH_PACK_NT_STORE
 #define PACK_ST(T, p, v) __builtin_nontemporal_store((v), reinterpret_cast<T*>(p))
 #else
@@ -393,7 +397,7 @@ __device__ __forceinline__ void fused_stats(const float* __restrict__ src, long 
 }
 
 template <int NCHK, int ROWS, bool SPLIT>
-__global__ __launch_bounds__(256, 4) void pack_dist_kernel(const float* __restrict__ src, long long bstride, long long vstride, int V, int C,
+__global__ __launch_bounds__(256, PDEPTH_PACK_OCC) void pack_dist_kernel(const float* __restrict__ src, long long bstride, long long vstride, int V, int C,
                                                         int H, int W, char* __restrict__ out, int* __restrict__ flags, int nflags,
                                                         int* queue, float* __restrict__ stats, const float* __restrict__ ref, long long ref_bstride,
                                                         int B, int tag) {

@@ -20,6 +20,8 @@ def test_committed_bench_line_of_round_6():
     assert "configs[2]" in w["cfg3_shard"]["workload"] and "configs[4]" in w["cfg5_share"]["workload"]
     assert w["cfg5_share"]["ms_per_call"] / w["cfg5_share"]["B"] < 2.3
     # the routed workload: every pixel block of every item left to the gather kernel, whose answer it then is
+    sm = w["cfg2_smooth"]   # smooth features at unit variance: the fast form, within the north star of the gather kernel
+    assert sm["direct_passes"] == 0 and sm["max_abs_depth_diff_vs_gather"] <= 1e-4 and sm["ms_per_call"] < 1.3 * line["ms_per_step"]
     r = w["cfg2_routed"]
     assert r["direct_passes"] == r["B"] * 256 * 512 // 16 and r["max_abs_depth_diff_vs_gather"] == 0.0 and r["ms_per_call"] > line["ms_per_step"]
     for key in ("B1_nchw", "B1_packed", "B4_nchw", "B4_packed"):
