@@ -413,16 +413,30 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
             }
             float rr = 0.0f, zc = 0.0f;    // |r'|^2 and |r|^2 of the pixel, scaled (set with the first pass)
             bool centred = false;
-            unsigned failmask = 0;         // uniform over the workgroup: passes (view v, plane group h) left to the direct evaluation
+            unsigned failmask = 0;         // uniform over the workgroup: half-passes (view v, plane group h, waves 0-1 | 2-3) left to the direct evaluation
             float cost[NC];
 #pragma unroll
             for (int j = 0; j < NC; ++j) cost[j] = 0.0f;
 
+            constexpr bool RETRY = NH == 2;   // (passes that do not fit are run again in halves: below)
             for (int v = 0; v < V; ++v) {
-                const char* srcv = KARG(const char*, packed) + (size_t)((size_t)b * V + v) * dist::view_bytes(C, H, W);
+                // (NH = 1: the view's address formed once per view, as the straight-line pass always had it)
+                const char* const srcv_v = RETRY ? nullptr : KARG(const char*, packed) + (size_t)((size_t)b * V + v) * dist::view_bytes(C, H, W);
+                const int H_ = H, W_ = W, C_ = C, D_ = D;
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
                     if (!item_ready) { PDEPTH_LDS_BARRIER(); item_ready = true; }   // (the item's tables above are in LDS)
+                    // A pass whose texel blocks do not fit the workgroup's LDS (nb > MAXB: the large windows of a forward motion at D >
+                    // 64) is run again as two HALF-passes -- the planes of waves 0-1, then those of waves 2-3: half the planes
+                    // touch about half the rows --, and only a half that still does not fit is left to the direct evaluation
+                    // (config 5: 1 482 whole passes were, 0.1 of its 3.45 ms).  attempt 0: all planes; 1, 2: the halves.  (The
+                    // positions are worked out again per attempt: kept across the attempts they were four registers too many.)
+                    // At D > 64 only (RETRY): around the pass of the D <= 64 instantiations -- whose passes fit -- the loop cost 1.7 %.
+                    int attempt = 0;
+                    for (;;) {
+                    const bool mine = attempt == 0 || (wave >> 1) == attempt - 1;   // (wave-uniform: this wave's planes are in)
+                    // (the shapes, re-read per attempt: held from the top of the item across the passes they were spilled scalars)
+                    const int H = RETRY ? KARG(int, a.H) : H_, W = RETRY ? KARG(int, a.W) : W_, C = RETRY ? KARG(int, a.C) : C_, D = RETRY ? KARG(int, a.D) : D_;
                     // ---- sample positions of this thread's planes of the pass (NO_CELL: no tap in the image, plane beyond D,
                     //      pixel beyond the image)
                     int cell[4];
@@ -449,7 +463,7 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                             //  half of a result in lanes 48..63 beside v_mfma_f32_16x16x32_f16 on gfx950: wave_util.hpp)
                             plane_sample_pos_fast(xf, t2a, t2b, t2c, dk[j], c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ix, iy);
                             cell[j] = cell_of(ix, iy, W, H, fw[j], fn[j]);
-                            if (k >= D || !xlive) cell[j] = NO_CELL;
+                            if (k >= D || !xlive || !mine) cell[j] = NO_CELL;
                             if (DIST_ABL & 1) {   // timing only: the position chain a second time (how much of the kernel is vector issue?)
                                 float ix2, iy2, f2, g2;
                                 plane_sample_pos_fast(xf, t2a, t2b, t2c, dk[j] * 1.0001f, c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, ix2, iy2);
@@ -599,6 +613,8 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                         constexpr int PB = dist::GROUP_PLANE_BYTES, GB = (8 * NCHK + 4) * PB;   // (= dist::group_bytes(C): nchk(C) = NCHK)
                         const int Wp = dist::wp(W);
                         const int ntex = (n / dist::GROUP) * GB + (n % dist::GROUP) * 16;
+                        // (the view's address: formed here, per pass -- across the pass and its attempts it was three spilled scalars)
+                        const char* srcv = RETRY ? KARG(const char*, packed) + (size_t)((size_t)b * KARG(int, a.V) + v) * dist::view_bytes(C, H, W) : srcv_v;
                         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)srcv, 0, (int)dist::view_bytes(C, H, W), 0x00020000);
                         const int voffA = opaque_v(ntex + kq * PB);
                         // a block's texel operands in consumption order: (high c, low c) for c < NCHK, tail; NS register sets: NS
@@ -715,9 +731,9 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                     }
 
                     // ---- combine: cost of this thread's planes of the pass ---------------------------------------------
-                    if (!fits) {   // (evaluated directly behind the view loop)
-                        failmask |= 1u << (v * NH + h);
-                    } else {
+                    if (!fits) {   // (a half: evaluated directly behind the view loop; the whole pass: again, in halves)
+                        if (attempt != 0) failmask |= 1u << ((v * NH + h) * 2 + attempt - 1);
+                    } else if (attempt == 0 || (wave >> 1) == attempt - 1) {   // (`mine`, formed again: kept from the top of the attempt it is a lane mask in two scalar registers)
                         const float cinv = L.cst[7];
                         const float* yr = &L.Ys[n * XSTRIDE + (n >> 3) * DIST_YSKEW];
 #pragma unroll
@@ -741,11 +757,26 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                         }
                     }
                     DSTAMP(9)   // combine
+                    if (!RETRY) {   // (D <= 64: straight-line, a pass that does not fit goes to the direct evaluation whole)
+                        if (!fits) failmask |= 3u << ((v * NH + h) * 2);
+                        break;
+                    }
+                    if (attempt == 0) {
+                        if (fits) break;
+                        if ((iflag & 3) != 0 || DIST_FORCE_DIRECT == -1 || DIST_FORCE_DIRECT == v) {   // (no half of this item fits either)
+                            failmask |= 3u << ((v * NH + h) * 2);
+                            break;
+                        }
+                    } else if (attempt == 2) {
+                        break;
+                    }
+                    ++attempt;
+                    }   // attempts
                 }
             }
 
             if (failmask != 0) {   // uniform
-                // Passes left to the direct evaluation: the reference's own form on the packed features -- per plane the four
+                // Half-passes left to the direct evaluation: the reference's own form on the packed features -- per plane the four
                 // taps of every group of 8 channels by two 16-byte loads each (high + low parts), the pixel's centred reference
                 // features from the operand image in LDS.  An item whose features did not fit the fp16 range: NaN.
                 // (the shapes re-read here: kept from the top of the item for this rarely run block, they were spilled scalars)
@@ -755,10 +786,11 @@ __global__ __launch_bounds__(256, NH == 1 ? DIST_OCC1 : DIST_OCC2) void sweep_di
                 const bool ovf = (L.iflag & 1) != 0;
                 (void)0;
 #pragma unroll 1
-                for (int vh = 0; vh < V * NH; ++vh) {
-                    if (!(failmask >> vh & 1u)) continue;
+                for (int vhh = 0; vhh < V * NH * 2; ++vhh) {
+                    if (!(failmask >> vhh & 1u)) continue;
                     if (tid == 0) ++n_direct;
-                    const int v = vh / NH, h = vh - v * NH;
+                    if ((wave >> 1) != (vhh & 1)) continue;   // (the planes of the other pair of waves; no barrier in this loop)
+                    const int vh = vhh >> 1, v = vh / NH, h = vh - v * NH;
                     ViewXform xf;
 #pragma unroll
                     for (int i = 0; i < 9; ++i) xf.kr[i] = L.xf[v * 12 + i];
