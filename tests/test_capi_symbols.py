@@ -188,3 +188,13 @@ def test_workspace_size_is_the_one_the_header_states():
         stats = 496 * 4 * B
         want = packed + flags + stats
         assert want <= got <= want + 4 * 256, (B, V, C, D, H, W, got, want)
+
+
+def test_graft_entry_checks_the_current_abi():
+    """__graft_entry__.build() asserts the library's ABI number: it must be the header's (a stale number fails the driver's
+    build check while every test is green -- it happened in round 6)."""
+    h = open(os.path.join(REPO, "include", "pdepth.h")).read()
+    ver = int(re.search(r"#define PDEPTH_ABI_VERSION (\d+)", h).group(1))
+    entry = open(os.path.join(REPO, "__graft_entry__.py")).read()
+    assert f"pdepth_abi_version() == {ver}" in entry
+    assert _native.load().pdepth_abi_version() == ver
