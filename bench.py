@@ -361,7 +361,8 @@ def main():
                 "traffic_source": prof.get("source"),
                 "traffic_collected": prof.get("collected"),
                 "kernel": ("fused sweep+DPV call = feature_stats_kernel + pack_dist_kernel (pre-pass: channel statistics, centred fp16 re-layout "
-                           "+ neighbour differences) + " + kname if impl == "dist" else
+                           "+ neighbour differences) + " + kname + " + sweep_direct_kernel in per-item mode (the gather kernel for the items the "
+                           "sweep routes to it: none on this workload, its blocks read one flag and leave)" if impl == "dist" else
                            "fused sweep+DPV call = feature_stats_kernel + pack_c4_kernel (pre-pass: channel means, centred re-layout) + " + kname
                            if impl == "corr" else
                            "fused sweep+DPV call = feature_stats_kernel + pack_c4_kernel (source re-layout pre-pass) + " + kname +
