@@ -38,6 +38,11 @@ struct SweepArgs {
 #ifndef PDEPTH_COND_LIMIT
 #define PDEPTH_COND_LIMIT 4.0e-4f
 #endif
+// ... for the LDS-tiled kernel, whose correlation-form plane group is noisier than the distance form (soak 9107: 1.04e-4 /
+// 1.09e-4 m, scaled, at 2.0e-4 / 2.3e-4 of this measure on unit-variance features, V = 3)
+#ifndef PDEPTH_COND_LIMIT_TILED
+#define PDEPTH_COND_LIMIT_TILED 1.5e-4f
+#endif
 constexpr int PICK_SLOT = 50, PICK_MFMA = 1;          // workspace int behind the tile flags (cleared with them)
 // more of the 64 workspace ints behind the tile flags:
 constexpr int NONCENTRED_SLOT = 51;        // set by the pre-pass of a NOT centred source whose channel offsets exceed the spread (sweep_pack.hip)

@@ -100,7 +100,7 @@ __device__ __forceinline__ void route_ill_conditioned_items(float* __restrict__ 
         const float scale = (float)pa.C / (float)nc;
         float dhi = 0.0f, dlo = INFINITY;
         for (int k = 0; k < pa.D; ++k) { const float d = fabsf(pa.d_candi[k]); dhi = fmaxf(dhi, d); dlo = fminf(dlo, d); }
-        const bool ill = pa.metric == 0 && (float)pa.V * scale * (2.0f * sv + m2) * (dhi - dlo) * 1.1920929e-7f > PDEPTH_COND_LIMIT * fabsf(pa.sigma);
+        const bool ill = pa.metric == 0 && (float)pa.V * scale * (2.0f * sv + m2) * (dhi - dlo) * 1.1920929e-7f > PDEPTH_COND_LIMIT_TILED * fabsf(pa.sigma);
         reinterpret_cast<int*>(st + STATS_FLAGS)[1] = ill ? 1 : 0;
     }
 }
