@@ -76,3 +76,25 @@ def test_queue_pop_is_not_read_back_at_once(listing):
         assert pops, name
         late = [i for i in pops if not any(x.startswith("s_waitcnt vmcnt(0)") for x in ins[i + 1:i + 4])]
         assert late, (name, "every returning atomic of the kernel is waited for at once: -amdgpu-atomic-optimizer-strategy=None lost?")
+
+
+def test_pack_kernel_keeps_four_waves_per_simd_without_spills():
+    """pack_dist_kernel (the NCHW entry's pre-pass, launch bound 4 waves per SIMD): <= 128 registers, nothing spilled, no scratch --
+    the whole-line stores of the group-major layout (pack_store_pair) cost eight registers; a spill here would sit in a kernel
+    that runs at memory speed."""
+    if shutil.which("make") is None or not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc here")
+    r = subprocess.run(["make", "-C", CSRC, "pack_dist.s"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(os.path.join(CSRC, "pack_dist.s")).read()
+    seen = 0
+    for m in re.finditer(r"- \.agpr_count:.*?\.wavefront_size:\s+\d+", text, re.S):
+        block = m.group(0)
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        md = {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)\s*$", block, re.M)}
+        if "pack_dist_kernel" in name:
+            seen += 1
+            assert md["vgpr_count"] <= 128 and md["vgpr_spill_count"] == 0 and md["sgpr_spill_count"] == 0 and md["private_segment_fixed_size"] == 0, (name, md)
+        elif "pack_views_dist_kernel" in name:
+            assert md["vgpr_spill_count"] == 0 and md["private_segment_fixed_size"] == 0, (name, md)
+    assert seen == 6, seen

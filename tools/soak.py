@@ -165,6 +165,8 @@ def main():
     n = fb = 0
     for case in range(cases):
         s, b = draw_case(rng, case, build=only is None or case in only)
+        if case % 500 == 499 and only is None:
+            print("... case", case + 1, "worst so far", worst, flush=True)   # (a GPU run that stays silent for seven minutes is taken to be hung)
         if b is None:
             continue
         d = {kk: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for kk, v in b.items()}
